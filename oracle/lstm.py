@@ -1,0 +1,246 @@
+"""Oracle: LSTM / BiLSTM / TimeDistributed(Dense) forward + BPTT, and the
+ctc_model() loss graph.  TEST INFRASTRUCTURE ONLY.
+
+Follows core/layers.py:432-469 (``LSTM.step``: fused (in,4H)/(H,4H) matmuls,
+column blocks i,f,c,o; variational masks B_W/B_U multiply x / h before the
+matmul), core/models.py:31-52 (ctc_model wiring) and core/models.py:217-281
+(brsmv1: L x Bidirectional(LSTM) concat -> TimeDistributed(Dense), l2 on W/U and
+the Dense kernel).  The enclosing machinery is keras==1.2.2 (msc.yaml:89), which
+is NOT under /root/reference: PARITY UNPINNED by the reference.  Recalled Keras
+semantics restated here:
+
+* inner_activation = hard_sigmoid = clip(0.2 x + 0.5, 0, 1); activation = tanh;
+* h0 = c0 = 0; b initialised 0 with the forget block = 1;
+* Bidirectional(concat): the backward copy consumes the PADDED batch from T-1
+  down to 0 (no Masking layer is applied, core/models.py:20 imports it unused),
+  its outputs are reversed back and concatenated [fwd, bwd] on the feature axis;
+* loss = mean_n ctc_n + sum l2 * sum(w^2)  (loss_weights [1, 0], train.py:140-143).
+
+All tensors are time-major (T, N, .) -- the reference's (N, T, .) transposed.
+Cross-checked against torch.autograd in tests/test_oracle_lstm.py.
+"""
+import numpy as np
+
+from . import ctc as _ctc
+
+
+def hard_sigmoid(x):
+    return np.clip(0.2 * x + 0.5, 0.0, 1.0)
+
+
+def hard_sigmoid_grad(x):
+    y = 0.2 * x + 0.5
+    return np.where((y >= 0.0) & (y <= 1.0), 0.2, 0.0).astype(x.dtype)
+
+
+def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None):
+    """One direction.  x (T,N,in); W (in,4H); U (H,4H); b (4H).
+
+    BW (N,in) / BU (N,H): variational dropout masks (already scaled by 1/(1-p))
+    or None.  Returns (h_seq (T,N,H), cache).
+    """
+    T, N, _ = x.shape
+    H = U.shape[0]
+    dt = x.dtype
+    xs = x if BW is None else x * BW[None]
+    h = np.zeros((N, H), dt)
+    c = np.zeros((N, H), dt)
+    hs = np.zeros((T, N, H), dt)
+    cs = np.zeros((T, N, H), dt)
+    gates = np.zeros((T, N, 4 * H), dt)     # post-activation i,f,g,o
+    zs = np.zeros((T, N, 4 * H), dt)        # pre-activation
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        hm = h if BU is None else h * BU
+        z = xs[t] @ W + hm @ U + b
+        i = hard_sigmoid(z[:, :H])
+        f = hard_sigmoid(z[:, H:2 * H])
+        g = np.tanh(z[:, 2 * H:3 * H])
+        o = hard_sigmoid(z[:, 3 * H:])
+        c = f * c + i * g
+        h = o * np.tanh(c)
+        hs[t], cs[t], zs[t] = h, c, z
+        gates[t] = np.concatenate([i, f, g, o], axis=1)
+    cache = dict(x=x, xs=xs, W=W, U=U, BW=BW, BU=BU, hs=hs, cs=cs, zs=zs,
+                 gates=gates, reverse=reverse)
+    return hs, cache
+
+
+def lstm_backward(dhs, cache):
+    """BPTT for one direction.  dhs (T,N,H) -> dx, dW, dU, db."""
+    x, xs, W, U = cache['x'], cache['xs'], cache['W'], cache['U']
+    BW, BU = cache['BW'], cache['BU']
+    hs, cs, zs, gates = cache['hs'], cache['cs'], cache['zs'], cache['gates']
+    reverse = cache['reverse']
+    T, N, H = hs.shape
+    dt = x.dtype
+    dW = np.zeros_like(W); dU = np.zeros_like(U); db = np.zeros(4 * H, dt)
+    dxs = np.zeros_like(xs)
+    dh_next = np.zeros((N, H), dt)
+    dc_next = np.zeros((N, H), dt)
+    order = list(range(T - 1, -1, -1) if reverse else range(T))
+    for k in range(T - 1, -1, -1):
+        t = order[k]
+        tp = order[k - 1] if k > 0 else None
+        h_prev = hs[tp] if tp is not None else np.zeros((N, H), dt)
+        c_prev = cs[tp] if tp is not None else np.zeros((N, H), dt)
+        i, f = gates[t][:, :H], gates[t][:, H:2 * H]
+        g, o = gates[t][:, 2 * H:3 * H], gates[t][:, 3 * H:]
+        z = zs[t]
+        dh = dhs[t] + dh_next
+        tc = np.tanh(cs[t])
+        do = dh * tc
+        dc = dc_next + dh * o * (1.0 - tc * tc)
+        di, dg, df = dc * g, dc * i, dc * c_prev
+        dc_next = dc * f
+        dz = np.concatenate([
+            di * hard_sigmoid_grad(z[:, :H]),
+            df * hard_sigmoid_grad(z[:, H:2 * H]),
+            dg * (1.0 - g * g),
+            do * hard_sigmoid_grad(z[:, 3 * H:])], axis=1)
+        hm = h_prev if BU is None else h_prev * BU
+        dW += xs[t].T @ dz
+        dU += hm.T @ dz
+        db += dz.sum(axis=0)
+        dxs[t] = dz @ W.T
+        dhm = dz @ U.T
+        dh_next = dhm if BU is None else dhm * BU
+    dx = dxs if BW is None else dxs * BW[None]
+    return dx, dW, dU, db
+
+
+def init_lstm(rs, n_in, H, dtype=np.float32):
+    """Keras-1.2.2 consume_less='gpu' init [recalled, SURVEY.md a17]: W
+    glorot_uniform over the fused (in,4H) shape, U(+-sqrt(6/(in+4H))); U
+    orthogonal over the fused (H,4H) shape (SVD of a normal matrix, the factor
+    whose shape matches, gain 1.1); b zeros with the f block = 1."""
+    lim = np.sqrt(6.0 / (n_in + 4 * H))
+    W = rs.uniform(-lim, lim, size=(n_in, 4 * H))
+    a = rs.normal(0.0, 1.0, (H, 4 * H))
+    u, _, v = np.linalg.svd(a, full_matrices=False)
+    U = 1.1 * (u if u.shape == (H, 4 * H) else v)
+    b = np.zeros(4 * H); b[H:2 * H] = 1.0
+    return dict(W=W.astype(dtype), U=U.astype(dtype), b=b.astype(dtype))
+
+
+def init_dense(rs, n_in, n_out, dtype=np.float32):
+    lim = np.sqrt(6.0 / (n_in + n_out))
+    return dict(W=rs.uniform(-lim, lim, size=(n_in, n_out)).astype(dtype),
+                b=np.zeros(n_out, dtype))
+
+
+def init_model(seed=0, num_features=39, num_hiddens=256, num_layers=5,
+               num_classes=28, dtype=np.float32, in_dense=None):
+    """Parameter pytree for brsmv1 / graves2006 (in_dense=None) or eyben."""
+    rs = np.random.RandomState(seed)
+    params = {'layers': []}
+    n_in = num_features
+    if in_dense:
+        params['in_dense'] = init_dense(rs, n_in, in_dense, dtype)
+        n_in = in_dense
+    hid = num_hiddens if isinstance(num_hiddens, (list, tuple)) \
+        else [num_hiddens] * num_layers
+    for H in hid:
+        params['layers'].append({'fwd': init_lstm(rs, n_in, H, dtype),
+                                 'bwd': init_lstm(rs, n_in, H, dtype)})
+        n_in = 2 * H
+    params['dense'] = init_dense(rs, n_in, num_classes, dtype)
+    return params
+
+
+def model_forward(params, x, masks=None):
+    """x (T,N,F) -> logits (T,N,C), caches.  masks[l][dir] = (BW, BU) or None."""
+    caches = {'layers': []}
+    o = x
+    if 'in_dense' in params:
+        caches['in_dense_x'] = o
+        o = o @ params['in_dense']['W'] + params['in_dense']['b']
+    for li, layer in enumerate(params['layers']):
+        outs, lc = [], {}
+        for dname, rev in (('fwd', False), ('bwd', True)):
+            p = layer[dname]
+            BW = BU = None
+            if masks is not None and masks[li] is not None:
+                BW, BU = masks[li][dname]
+            hs, cache = lstm_forward(o, p['W'], p['U'], p['b'], rev, BW, BU)
+            outs.append(hs); lc[dname] = cache
+        caches['layers'].append(lc)
+        o = np.concatenate(outs, axis=-1)
+    caches['dense_x'] = o
+    logits = o @ params['dense']['W'] + params['dense']['b']
+    return logits, caches
+
+
+def model_backward(params, caches, dlogits):
+    grads = {'layers': [None] * len(params['layers'])}
+    xd = caches['dense_x']
+    T, N, D = xd.shape
+    grads['dense'] = {'W': xd.reshape(T * N, D).T @ dlogits.reshape(T * N, -1),
+                      'b': dlogits.sum(axis=(0, 1))}
+    do = dlogits @ params['dense']['W'].T
+    for li in range(len(params['layers']) - 1, -1, -1):
+        H = params['layers'][li]['fwd']['U'].shape[0]
+        g = {}
+        dx_total = None
+        for dname, sl in (('fwd', slice(0, H)), ('bwd', slice(H, 2 * H))):
+            dx, dW, dU, db = lstm_backward(np.ascontiguousarray(do[..., sl]),
+                                           caches['layers'][li][dname])
+            g[dname] = {'W': dW, 'U': dU, 'b': db}
+            dx_total = dx if dx_total is None else dx_total + dx
+        grads['layers'][li] = g
+        do = dx_total
+    if 'in_dense' in params:
+        xi = caches['in_dense_x']
+        T, N, D = xi.shape
+        grads['in_dense'] = {'W': xi.reshape(T * N, D).T @ do.reshape(T * N, -1),
+                             'b': do.sum(axis=(0, 1))}
+        do = do @ params['in_dense']['W'].T
+    grads['input'] = do
+    return grads
+
+
+def l2_penalty(params, weight_decay, in_dense_l2=False):
+    """sum_w weight_decay * sum(w^2) over LSTM W,U and the output Dense kernel
+    (core/models.py:263-264,279)."""
+    tot = 0.0
+    if weight_decay:
+        for layer in params['layers']:
+            for d in ('fwd', 'bwd'):
+                tot += weight_decay * (np.sum(layer[d]['W'].astype(np.float64) ** 2) +
+                                       np.sum(layer[d]['U'].astype(np.float64) ** 2))
+        tot += weight_decay * np.sum(params['dense']['W'].astype(np.float64) ** 2)
+    return tot
+
+
+def loss_and_grads(params, x, labels, seq_len, weight_decay=0.0, masks=None):
+    """ctc_model() training objective and its gradients.
+
+    Returns dict(loss (scalar: mean ctc + l2), ctc (N,), logits, grads).
+    """
+    logits, caches = model_forward(params, x, masks)
+    T, N, C = logits.shape
+    ctc_n, dlog = _ctc.ctc_loss_grad(logits, labels, seq_len, dtype=logits.dtype)
+    dlog = dlog / N                       # mean over the batch
+    grads = model_backward(params, caches, dlog.astype(logits.dtype))
+    if weight_decay:
+        for li, layer in enumerate(params['layers']):
+            for d in ('fwd', 'bwd'):
+                grads['layers'][li][d]['W'] += 2 * weight_decay * layer[d]['W']
+                grads['layers'][li][d]['U'] += 2 * weight_decay * layer[d]['U']
+        grads['dense']['W'] += 2 * weight_decay * params['dense']['W']
+    loss = float(np.mean(ctc_n)) + l2_penalty(params, weight_decay)
+    return dict(loss=loss, ctc=ctc_n, logits=logits, grads=grads, caches=caches)
+
+
+def flatten(tree):
+    """Deterministic flat list of (name, array) in checkpoint order."""
+    out = []
+    if 'in_dense' in tree:
+        out += [('in_dense/W', tree['in_dense']['W']),
+                ('in_dense/b', tree['in_dense']['b'])]
+    for li, layer in enumerate(tree['layers']):
+        for d in ('fwd', 'bwd'):
+            for k in ('W', 'U', 'b'):
+                out.append(('layer%d/%s/%s' % (li, d, k), layer[d][k]))
+    out += [('dense/W', tree['dense']['W']), ('dense/b', tree['dense']['b'])]
+    return out

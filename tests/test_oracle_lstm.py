@@ -1,0 +1,122 @@
+"""oracle/lstm.py BPTT against torch.autograd over the same plain tensor ops."""
+import numpy as np
+import torch
+
+from oracle import lstm as L
+from oracle import ctc as C
+
+
+def _torch_model(params, x, masks=None):
+    def hs(v):
+        return torch.clamp(0.2 * v + 0.5, 0.0, 1.0)
+
+    def run(o, p, rev, BW, BU):
+        T, N, _ = o.shape
+        H = p['U'].shape[0]
+        h = torch.zeros(N, H, dtype=o.dtype); c = torch.zeros(N, H, dtype=o.dtype)
+        outs = [None] * T
+        for t in (range(T - 1, -1, -1) if rev else range(T)):
+            xt = o[t] if BW is None else o[t] * BW
+            hm = h if BU is None else h * BU
+            z = xt @ p['W'] + hm @ p['U'] + p['b']
+            i, f = hs(z[:, :H]), hs(z[:, H:2 * H])
+            g, oo = torch.tanh(z[:, 2 * H:3 * H]), hs(z[:, 3 * H:])
+            c = f * c + i * g
+            h = oo * torch.tanh(c)
+            outs[t] = h
+        return torch.stack(outs)
+
+    o = x
+    if 'in_dense' in params:
+        o = o @ params['in_dense']['W'] + params['in_dense']['b']
+    for li, layer in enumerate(params['layers']):
+        outs = []
+        for d, rev in (('fwd', False), ('bwd', True)):
+            BW = BU = None
+            if masks is not None:
+                BW, BU = [torch.tensor(m) for m in masks[li][d]]
+            outs.append(run(o, layer[d], rev, BW, BU))
+        o = torch.cat(outs, -1)
+    return o @ params['dense']['W'] + params['dense']['b']
+
+
+def _to_torch(tree):
+    if isinstance(tree, dict):
+        return {k: _to_torch(v) for k, v in tree.items()}
+    if isinstance(tree, list):
+        return [_to_torch(v) for v in tree]
+    return torch.tensor(tree, dtype=torch.float64, requires_grad=True)
+
+
+def _check(in_dense, use_masks):
+    rs = np.random.RandomState(3)
+    T, N, F, H, Cc = 13, 3, 5, 4, 6
+    params = L.init_model(seed=1, num_features=F, num_hiddens=H, num_layers=2,
+                          num_classes=Cc, dtype=np.float64, in_dense=in_dense)
+    # make biases / weights generic (exercise every gradient path)
+    for name, a in L.flatten(params):
+        a += rs.randn(*a.shape) * 0.3
+    x = rs.randn(T, N, F)
+    x[9:, 1] = 0.0                                   # padded tail of sample 1
+    seq_len = [T, 9, T]
+    labels = [[0, 1, 1], [2], [4, 3, 0, 0]]
+    masks = None
+    if use_masks:
+        masks = []
+        n_in = in_dense or F
+        for li in range(2):
+            m = {}
+            for d in ('fwd', 'bwd'):
+                m[d] = ((rs.rand(N, n_in) > 0.2) / 0.8, (rs.rand(N, H) > 0.2) / 0.8)
+            masks.append(m)
+            n_in = 2 * H
+    wd = 1e-2
+    out = L.loss_and_grads(params, x, labels, seq_len, weight_decay=wd, masks=masks)
+
+    tp = _to_torch(params)
+    logits = _torch_model(tp, torch.tensor(x), masks)
+    lp = torch.log_softmax(logits, -1)
+    tgt = torch.tensor(sum(labels, []))
+    ctc = torch.nn.functional.ctc_loss(lp, tgt, torch.tensor(seq_len),
+                                       torch.tensor([len(l) for l in labels]),
+                                       blank=Cc - 1, reduction='none')
+    l2 = sum((tp['layers'][li][d][k] ** 2).sum() for li in range(2)
+             for d in ('fwd', 'bwd') for k in ('W', 'U')) + (tp['dense']['W'] ** 2).sum()
+    loss = ctc.mean() + wd * l2
+    loss.backward()
+    np.testing.assert_allclose(out['logits'], logits.detach().numpy(), atol=1e-12)
+    np.testing.assert_allclose(out['loss'], float(loss.detach()), rtol=1e-12)
+    for (name, g), (_, tg) in zip(L.flatten(out['grads']), L.flatten(tp)):
+        np.testing.assert_allclose(g, tg.grad.numpy(), atol=1e-10, err_msg=name)
+
+
+def test_bptt_matches_autograd_plain():
+    _check(None, False)
+
+
+def test_bptt_matches_autograd_masks_and_in_dense():
+    _check(7, True)
+
+
+def test_backward_direction_sees_padding():
+    """No Masking layer: the reverse direction must consume the zero tail first,
+    so its state at the last real frame is NOT the zero initial state."""
+    rs = np.random.RandomState(0)
+    p = L.init_lstm(rs, 3, 4, np.float64)
+    p['b'] += rs.randn(16) * 0.5    # at init b_c = 0 keeps the state at exactly 0
+    x = rs.randn(6, 1, 3); x[4:] = 0.0
+    hs, _ = L.lstm_forward(x, p['W'], p['U'], p['b'], reverse=True)
+    hs_cut, _ = L.lstm_forward(x[:4], p['W'], p['U'], p['b'], reverse=True)
+    assert np.abs(hs[3] - hs_cut[3]).max() > 1e-3      # forget bias 1 -> c != 0
+    assert np.abs(hs[5]).max() > 0                      # zero input still moves
+
+
+def test_init_shapes_and_forget_bias():
+    p = L.init_model(seed=0, num_features=39, num_hiddens=8, num_layers=2)
+    l0 = p['layers'][0]['fwd']
+    assert l0['W'].shape == (39, 32) and l0['U'].shape == (8, 32)
+    assert np.all(l0['b'][8:16] == 1) and l0['b'].sum() == 8
+    u = l0['U'].astype(np.float64)
+    np.testing.assert_allclose(u @ u.T, 1.21 * np.eye(8), atol=1e-5)
+    assert p['layers'][1]['fwd']['W'].shape == (16, 32)
+    assert p['dense']['W'].shape == (16, 28)
