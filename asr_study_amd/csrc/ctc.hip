@@ -1,0 +1,429 @@
+// K7 CTC loss + gradient, K8 greedy decode -- gfx950.
+//
+// Replaces core/ctc_utils.py:60-70 (tf.nn.ctc_loss) and :42
+// (tf.nn.ctc_greedy_decoder) of the reference.  Algorithm: Graves 2006 eq. 6-16
+// in log space, blank = C-1, beta excluding the emission at t (TF convention),
+// see oracle/ctc.py for the restatement this is tested against.
+//
+// Mapping to CDNA4.  The alpha (and beta) recursion is a 999-deep dependent
+// chain per utterance, so the design minimises the latency of ONE step rather
+// than bytes moved:
+//   * one 64-lane wave per (utterance, direction); lane k owns the state PAIR
+//     (blank before label k, label k), so the only cross-lane traffic per step is
+//     ONE DPP wave-shift of a single register (no LDS, no barrier);
+//   * alpha and beta chains of all utterances run concurrently (2N waves);
+//   * log-softmax rows are produced by a separate fully parallel kernel (into the
+//     gradient buffer, reused in place) and the per-step emission gathers are
+//     software-pipelined several steps ahead of the dependent chain;
+//   * the gradient kernel is fully parallel over (t, n): one wave per frame,
+//     class bins in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// ---- DPP wave shifts (gfx9 encodings: wave_shr:1 = 0x138, wave_shl:1 = 0x130).
+__device__ __forceinline__ float wave_shift_up(float v, float fill) {
+  // lane i receives lane i-1; lane 0 receives `fill`.
+  int r = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v),
+                                      0x138, 0xf, 0xf, false);
+  return __int_as_float(r);
+}
+__device__ __forceinline__ float wave_shift_down(float v, float fill) {
+  // lane i receives lane i+1; lane 63 receives `fill`.
+  int r = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v),
+                                      0x130, 0xf, 0xf, false);
+  return __int_as_float(r);
+}
+
+// ---------------------------------------------------------------------------
+// log-softmax over the class axis; one wave per (t, n) row.
+__global__ void __launch_bounds__(256)
+ctc_logsoftmax_kernel(const float* __restrict__ logits, float* __restrict__ logp,
+                      int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = logits + (size_t)row * C;
+  float* y = logp + (size_t)row * C;
+  float m = kNegInf;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+  m = asr_wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += __expf(x[c] - m);
+  s = asr_wave_sum(s);
+  const float lse = m + __logf(s);
+  for (int c = lane; c < C; c += 64) y[c] = x[c] - lse;
+}
+
+// ---------------------------------------------------------------------------
+// alpha / beta chains.  PPL = state pairs per lane (labels up to 64*PPL-1).
+template <int PPL>
+__global__ void __launch_bounds__(64)
+ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ labels,
+                      const int* __restrict__ label_len, const int* __restrict__ seq_len,
+                      int T, int N, int n_pad, int C, int l_max,
+                      float* __restrict__ alpha, float* __restrict__ beta,
+                      float* __restrict__ loss, int do_beta) {
+  constexpr int UNR = 4;
+  const int lane = threadIdx.x;
+  const int n = do_beta ? (blockIdx.x >> 1) : blockIdx.x;
+  const int dir = do_beta ? (blockIdx.x & 1) : 0;
+  const int blank = C - 1;
+  const int L = label_len[n];
+  int Tn = seq_len[n];
+  Tn = Tn < 1 ? 1 : (Tn > T ? T : Tn);
+  const int SP = 2 * 64 * PPL;
+  __shared__ float fin[2 * 64 * PPL];
+
+  int lab[PPL];
+  bool valid[PPL];     // label state exists (q < L)
+  bool diffp[PPL];     // label q differs from label q-1 (skip transition legal)
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) {
+    const int q = lane * PPL + p;
+    valid[p] = q < L;
+    lab[p] = valid[p] ? labels[(size_t)n * l_max + q] : blank;
+    const int prev = (q >= 1 && q - 1 < L) ? labels[(size_t)n * l_max + q - 1] : -1;
+    diffp[p] = valid[p] && (q == 0 || lab[p] != prev);
+    if (lab[p] < 0 || lab[p] >= C) lab[p] = blank;
+  }
+
+  float sb[PPL], sl[PPL];   // blank-state / label-state log values
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) { sb[p] = kNegInf; sl[p] = kNegInf; }
+
+  const size_t row_stride = (size_t)n_pad * C;
+  const float* lp_n = logp + (size_t)n * C;
+  const int ngroups = (Tn + UNR - 1) / UNR;
+
+  if (dir == 0) {
+    // ----- alpha: virtual state before t=0 is "blank 0 with probability 1".
+    if (lane == 0) sb[0] = 0.f;
+    float eb[UNR], el[UNR][PPL];
+    auto load_group = [&](int g, float (&b)[UNR], float (&l)[UNR][PPL]) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        int t = g * UNR + u; t = t < Tn ? t : Tn - 1;
+        const float* r = lp_n + (size_t)t * row_stride;
+        b[u] = r[blank];
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) l[u][p] = r[lab[p]];
+      }
+    };
+    load_group(0, eb, el);
+    for (int g = 0; g < ngroups; ++g) {
+      float nb[UNR], nl[UNR][PPL];
+      load_group(g + 1 < ngroups ? g + 1 : g, nb, nl);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int t = g * UNR + u;
+        if (t < Tn) {
+          // label state of the previous pair (lane-local, or lane-1's last pair)
+          float lprev = wave_shift_up(sl[PPL - 1], kNegInf);
+          float nsb[PPL], nsl[PPL];
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            const float lp1 = (p == 0) ? lprev : sl[p - 1];
+            nsb[p] = asr_lse2(sb[p], lp1) + eb[u];
+            const float sk = diffp[p] ? lp1 : kNegInf;
+            const float e = valid[p] ? el[u][p] : kNegInf;
+            nsl[p] = asr_lse3(sl[p], sb[p], sk) + e;
+          }
+          float2* out = reinterpret_cast<float2*>(alpha + ((size_t)t * N + n) * SP) + lane * PPL;
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            sb[p] = nsb[p]; sl[p] = nsl[p];
+            out[p] = make_float2(sb[p], sl[p]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        eb[u] = nb[u];
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) el[u][p] = nl[u][p];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      fin[2 * (lane * PPL + p)] = sb[p];
+      fin[2 * (lane * PPL + p) + 1] = sl[p];
+    }
+    __syncthreads();
+    if (lane == 0) {
+      const float e1 = fin[2 * L];                          // final blank
+      const float e2 = L > 0 ? fin[2 * (L - 1) + 1] : kNegInf;  // last label
+      loss[n] = -asr_lse2(e1, e2);
+    }
+  } else {
+    // ----- beta (excludes the emission at t).  Virtual frame Tn has emission 0
+    // and state "final blank" = 0.
+    {
+      const int qL = L;   // pair index of the final blank
+      if (lane == qL / PPL) {
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) if (p == qL % PPL) sb[p] = 0.f;
+      }
+    }
+    float eb[UNR], el[UNR][PPL];
+    // group g covers t = Tn-1-g*UNR-u ; emissions come from frame t+1.
+    auto load_group = [&](int g, float (&b)[UNR], float (&l)[UNR][PPL]) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        int t = Tn - 1 - (g * UNR + u); t = t < 0 ? 0 : t;
+        const bool virt = (t + 1 >= Tn);
+        const float* r = lp_n + (size_t)(virt ? t : t + 1) * row_stride;
+        const float vb = r[blank];
+        b[u] = virt ? 0.f : vb;
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) { const float v = r[lab[p]]; l[u][p] = virt ? 0.f : v; }
+      }
+    };
+    load_group(0, eb, el);
+    for (int g = 0; g < ngroups; ++g) {
+      float nb[UNR], nl[UNR][PPL];
+      load_group(g + 1 < ngroups ? g + 1 : g, nb, nl);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int t = Tn - 1 - (g * UNR + u);
+        if (t >= 0) {
+          float xb[PPL], xl[PPL], y[PPL];
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            xb[p] = sb[p] + eb[u];
+            xl[p] = valid[p] ? sl[p] + el[u][p] : kNegInf;
+            // what the PREVIOUS pair's label state may move into from this pair
+            y[p] = asr_lse2(xb[p], diffp[p] ? xl[p] : kNegInf);
+          }
+          const float ynext = wave_shift_down(y[0], kNegInf);
+          float2* out = reinterpret_cast<float2*>(beta + ((size_t)t * N + n) * SP) + lane * PPL;
+#pragma unroll
+          for (int p = 0; p < PPL; ++p) {
+            const float yn = (p == PPL - 1) ? ynext : y[p + 1];
+            sb[p] = asr_lse2(xb[p], xl[p]);
+            sl[p] = valid[p] ? asr_lse2(xl[p], yn) : kNegInf;
+            out[p] = make_float2(sb[p], sl[p]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        eb[u] = nb[u];
+#pragma unroll
+        for (int p = 0; p < PPL; ++p) el[u][p] = nl[u][p];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// gradient: one wave per (t, n).  grad holds log-softmax on entry (in place).
+template <int PPL>
+__global__ void __launch_bounds__(256)
+ctc_grad_kernel(const float* __restrict__ alpha, const float* __restrict__ beta,
+                const float* __restrict__ loss, const int* __restrict__ labels,
+                const int* __restrict__ label_len, const int* __restrict__ seq_len,
+                int T, int N, int n_pad, int C, int l_max, float scale,
+                float* __restrict__ grad) {
+  extern __shared__ __attribute__((aligned(16))) float bins_all[];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const long pair = (long)blockIdx.x * 4 + w;
+  const bool in_range = pair < (long)T * n_pad;
+  const int t = in_range ? (int)(pair / n_pad) : 0;
+  const int n = in_range ? (int)(pair % n_pad) : 0;
+  float* bins = bins_all + (size_t)w * C;
+  const int blank = C - 1;
+  const int SP = 2 * 64 * PPL;
+  bool active = in_range && n < N;
+  int L = 0;
+  float logZ = kNegInf;
+  if (active) {
+    int Tn = seq_len[n];
+    Tn = Tn < 1 ? 1 : (Tn > T ? T : Tn);
+    active = t < Tn;
+    L = label_len[n];
+    logZ = -loss[n];
+    if (!(logZ > kNegInf)) active = false;   // infeasible target: zero gradient
+  }
+  for (int c = lane; c < C; c += 64) bins[c] = 0.f;
+  __syncthreads();
+  float bsum = 0.f;
+  if (active) {
+    const float2* a2 = reinterpret_cast<const float2*>(alpha + ((size_t)t * N + n) * SP) + lane * PPL;
+    const float2* b2 = reinterpret_cast<const float2*>(beta + ((size_t)t * N + n) * SP) + lane * PPL;
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      const int q = lane * PPL + p;
+      if (q <= L) {
+        const float2 a = a2[p];
+        const float2 b = b2[p];
+        const float vb = a.x + b.x - logZ;
+        if (vb > kNegInf) bsum += __expf(vb);
+        if (q < L) {
+          const float vl = a.y + b.y - logZ;
+          if (vl > kNegInf) {
+            int lab = labels[(size_t)n * l_max + q];
+            lab = (lab < 0 || lab >= C) ? blank : lab;
+            atomicAdd(&bins[lab], __expf(vl));
+          }
+        }
+      }
+    }
+  }
+  bsum = asr_wave_sum(bsum);
+  __syncthreads();
+  if (lane == 0 && active) bins[blank] += bsum;
+  __syncthreads();
+  if (in_range) {
+    float* g = grad + ((size_t)t * n_pad + n) * C;
+    for (int c = lane; c < C; c += 64) {
+      g[c] = active ? scale * (__expf(g[c]) - bins[c]) : 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// greedy decode: one 256-thread block per utterance.
+__global__ void __launch_bounds__(256)
+ctc_greedy_kernel(const float* __restrict__ logits, const int* __restrict__ seq_len,
+                  int T, int N, int n_pad, int C, int* __restrict__ decoded,
+                  int* __restrict__ decoded_len) {
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int blank = C - 1;
+  int Tn = seq_len[n];
+  Tn = Tn < 0 ? 0 : (Tn > T ? T : Tn);
+  __shared__ int s_best[256 + 1];
+  __shared__ int s_scan[256];
+  __shared__ int s_base;
+  if (tid == 0) { s_base = 0; s_best[0] = -1; }
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 256) {
+    const int t = t0 + tid;
+    int best = -1;
+    if (t < Tn) {
+      const float* r = logits + ((size_t)t * n_pad + n) * C;
+      float bv = r[0]; best = 0;
+      for (int c = 1; c < C; ++c) { const float v = r[c]; if (v > bv) { bv = v; best = c; } }
+    }
+    // s_best[0] carries the previous chunk's last argmax
+    s_best[tid + 1] = best;
+    __syncthreads();
+    const int prev = s_best[tid];
+    const int keep = (t < Tn && best != blank && best != prev) ? 1 : 0;
+    s_scan[tid] = keep;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {          // Hillis-Steele inclusive scan
+      int v = (tid >= o) ? s_scan[tid - o] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    const int base = s_base;
+    if (keep) decoded[(size_t)n * T + base + s_scan[tid] - 1] = best;
+    __syncthreads();
+    if (tid == 255) { s_base = base + s_scan[255]; s_best[0] = s_best[256]; }
+    __syncthreads();
+  }
+  const int total = s_base;
+  for (int i = total + tid; i < T; i += 256) decoded[(size_t)n * T + i] = -1;
+  if (tid == 0) decoded_len[n] = total;
+}
+
+int pick_ppl(int l_max) {
+  const int pairs = l_max + 1;
+  if (pairs <= 64) return 1;
+  if (pairs <= 128) return 2;
+  if (pairs <= 256) return 4;
+  if (pairs <= 512) return 8;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t asr_ctc_workspace_bytes(int T, int N, int n_pad, int C, int l_max) {
+  const int ppl = pick_ppl(l_max);
+  if (ppl == 0 || T <= 0 || N <= 0) return 0;
+  const size_t sp = (size_t)2 * 64 * ppl;
+  const int n_pad16 = n_pad > N ? n_pad : N;
+  // alpha + beta + (log-softmax scratch for the loss-only path)
+  return asr_align_up((size_t)T * N * sp * sizeof(float), 256) * 2 +
+         asr_align_up((size_t)T * n_pad16 * C * sizeof(float), 256);
+}
+
+extern "C" int asr_ctc_loss_grad(const float* logits, const int* labels,
+                                 const int* label_len, const int* seq_len, int T,
+                                 int N, int n_pad, int C, int l_max,
+                                 float grad_scale, float* loss, float* grad,
+                                 void* workspace, size_t ws_bytes,
+                                 asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(logits && labels && label_len && seq_len && loss, "ctc: null pointer");
+  ASR_CHECK_ARG(T > 0 && N > 0 && n_pad >= N && C >= 2 && l_max >= 1,
+                "ctc: bad shape T=%d N=%d n_pad=%d C=%d l_max=%d", T, N, n_pad, C, l_max);
+  const int ppl = pick_ppl(l_max);
+  ASR_CHECK_ARG(ppl != 0, "ctc: l_max=%d unsupported (max 511)", l_max);
+  const size_t sp = (size_t)2 * 64 * ppl;
+  const size_t ab_bytes = asr_align_up((size_t)T * N * sp * sizeof(float), 256);
+  const size_t lp_bytes = asr_align_up((size_t)T * n_pad * C * sizeof(float), 256);
+  const size_t need = ab_bytes * 2 + (grad ? 0 : lp_bytes);
+  if (!workspace || ws_bytes < need) {
+    asr_set_error("ctc: workspace %zu < %zu bytes", ws_bytes, need);
+    return ASR_ERR_WORKSPACE;
+  }
+  float* alpha = reinterpret_cast<float*>(workspace);
+  float* beta = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ab_bytes);
+  float* logp = grad ? grad
+                     : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 2 * ab_bytes);
+  const int rows = T * n_pad;
+  hipLaunchKernelGGL(ctc_logsoftmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream,
+                     logits, logp, rows, C);
+  ASR_CHECK_LAUNCH();
+  const int do_beta = grad ? 1 : 0;
+  const dim3 grid_ab(do_beta ? 2 * N : N);
+#define LAUNCH_AB(P)                                                                \
+  hipLaunchKernelGGL(ctc_alpha_beta_kernel<P>, grid_ab, dim3(64), 0, stream, logp,  \
+                     labels, label_len, seq_len, T, N, n_pad, C, l_max, alpha, beta, \
+                     loss, do_beta)
+  switch (ppl) {
+    case 1: LAUNCH_AB(1); break;
+    case 2: LAUNCH_AB(2); break;
+    case 4: LAUNCH_AB(4); break;
+    default: LAUNCH_AB(8); break;
+  }
+#undef LAUNCH_AB
+  ASR_CHECK_LAUNCH();
+  if (grad) {
+    const long pairs = (long)T * n_pad;
+    const dim3 grid_g((unsigned)((pairs + 3) / 4));
+    const size_t shm = (size_t)4 * C * sizeof(float);
+#define LAUNCH_G(P)                                                                  \
+  hipLaunchKernelGGL(ctc_grad_kernel<P>, grid_g, dim3(256), shm, stream, alpha, beta, \
+                     loss, labels, label_len, seq_len, T, N, n_pad, C, l_max,         \
+                     grad_scale, grad)
+    switch (ppl) {
+      case 1: LAUNCH_G(1); break;
+      case 2: LAUNCH_G(2); break;
+      case 4: LAUNCH_G(4); break;
+      default: LAUNCH_G(8); break;
+    }
+#undef LAUNCH_G
+    ASR_CHECK_LAUNCH();
+  }
+  return ASR_OK;
+}
+
+extern "C" int asr_ctc_greedy(const float* logits, const int* seq_len, int T, int N,
+                              int n_pad, int C, int* decoded, int* decoded_len,
+                              asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(logits && seq_len && decoded && decoded_len, "greedy: null pointer");
+  ASR_CHECK_ARG(T > 0 && N > 0 && n_pad >= N && C >= 2, "greedy: bad shape");
+  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(N), dim3(256), 0, stream, logits, seq_len,
+                     T, N, n_pad, C, decoded, decoded_len);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}

@@ -1,0 +1,345 @@
+// K1-K3 MFCC / log-mel front-end -- gfx950.
+//
+// Replaces preprocessing/audio.py (FBank/MFCC/LogFbank._call, _postprocessing,
+// _standarize) and preprocessing/audio_utils.py (preemphasis, framesig, powspec,
+// delta) of the reference; tested against oracle/frontend.py, which is pinned
+// bit-for-bit on the reference's own NumPy code.
+//
+// Kernel 1 (fe_frames_kernel): one 64-lane wave per frame.  Pre-emphasis, zero
+//   padded framing and the Hamming window are applied while the 400 samples are
+//   read (coalesced); the 512-point real FFT is a 256-point complex radix-4
+//   Stockham FFT (4 stages x one butterfly per lane) in LDS plus the real-FFT
+//   split; power spectrum, frame energy, the (sparse) triangular mel filters,
+//   log and the 13-column DCT (lifter folded into the table) all stay in LDS /
+//   registers.  Only T x (13 | nfilt[+1]) base features are written.
+// Kernel 2 (fe_finalize_kernel): one workgroup per utterance.  Deltas and
+//   delta-deltas (edge-replicated, audio_utils.py:153-173), stride / context
+//   stacking, per-column mean / population-std (float64 accumulators, wave
+//   shuffles + LDS) and the normalised write into the time-major (T, N, F) slab,
+//   zero-filled past the utterance (pad_sequences 'post').
+#include "common.h"
+
+namespace {
+
+constexpr int NFFT = 512;
+constexpr int NBINS = NFFT / 2 + 1;     // 257
+constexpr int FRAMES_PER_WAVE = 4;
+constexpr int WAVES = 4;
+constexpr int FRAMES_PER_BLOCK = FRAMES_PER_WAVE * WAVES;
+constexpr float kF64Eps = 2.220446049250313e-16f;   // np.finfo(float).eps
+
+struct float2c { float x, y; };
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__global__ void __launch_bounds__(256)
+fe_frames_kernel(asr_frontend_cfg cfg, const float* __restrict__ audio,
+                 const int* __restrict__ offsets, const int* __restrict__ lengths,
+                 const float* __restrict__ window, const float* __restrict__ mel,
+                 const int* __restrict__ mel_range, const float* __restrict__ dct,
+                 float* __restrict__ base, int max_frames, int fb) {
+  __shared__ float2 tw[384 + 1];                 // e^{-2 pi i m / 512}, m = 0..384
+  __shared__ float2 buf[WAVES][2][256];          // ping-pong complex buffers
+  __shared__ float pspec[WAVES][NBINS + 3];
+  __shared__ float lmel[WAVES][128];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int utt = blockIdx.y;
+  const int len = lengths[utt];
+  const int off = offsets[utt];
+  int nframes = 1;
+  if (len > cfg.frame_len)
+    nframes = 1 + (len - cfg.frame_len + cfg.frame_step - 1) / cfg.frame_step;
+  const int f_block = blockIdx.x * FRAMES_PER_BLOCK;
+  if (f_block >= nframes) return;                 // uniform per block
+
+  for (int m = tid; m <= 384; m += 256) {
+    float s, c;
+    sincospif(-(float)m / 256.0f, &s, &c);        // angle = -2 pi m / 512
+    tw[m] = make_float2(c, s);
+  }
+  __syncthreads();
+
+  float* real_in = reinterpret_cast<float*>(&buf[w][0][0]);   // 512 reals == 256 complex
+  for (int fi = 0; fi < FRAMES_PER_WAVE; ++fi) {
+    const int f = f_block + w * FRAMES_PER_WAVE + fi;
+    const bool live = f < nframes;
+    // ---- load + pre-emphasis + window (zero padded to 512)
+    const int s0 = f * cfg.frame_step;
+    for (int i = lane; i < NFFT; i += 64) {
+      float v = 0.f;
+      if (live && i < cfg.frame_len) {
+        const int idx = s0 + i;
+        if (idx < len) {
+          const float x = audio[off + idx];
+          const float xp = idx > 0 ? audio[off + idx - 1] : 0.f;
+          v = (idx > 0 ? x - cfg.pre_emph * xp : x) * window[i];
+        }
+      }
+      real_in[i] = v;
+    }
+    __syncthreads();
+    // ---- 256-point complex FFT, radix-4 Stockham, Ns = 1, 4, 16, 64
+    int cur = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int Ns = 1 << (2 * s);
+      const float2* in = buf[w][cur];
+      float2* out = buf[w][cur ^ 1];
+      const int j = lane;
+      const int k = j & (Ns - 1);
+      float2 v0 = in[j], v1 = in[j + 64], v2 = in[j + 128], v3 = in[j + 192];
+      if (s > 0) {
+        const int tstep = (128 / Ns) * k;        // index into tw (512-based): 2*(64/Ns)*k
+        v1 = cmul(v1, tw[tstep]);
+        v2 = cmul(v2, tw[2 * tstep]);
+        v3 = cmul(v3, tw[3 * tstep]);
+      }
+      const float2 t0 = make_float2(v0.x + v2.x, v0.y + v2.y);
+      const float2 t1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+      const float2 t2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+      const float2 d = make_float2(v1.x - v3.x, v1.y - v3.y);
+      const float2 t3 = make_float2(d.y, -d.x);  // -i * (v1 - v3)
+      const int base_idx = ((j - k) << 2) + k;   // (j / Ns) * Ns * 4 + k
+      out[base_idx] = make_float2(t0.x + t2.x, t0.y + t2.y);
+      out[base_idx + Ns] = make_float2(t1.x + t3.x, t1.y + t3.y);
+      out[base_idx + 2 * Ns] = make_float2(t0.x - t2.x, t0.y - t2.y);
+      out[base_idx + 3 * Ns] = make_float2(t1.x - t3.x, t1.y - t3.y);
+      cur ^= 1;
+      __syncthreads();
+    }
+    // ---- real-FFT split + power spectrum / nfft, frame energy
+    const float2* Z = buf[w][cur];
+    float esum = 0.f;
+    for (int k = lane; k < NBINS; k += 64) {
+      const float2 zk = Z[k & 255];
+      const float2 zc = Z[(256 - k) & 255];
+      const float2 zn = make_float2(zc.x, -zc.y);                 // conj
+      const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
+      const float2 dd = make_float2(zk.x - zn.x, zk.y - zn.y);
+      const float2 o = make_float2(0.5f * dd.y, -0.5f * dd.x);    // -i/2 * (zk - zn)
+      const float2 wo = cmul(tw[k], o);
+      const float xr = e.x + wo.x, xi = e.y + wo.y;
+      const float p = (xr * xr + xi * xi) * (1.0f / NFFT);
+      pspec[w][k] = p;
+      esum += p;
+    }
+    esum = asr_wave_sum(esum);
+    if (esum == 0.f) esum = kF64Eps;
+    __syncthreads();
+    // ---- mel filterbank (triangles are sparse: only [lo, hi) bins) + log
+    for (int jf = lane; jf < cfg.num_filt; jf += 64) {
+      const int lo = mel_range[2 * jf], hi = mel_range[2 * jf + 1];
+      const float* mrow = mel + (size_t)jf * NBINS;
+      float acc = 0.f;
+      for (int k = lo; k < hi; ++k) acc += pspec[w][k] * mrow[k];
+      if (acc == 0.f) acc = kF64Eps;
+      lmel[w][jf] = logf(acc);
+    }
+    __syncthreads();
+    // ---- write base features
+    if (live) {
+      float* row = base + ((size_t)utt * max_frames + f) * fb;
+      const float le = logf(esum + cfg.eps);
+      if (cfg.kind == 0) {
+        for (int c = lane; c < cfg.num_cep; c += 64) {
+          float acc = 0.f;
+          for (int jf = 0; jf < cfg.num_filt; ++jf)
+            acc += lmel[w][jf] * dct[jf * cfg.num_cep + c];
+          if (c == 0 && cfg.append_energy) acc = le;
+          row[c] = acc;
+        }
+      } else {
+        for (int c = lane; c < cfg.num_filt; c += 64) row[c] = lmel[w][c];
+        if (cfg.append_energy && lane == 0) row[cfg.num_filt] = le;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// full[t][0:fb] = base, [fb:2fb] = delta, [2fb:3fb] = delta-delta
+__device__ __forceinline__ float delta_at(const float* __restrict__ x, int ld, int T, int t,
+                                          int c) {
+  // sum_{n=-2..2} n * x[clamp(t+n)] / 10, same association order as the reference
+  float acc = 0.f;
+#pragma unroll
+  for (int n = -2; n <= 2; ++n) {
+    int tt = t + n;
+    tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+    acc += (float)n * x[(size_t)tt * ld + c];
+  }
+  return acc / 10.0f;
+}
+
+__global__ void __launch_bounds__(256)
+fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
+                   float* __restrict__ full, int max_frames, int fb, int ffull,
+                   float* __restrict__ out, int t_out, int n_pad, int f_out,
+                   int* __restrict__ out_frames) {
+  const int utt = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int len = lengths[utt];
+  int T = 1;
+  if (len > cfg.frame_len) T = 1 + (len - cfg.frame_len + cfg.frame_step - 1) / cfg.frame_step;
+  if (T > max_frames) T = max_frames;
+  float* x = full + (size_t)utt * max_frames * ffull;
+  // ---- deltas (global scratch, visible block-wide after the barrier)
+  if (cfg.d) {
+    for (int e = tid; e < T * fb; e += 256) {
+      const int t = e / fb, c = e % fb;
+      x[(size_t)t * ffull + fb + c] = delta_at(x, ffull, T, t, c);
+    }
+    __syncthreads();
+    if (cfg.dd) {
+      for (int e = tid; e < T * fb; e += 256) {
+        const int t = e / fb, c = e % fb;
+        x[(size_t)t * ffull + 2 * fb + c] = delta_at(x + fb, ffull, T, t, c);
+      }
+      __syncthreads();
+    }
+  }
+  const int stride = cfg.stride < 1 ? 1 : cfg.stride;
+  const int Ts = (T + stride - 1) / stride;       // frames after feats[::stride]
+  const int nctx = 2 * cfg.num_context + 1;
+  auto get = [&](int ts, int col) -> float {
+    const int cslot = col / ffull, c = col % ffull;
+    const int src = ts + cslot - cfg.num_context;
+    if (src < 0 || src >= Ts) return 0.f;
+    return x[(size_t)(src * stride) * ffull + c];
+  };
+  (void)nctx;
+  // ---- column statistics: thread (cx, ty) walks t = ty, ty+TY, ... of column cx
+  constexpr int CX = 64, TY = 4;
+  __shared__ double s_sum[TY][CX];
+  __shared__ double s_sq[TY][CX];
+  __shared__ float s_mean[CX];
+  __shared__ float s_inv[CX];
+  const int cx = tid & 63, ty = tid >> 6;
+  for (int c0 = 0; c0 < f_out; c0 += CX) {
+    const int col = c0 + cx;
+    double sum = 0.0;
+    if (col < f_out)
+      for (int ts = ty; ts < Ts; ts += TY) sum += (double)get(ts, col);
+    s_sum[ty][cx] = sum;
+    __syncthreads();
+    double mean = 0.0;
+    if (col < f_out) mean = (s_sum[0][cx] + s_sum[1][cx] + s_sum[2][cx] + s_sum[3][cx]) / Ts;
+    double sq = 0.0;
+    if (col < f_out)
+      for (int ts = ty; ts < Ts; ts += TY) {
+        const double dlt = (double)get(ts, col) - mean;
+        sq += dlt * dlt;
+      }
+    s_sq[ty][cx] = sq;
+    __syncthreads();
+    if (ty == 0 && col < f_out) {
+      const double var = (s_sq[0][cx] + s_sq[1][cx] + s_sq[2][cx] + s_sq[3][cx]) / Ts;
+      s_mean[cx] = cfg.mean_norm ? (float)mean : 0.f;
+      double sd = sqrt(var);
+      if (!cfg.mean_norm) {
+        // std is still computed about the true mean (np.std), only the shift is skipped
+      }
+      s_inv[cx] = cfg.var_norm ? (float)(1.0 / (sd + (double)cfg.eps)) : 1.f;
+    }
+    __syncthreads();
+    if (col < f_out) {
+      const float mu = s_mean[cx], inv = s_inv[cx];
+      for (int ts = ty; ts < t_out; ts += TY) {
+        float v = 0.f;
+        if (ts < Ts) v = (get(ts, col) - mu) * inv;
+        out[((size_t)ts * n_pad + utt) * f_out + col] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && out_frames) out_frames[utt] = Ts < t_out ? Ts : t_out;
+}
+
+__global__ void fe_zero_pad_rows_kernel(float* __restrict__ out, int t_out, int n_utt,
+                                        int n_pad, int f_out) {
+  // rows n in [n_utt, n_pad) of every time step are batch padding: zero them.
+  const int padn = n_pad - n_utt;
+  const size_t total = (size_t)t_out * padn * f_out;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % f_out);
+    const size_t r = e / f_out;
+    const int n = n_utt + (int)(r % padn);
+    const int t = (int)(r / padn);
+    out[((size_t)t * n_pad + n) * f_out + c] = 0.f;
+  }
+}
+
+int base_cols(const asr_frontend_cfg* cfg) {
+  return cfg->kind == 0 ? cfg->num_cep : cfg->num_filt + (cfg->append_energy ? 1 : 0);
+}
+
+}  // namespace
+
+extern "C" int asr_frontend_num_frames(int samples, int frame_len, int frame_step) {
+  if (samples <= frame_len) return 1;
+  return 1 + (samples - frame_len + frame_step - 1) / frame_step;
+}
+
+extern "C" int asr_frontend_num_feats(const asr_frontend_cfg* cfg) {
+  return base_cols(cfg) * (1 + (cfg->d ? 1 : 0) + ((cfg->d && cfg->dd) ? 1 : 0));
+}
+
+extern "C" size_t asr_frontend_workspace_bytes(const asr_frontend_cfg* cfg, int n_utt,
+                                               int max_frames) {
+  return asr_align_up((size_t)n_utt * max_frames * asr_frontend_num_feats(cfg) *
+                          sizeof(float), 256);
+}
+
+extern "C" int asr_frontend_features(const asr_frontend_cfg* cfg, const float* audio,
+                                     const int* offsets, const int* lengths,
+                                     const int* host_lengths, int n_utt, int n_pad,
+                                     const float* window, const float* mel,
+                                     const int* mel_range, const float* dct,
+                                     float* out, int t_out, int* out_frames,
+                                     void* workspace, size_t ws_bytes,
+                                     asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(cfg && audio && offsets && lengths && host_lengths && window && mel &&
+                    mel_range && out && workspace, "frontend: null pointer");
+  ASR_CHECK_ARG(cfg->nfft == NFFT, "frontend: nfft must be 512 (got %d)", cfg->nfft);
+  ASR_CHECK_ARG(cfg->frame_len > 0 && cfg->frame_len <= NFFT && cfg->frame_step > 0,
+                "frontend: bad frame_len/frame_step");
+  ASR_CHECK_ARG(cfg->num_filt > 0 && cfg->num_filt <= 128, "frontend: num_filt > 128");
+  ASR_CHECK_ARG(cfg->kind == 1 || (cfg->num_cep > 0 && cfg->num_cep <= 64 && dct),
+                "frontend: bad num_cep / missing dct");
+  ASR_CHECK_ARG(n_utt > 0 && n_pad >= n_utt && t_out > 0, "frontend: bad batch shape");
+  int max_frames = 1;
+  for (int i = 0; i < n_utt; ++i) {
+    ASR_CHECK_ARG(host_lengths[i] > 1, "frontend: utterance %d has < 2 samples", i);
+    const int nf = asr_frontend_num_frames(host_lengths[i], cfg->frame_len, cfg->frame_step);
+    if (nf > max_frames) max_frames = nf;
+  }
+  const int fb = base_cols(cfg);
+  const int ffull = asr_frontend_num_feats(cfg);
+  const int f_out = ffull * (2 * cfg->num_context + 1);
+  const size_t need = asr_frontend_workspace_bytes(cfg, n_utt, max_frames);
+  if (ws_bytes < need) {
+    asr_set_error("frontend: workspace %zu < %zu bytes", ws_bytes, need);
+    return ASR_ERR_WORKSPACE;
+  }
+  float* full = reinterpret_cast<float*>(workspace);
+  dim3 grid((max_frames + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK, n_utt);
+  hipLaunchKernelGGL(fe_frames_kernel, grid, dim3(256), 0, stream, *cfg, audio, offsets,
+                     lengths, window, mel, mel_range, dct, full, max_frames, ffull);
+  ASR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fe_finalize_kernel, dim3(n_utt), dim3(256), 0, stream, *cfg, lengths,
+                     full, max_frames, fb, ffull, out, t_out, n_pad, f_out, out_frames);
+  ASR_CHECK_LAUNCH();
+  if (n_pad > n_utt) {
+    hipLaunchKernelGGL(fe_zero_pad_rows_kernel, dim3(256), dim3(256), 0, stream, out, t_out,
+                       n_utt, n_pad, f_out);
+    ASR_CHECK_LAUNCH();
+  }
+  return ASR_OK;
+}

@@ -1,0 +1,306 @@
+// K4/K6 fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32) + column sum -- gfx950.
+//
+// Replaces the hoisted input->4H gate matmul K.dot(x*B_W, W) (core/layers.py:439),
+// TimeDistributed(Dense) (core/models.py:278-279) and their gradients.  fp32 in /
+// fp32 accumulate MFMA is bit-identical to an fmaf chain, so the 1e-4 parity
+// budget is untouched (there is no xf32/TF32 path on gfx950).
+//
+// Tiling: 128x128x16 block tile, 256 threads = 4 waves in a 2x2 grid, each wave
+// owns a 64x64 sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs).  Both
+// operands are staged K-MAJOR in LDS (As[k][m], Bs[k][n], row pad 4) so that the
+// MFMA fragment reads (lane l -> [k = 2kk + l/32][l%32]) are conflict-free
+// ds_read_b32; whichever of the four storage orders the caller has is transposed
+// on the way in (16-byte global loads; ds_write_b128 for mn-contiguous sources,
+// 2-way (free) ds_write_b32 for k-contiguous ones).  Global->register prefetch of
+// tile k+1 overlaps the 32 MFMAs of tile k; one barrier per K step.
+// Variational-dropout masks (core/models.py:265-266) are applied in the loader
+// (A side) or the epilogue (C side), bias in the epilogue.  Split-K writes
+// per-split partials and reduces them in a fixed order (deterministic).
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128, BN = 128, BK = 16, PAD = 4;
+constexpr int LDS_LD = BM + PAD;   // BM == BN
+
+struct TileSrc {
+  const float* p;      // base pointer
+  int ld;              // leading dimension of the storage
+  int mn_contig;       // 1: storage is (K, MN) row-major; 0: (MN, K) row-major
+  int mn_total, k_total;
+  const float* scale;  // optional mask over storage (row % period, col)
+  int period, scale_ld;
+  int vec_ok;          // 16-byte aligned rows
+};
+
+// Loads the (BK x 128) tile starting at (k0, mn0) into 2 float4 registers.
+__device__ __forceinline__ void tile_load(const TileSrc& s, int k0, int mn0, int k_end,
+                                          float4 (&r)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s.mn_contig) {
+      const int kk = (tid >> 5) + 8 * it;
+      const int mn = mn0 + 4 * (tid & 31);
+      const int k = k0 + kk;
+      if (k < k_end) {
+        const float* src = s.p + (size_t)k * s.ld + mn;
+        if (s.vec_ok && mn + 3 < s.mn_total) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (mn + e < s.mn_total) v[e] = src[e];
+        }
+        if (s.scale) {
+          const float* sc = s.scale + (size_t)(k % s.period) * s.scale_ld + mn;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (mn + e < s.mn_total) v[e] *= sc[e];
+        }
+      }
+    } else {
+      const int mn = mn0 + (tid >> 2) + 64 * it;
+      const int k = k0 + 4 * (tid & 3);
+      if (mn < s.mn_total) {
+        const float* src = s.p + (size_t)mn * s.ld + k;
+        if (s.vec_ok && k + 3 < k_end) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e < k_end) v[e] = src[e];
+        }
+        if (s.scale) {
+          const float* sc = s.scale + (size_t)(mn % s.period) * s.scale_ld + k;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e < k_end) v[e] *= sc[e];
+        }
+      }
+    }
+    r[it] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+__device__ __forceinline__ void tile_store(int mn_contig, const float4 (&r)[2],
+                                           float (*S)[LDS_LD]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (mn_contig) {
+      const int kk = (tid >> 5) + 8 * it;
+      *reinterpret_cast<float4*>(&S[kk][4 * (tid & 31)]) = r[it];
+    } else {
+      const int mn = (tid >> 2) + 64 * it;
+      const int kb = 4 * (tid & 3);
+      S[kb + 0][mn] = r[it].x;
+      S[kb + 1][mn] = r[it].y;
+      S[kb + 2][mn] = r[it].z;
+      S[kb + 3][mn] = r[it].w;
+    }
+  }
+}
+
+struct Epilogue {
+  float* C; int ldc;
+  float alpha, beta;
+  const float* bias;
+  const float* c_scale; int c_period, c_ld;
+  float* partial;      // split-K: raw accumulators go here ([split][M][N])
+};
+
+__global__ void __launch_bounds__(256)
+gemm_f32_mfma_kernel(TileSrc A, TileSrc B, int M, int N, int K, int k_per_split,
+                     Epilogue ep) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDS_LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int k_begin = blockIdx.z * k_per_split;
+  int k_end = k_begin + k_per_split;
+  if (k_end > K) k_end = K;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[2], rb[2];
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  if (nk > 0) {
+    tile_load(A, k_begin, m0, k_end, ra);
+    tile_load(B, k_begin, n0, k_end, rb);
+    tile_store(A.mn_contig, ra, As[0]);
+    tile_store(B.mn_contig, rb, Bs[0]);
+  }
+  __syncthreads();
+  const int lrow = lane >> 5, lcol = lane & 31;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      tile_load(A, k_begin + (kt + 1) * BK, m0, k_end, ra);
+      tile_load(B, k_begin + (kt + 1) * BK, n0, k_end, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[cur][2 * kk + lrow][wm * 64 + i * 32 + lcol];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[cur][2 * kk + lrow][wn * 64 + j * 32 + lcol];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      tile_store(A.mn_contig, ra, As[cur ^ 1]);
+      tile_store(B.mn_contig, rb, Bs[cur ^ 1]);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31,
+  //      row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + lcol;
+      if (col >= N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lrow;
+        if (row >= M) continue;
+        float v = acc[i][j][e];
+        if (ep.partial) {
+          ep.partial[((size_t)blockIdx.z * M + row) * N + col] = v;
+        } else {
+          v *= ep.alpha;
+          float* dst = ep.C + (size_t)row * ep.ldc + col;
+          if (ep.beta != 0.f) v += ep.beta * *dst;
+          if (ep.bias) v += ep.bias[col];
+          if (ep.c_scale) v *= ep.c_scale[(size_t)(row % ep.c_period) * ep.c_ld + col];
+          *dst = v;
+        }
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N,
+                          Epilogue ep) {
+  const size_t total = (size_t)M * N;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(e / N), col = (int)(e % N);
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += partial[(size_t)s * total + e];
+    v *= ep.alpha;
+    float* dst = ep.C + (size_t)row * ep.ldc + col;
+    if (ep.beta != 0.f) v += ep.beta * *dst;
+    if (ep.bias) v += ep.bias[col];
+    if (ep.c_scale) v *= ep.c_scale[(size_t)(row % ep.c_period) * ep.c_ld + col];
+    *dst = v;
+  }
+}
+
+// out[n] = beta*out[n] + sum_m X[m][n]; block = 256 threads covers 64 columns x 4
+// row phases; rows are split over blockIdx.y and combined with atomics only when
+// gridDim.y > 1 (kept at 1 here: deterministic).
+__global__ void __launch_bounds__(256)
+colsum_kernel(const float* __restrict__ X, int M, int N, int ldx, float* __restrict__ out,
+              float beta) {
+  __shared__ double part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  double s = 0.0;
+  if (col < N)
+    for (int m = ry; m < M; m += 4) s += (double)X[(size_t)m * ldx + col];
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < N) {
+    const double t = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+    out[col] = (beta != 0.f ? beta * out[col] : 0.f) + (float)t;
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" size_t asr_gemm_workspace_bytes(const asr_gemm_args* a) {
+  if (!a || a->split_k <= 1) return 0;
+  return asr_align_up((size_t)a->split_k * a->M * a->N * sizeof(float), 256);
+}
+
+extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes,
+                        asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(a && a->A && a->B && a->C, "gemm: null pointer");
+  ASR_CHECK_ARG(a->M > 0 && a->N > 0 && a->K >= 0, "gemm: bad shape %d %d %d", a->M, a->N, a->K);
+  TileSrc A, B;
+  A.p = a->A; A.ld = a->lda; A.mn_contig = a->trans_a ? 1 : 0;
+  A.mn_total = a->M; A.k_total = a->K;
+  A.scale = a->a_scale; A.period = a->a_scale_period > 0 ? a->a_scale_period : 1;
+  A.scale_ld = a->a_scale_ld;
+  A.vec_ok = (a->lda % 4 == 0) && aligned16(a->A);
+  B.p = a->B; B.ld = a->ldb; B.mn_contig = a->trans_b ? 0 : 1;
+  B.mn_total = a->N; B.k_total = a->K;
+  B.scale = nullptr; B.period = 1; B.scale_ld = 0;
+  B.vec_ok = (a->ldb % 4 == 0) && aligned16(a->B);
+  ASR_CHECK_ARG(a->lda >= (a->trans_a ? a->M : a->K), "gemm: lda too small");
+  ASR_CHECK_ARG(a->ldb >= (a->trans_b ? a->K : a->N), "gemm: ldb too small");
+  ASR_CHECK_ARG(a->ldc >= a->N, "gemm: ldc too small");
+  int splits = a->split_k > 1 ? a->split_k : 1;
+  int k_per_split = (a->K + splits - 1) / splits;
+  k_per_split = (k_per_split + BK - 1) / BK * BK;
+  if (k_per_split < BK) k_per_split = BK;
+  // vector loads along K need 4-aligned split starts: BK multiple guarantees it
+  while (splits > 1 && (size_t)(splits - 1) * k_per_split >= (size_t)a->K) --splits;
+  Epilogue ep;
+  ep.C = a->C; ep.ldc = a->ldc; ep.alpha = a->alpha; ep.beta = a->beta; ep.bias = a->bias;
+  ep.c_scale = a->c_scale; ep.c_period = a->c_scale_period > 0 ? a->c_scale_period : 1;
+  ep.c_ld = a->c_scale_ld; ep.partial = nullptr;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * a->M * a->N * sizeof(float);
+    if (!workspace || ws_bytes < need) {
+      asr_set_error("gemm: split-K workspace %zu < %zu bytes", ws_bytes, need);
+      return ASR_ERR_WORKSPACE;
+    }
+    ep.partial = reinterpret_cast<float*>(workspace);
+  }
+  dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, splits);
+  hipLaunchKernelGGL(gemm_f32_mfma_kernel, grid, dim3(256), 0, stream, A, B, a->M, a->N,
+                     a->K, k_per_split, ep);
+  ASR_CHECK_LAUNCH();
+  if (splits > 1) {
+    Epilogue ep2 = ep;
+    ep2.partial = nullptr;
+    const size_t total = (size_t)a->M * a->N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const float*>(workspace), splits, a->M, a->N, ep2);
+    ASR_CHECK_LAUNCH();
+  }
+  return ASR_OK;
+}
+
+extern "C" int asr_colsum(const float* X, int M, int N, int ldx, float* out, float beta,
+                          asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(X && out && M > 0 && N > 0 && ldx >= N, "colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, X, M, N, ldx,
+                     out, beta);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}

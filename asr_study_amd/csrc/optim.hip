@@ -1,0 +1,171 @@
+// K11 optimiser: global-norm clip + Adam / SGD-momentum over one flat fp32 buffer.
+//
+// Replaces Keras 1.2.2 Adam/SGD(clipnorm=...) (train.py:133-137) and the l2
+// weight regularisers (core/models.py:263-264,279: their gradient 2*l2*w is part
+// of the clipped gradient, their value l2*sum(w^2) part of the reported loss).
+// HBM-bound: 28 B/param for Adam (read g,p,m,v; write p,m,v), 16-byte accesses,
+// one pass for the norm (float64 accumulation, fixed-order two-level reduce ->
+// deterministic) and one for the update; the clip scale is read from device
+// memory so there is no host round trip between the two.
+#include "common.h"
+
+namespace {
+
+constexpr int kNormBlocks = 1024;
+
+__device__ __forceinline__ float seg_l2(const asr_segment* seg, int n_seg, int64_t idx) {
+  // segments are sorted by offset and cover the buffer; binary search
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg[mid].offset <= idx) lo = mid; else hi = mid - 1;
+  }
+  return seg[lo].l2;
+}
+
+__global__ void __launch_bounds__(256)
+norm_partial_kernel(const float* __restrict__ p, const float* __restrict__ g, int64_t n,
+                    const asr_segment* __restrict__ seg, int n_seg,
+                    double* __restrict__ partial) {
+  double s_g = 0.0, s_w = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float l2 = seg_l2(seg, n_seg, i);
+    const float w = p[i];
+    const float gg = g[i] + 2.f * l2 * w;
+    s_g += (double)gg * gg;
+    s_w += (double)l2 * w * w;
+  }
+  s_g = asr_wave_sum_d(s_g);
+  s_w = asr_wave_sum_d(s_w);
+  __shared__ double sh[2][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[0][w] = s_g; sh[1][w] = s_w; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    partial[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+norm_final_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+  double s_g = 0.0, s_w = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    s_g += partial[2 * i];
+    s_w += partial[2 * i + 1];
+  }
+  s_g = asr_wave_sum_d(s_g);
+  s_w = asr_wave_sum_d(s_w);
+  __shared__ double sh[2][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[0][w] = s_g; sh[1][w] = s_w; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = sqrt(sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+    out[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+
+__device__ __forceinline__ float clip_scale(const double* norm, float clipnorm) {
+  if (!(clipnorm > 0.f) || norm == nullptr) return 1.f;
+  const double nrm = norm[0];
+  return nrm >= (double)clipnorm ? (float)((double)clipnorm / nrm) : 1.f;
+}
+
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+            float* __restrict__ v, int64_t n, const asr_segment* __restrict__ seg, int n_seg,
+            const double* __restrict__ norm, float clipnorm, float lr_t, float b1, float b2,
+            float eps) {
+  const float sc = clip_scale(norm, clipnorm);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float l2 = seg_l2(seg, n_seg, i);
+    const float w = p[i];
+    const float gg = (g[i] + 2.f * l2 * w) * sc;
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm;
+    v[i] = vv;
+    p[i] = w - lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ vel,
+           int64_t n, const asr_segment* __restrict__ seg, int n_seg,
+           const double* __restrict__ norm, float clipnorm, float lr, float mu) {
+  const float sc = clip_scale(norm, clipnorm);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float l2 = seg_l2(seg, n_seg, i);
+    const float w = p[i];
+    const float gg = (g[i] + 2.f * l2 * w) * sc;
+    const float vn = mu * vel[i] - lr * gg;
+    vel[i] = vn;
+    p[i] = w + vn;
+  }
+}
+
+int grid_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" size_t asr_optim_workspace_bytes(int64_t n) {
+  (void)n;
+  return (size_t)kNormBlocks * 2 * sizeof(double);
+}
+
+extern "C" int asr_grad_norm(const float* params, const float* grads, int64_t n,
+                             const asr_segment* segments_dev, int n_seg, double* norm_out,
+                             void* workspace, size_t ws_bytes, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(params && grads && segments_dev && norm_out && workspace && n > 0 && n_seg > 0,
+                "grad_norm: bad arguments");
+  if (ws_bytes < asr_optim_workspace_bytes(n)) {
+    asr_set_error("grad_norm: workspace too small");
+    return ASR_ERR_WORKSPACE;
+  }
+  int blocks = grid_for(n);
+  if (blocks > kNormBlocks) blocks = kNormBlocks;
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(norm_partial_kernel, dim3(blocks), dim3(256), 0, stream, params, grads, n,
+                     segments_dev, n_seg, partial);
+  ASR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks,
+                     norm_out);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}
+
+extern "C" int asr_adam_step(float* params, const float* grads, float* m, float* v, int64_t n,
+                             const asr_segment* segments_dev, int n_seg,
+                             const double* norm_dev, float clipnorm, float lr, float beta1,
+                             float beta2, float eps, int step, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(params && grads && m && v && segments_dev && n > 0 && n_seg > 0 && step >= 1,
+                "adam: bad arguments");
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) /
+                      (1.0 - pow((double)beta1, step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, stream, params, grads, m, v,
+                     n, segments_dev, n_seg, norm_dev, clipnorm, (float)lr_t, beta1, beta2, eps);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}
+
+extern "C" int asr_sgd_step(float* params, const float* grads, float* vel, int64_t n,
+                            const asr_segment* segments_dev, int n_seg,
+                            const double* norm_dev, float clipnorm, float lr, float momentum,
+                            asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(params && grads && vel && segments_dev && n > 0 && n_seg > 0,
+                "sgd: bad arguments");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, params, grads, vel, n,
+                     segments_dev, n_seg, norm_dev, clipnorm, lr, momentum);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}

@@ -1,0 +1,265 @@
+"""Thin torch-tensor level wrappers over the C ABI (libasr_hip.so).
+
+torch is used ONLY as a device-memory / stream provider: every function here takes
+``tensor.data_ptr()`` and the current HIP stream handle and calls the C ABI through
+ctypes.  No torch.nn, no torch math on the hot path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
+                'expected contiguous float32 CUDA tensor'
+
+
+class _Workspaces(object):
+    """Caller-owned scratch buffers, grown on demand, one per op family."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, nbytes, device):
+        key = (name, str(device))
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
+
+
+WS = _Workspaces()
+
+
+def pad16(n):
+    return (int(n) + 15) // 16 * 16
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None,
+         alpha=1.0, beta=0.0, bias=None, a_scale=None, a_scale_period=0, c_scale=None,
+         c_scale_period=0, split_k=0, a_off=0, b_off=0, c_off=0):
+    """C[M,N] = alpha * opA(A) @ opB(B) + beta*C (+bias), see include/asr_hip.h.
+
+    A/B/Cm are float32 CUDA tensors used as raw storage; *_off are element
+    offsets into them (sub-matrix views without torch slicing semantics)."""
+    lib = L.load()
+    a = L.GemmArgs()
+    a.M, a.N, a.K = int(M), int(N), int(K)
+    a.trans_a, a.trans_b = int(bool(trans_a)), int(bool(trans_b))
+    a.A = A.data_ptr() + 4 * int(a_off)
+    a.B = B.data_ptr() + 4 * int(b_off)
+    a.C = Cm.data_ptr() + 4 * int(c_off)
+    a.lda = int(lda if lda is not None else (M if trans_a else K))
+    a.ldb = int(ldb if ldb is not None else (K if trans_b else N))
+    a.ldc = int(ldc if ldc is not None else N)
+    a.alpha, a.beta = float(alpha), float(beta)
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.a_scale = a_scale.data_ptr() if a_scale is not None else None
+    a.a_scale_period = int(a_scale_period)
+    a.a_scale_ld = int(a_scale.shape[-1]) if a_scale is not None else 0
+    a.c_scale = c_scale.data_ptr() if c_scale is not None else None
+    a.c_scale_period = int(c_scale_period)
+    a.c_scale_ld = int(c_scale.shape[-1]) if c_scale is not None else 0
+    a.split_k = int(split_k)
+    nbytes = lib.asr_gemm_workspace_bytes(C.byref(a))
+    ws = WS.get('gemm', nbytes, Cm.device) if nbytes else None
+    L.check(lib.asr_gemm(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_gemm')
+
+
+def colsum(X, M, N, ldx, out, beta=0.0, x_off=0):
+    lib = L.load()
+    L.check(lib.asr_colsum(C.c_void_p(X.data_ptr() + 4 * int(x_off)), int(M), int(N),
+                           int(ldx), _ptr(out), float(beta), _stream()), 'asr_colsum')
+
+
+# --------------------------------------------------------------------------- LSTM
+def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=None,
+               dy=None, dz=None, mode=0):
+    a = L.LstmArgs()
+    a.T, a.n_pad, a.H, a.mode = int(T), int(n_pad), int(H), int(mode)
+    a.U = U.data_ptr()
+    for name, t in (('mask_u', mask_u), ('zx', zx), ('y', y), ('cell', cell),
+                    ('gates', gates), ('dy', dy), ('dz', dz)):
+        setattr(a, name, t.data_ptr() if t is not None else None)
+    return a
+
+
+def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=False):
+    lib = L.load()
+    _check_f32(zx, U, y, cell, gates, mask_u)
+    a = _lstm_args(T, n_pad, H, U, mask_u, zx=zx, y=y, cell=cell, gates=gates, mode=mode)
+    nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 0)
+    ws = WS.get('lstm_fwd', nbytes, zx.device)
+    L.check(lib.asr_lstm_seq_fwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_fwd')
+    if check:
+        L.check(lib.asr_lstm_status(_ptr(ws), _stream()), 'asr_lstm_status(fwd)')
+    return ws
+
+
+def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check=False):
+    lib = L.load()
+    _check_f32(dy, U, cell, gates, dz, mask_u)
+    a = _lstm_args(T, n_pad, H, U, mask_u, cell=cell, gates=gates, dy=dy, dz=dz, mode=mode)
+    nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 1)
+    ws = WS.get('lstm_bwd', nbytes, dy.device)
+    L.check(lib.asr_lstm_seq_bwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_bwd')
+    if check:
+        L.check(lib.asr_lstm_status(_ptr(ws), _stream()), 'asr_lstm_status(bwd)')
+    return ws
+
+
+def lstm_status(ws):
+    L.check(L.load().asr_lstm_status(_ptr(ws), _stream()), 'asr_lstm_status')
+
+
+def lstm_plan(T, n_pad, H, backward):
+    lib = L.load()
+    a = L.LstmArgs()
+    a.T, a.n_pad, a.H = int(T), int(n_pad), int(H)
+    ks, r, blocks, cpl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    L.check(lib.asr_lstm_plan(C.byref(a), int(backward), C.byref(ks), C.byref(r),
+                              C.byref(blocks), C.byref(cpl)), 'asr_lstm_plan')
+    return dict(k_split=ks.value, k_per_lane=r.value, blocks=blocks.value,
+                chains_per_launch=cpl.value)
+
+
+# --------------------------------------------------------------------------- CTC
+def ctc_loss_grad(logits, labels, label_len, seq_len, N, grad=None, grad_scale=1.0,
+                  loss=None):
+    """logits (T, n_pad, C) float32; labels (N, l_max) int32; returns loss (N,)."""
+    lib = L.load()
+    T, n_pad, Cc = logits.shape
+    l_max = int(labels.shape[1])
+    _check_f32(logits, grad)
+    if loss is None:
+        loss = torch.empty(N, dtype=torch.float32, device=logits.device)
+    nbytes = lib.asr_ctc_workspace_bytes(T, int(N), n_pad, Cc, l_max)
+    ws = WS.get('ctc', nbytes, logits.device)
+    L.check(lib.asr_ctc_loss_grad(_ptr(logits), _ptr(labels), _ptr(label_len), _ptr(seq_len),
+                                  T, int(N), n_pad, Cc, l_max, float(grad_scale), _ptr(loss),
+                                  _ptr(grad), _ptr(ws), nbytes, _stream()),
+            'asr_ctc_loss_grad')
+    return loss
+
+
+def ctc_greedy(logits, seq_len, N):
+    lib = L.load()
+    T, n_pad, Cc = logits.shape
+    dec = torch.empty((int(N), T), dtype=torch.int32, device=logits.device)
+    dlen = torch.empty(int(N), dtype=torch.int32, device=logits.device)
+    L.check(lib.asr_ctc_greedy(_ptr(logits), _ptr(seq_len), T, int(N), n_pad, Cc, _ptr(dec),
+                               _ptr(dlen), _stream()), 'asr_ctc_greedy')
+    return dec, dlen
+
+
+def ctc_beam_search_host(logits_host, seq_len_host, N, beam_width=100, merge_repeated=True):
+    """logits_host: (T, n_pad, C) float32 numpy array (already on the host)."""
+    lib = L.load()
+    logits_host = np.ascontiguousarray(logits_host, dtype=np.float32)
+    seq = np.ascontiguousarray(seq_len_host, dtype=np.int32)
+    T, n_pad, Cc = logits_host.shape
+    dec = np.empty((int(N), T), dtype=np.int32)
+    dlen = np.empty(int(N), dtype=np.int32)
+    score = np.empty(int(N), dtype=np.float32)
+    L.check(lib.asr_ctc_beam_search_host(
+        logits_host.ctypes.data_as(C.c_void_p), seq.ctypes.data_as(C.c_void_p), T, int(N),
+        n_pad, Cc, int(beam_width), int(bool(merge_repeated)),
+        dec.ctypes.data_as(C.c_void_p), dlen.ctypes.data_as(C.c_void_p),
+        score.ctypes.data_as(C.c_void_p)), 'asr_ctc_beam_search_host')
+    return [dec[n, :dlen[n]].tolist() for n in range(int(N))], score
+
+
+def edit_distance_host(hyps, truths):
+    """Lists of int lists -> per-sample normalised Levenshtein (numpy float32)."""
+    lib = L.load()
+    N = len(hyps)
+
+    def pack(seqs):
+        ld = max([len(s) for s in seqs] + [1])
+        a = np.zeros((N, ld), np.int32)
+        ln = np.zeros(N, np.int32)
+        for i, s in enumerate(seqs):
+            a[i, :len(s)] = s
+            ln[i] = len(s)
+        return a, ln, ld
+
+    h, hl, hld = pack(hyps)
+    t, tl, tld = pack(truths)
+    out = np.empty(N, np.float32)
+    L.check(lib.asr_edit_distance_host(
+        h.ctypes.data_as(C.c_void_p), hl.ctypes.data_as(C.c_void_p), hld,
+        t.ctypes.data_as(C.c_void_p), tl.ctypes.data_as(C.c_void_p), tld, N,
+        out.ctypes.data_as(C.c_void_p)), 'asr_edit_distance_host')
+    return out
+
+
+# --------------------------------------------------------------------------- optimiser
+def make_segments(entries, device):
+    """entries: list of (offset, length, l2) -> device buffer of asr_segment."""
+    arr = (L.Segment * len(entries))()
+    for i, (off, ln, l2) in enumerate(entries):
+        arr[i].offset, arr[i].len, arr[i].l2, arr[i].reserved = int(off), int(ln), float(l2), 0.0
+    raw = np.frombuffer(memoryview(arr), dtype=np.uint8).copy()
+    return torch.from_numpy(raw).to(device), len(entries)
+
+
+def grad_norm(params, grads, segs, n_seg, norm_out):
+    lib = L.load()
+    n = params.numel()
+    nbytes = lib.asr_optim_workspace_bytes(n)
+    ws = WS.get('optim', nbytes, params.device)
+    L.check(lib.asr_grad_norm(_ptr(params), _ptr(grads), n, _ptr(segs), n_seg, _ptr(norm_out),
+                              _ptr(ws), nbytes, _stream()), 'asr_grad_norm')
+
+
+def adam_step(params, grads, m, v, segs, n_seg, norm, clipnorm, lr, step, beta1=0.9,
+              beta2=0.999, eps=1e-8):
+    L.check(L.load().asr_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), params.numel(),
+                                   _ptr(segs), n_seg, _ptr(norm), float(clipnorm), float(lr),
+                                   float(beta1), float(beta2), float(eps), int(step),
+                                   _stream()), 'asr_adam_step')
+
+
+def sgd_step(params, grads, vel, segs, n_seg, norm, clipnorm, lr, momentum=0.9):
+    L.check(L.load().asr_sgd_step(_ptr(params), _ptr(grads), _ptr(vel), params.numel(),
+                                  _ptr(segs), n_seg, _ptr(norm), float(clipnorm), float(lr),
+                                  float(momentum), _stream()), 'asr_sgd_step')
+
+
+# --------------------------------------------------------------------------- front-end
+def frontend_features(cfg, audio, offsets, lengths, host_lengths, n_pad, tables, t_out):
+    """cfg: _lib.FrontendCfg; audio float32 CUDA (concatenated); offsets/lengths
+    int32 CUDA; tables: dict(window, mel, mel_range, dct) CUDA tensors.
+    Returns (out (t_out, n_pad, F) float32, out_frames int32 (n_utt,))."""
+    lib = L.load()
+    n_utt = len(host_lengths)
+    hl = (C.c_int * n_utt)(*[int(x) for x in host_lengths])
+    ffull = lib.asr_frontend_num_feats(C.byref(cfg))
+    f_out = ffull * (2 * cfg.num_context + 1)
+    max_frames = max(lib.asr_frontend_num_frames(int(x), cfg.frame_len, cfg.frame_step)
+                     for x in host_lengths)
+    nbytes = lib.asr_frontend_workspace_bytes(C.byref(cfg), n_utt, max_frames)
+    ws = WS.get('frontend', nbytes, audio.device)
+    out = torch.empty((int(t_out), int(n_pad), f_out), dtype=torch.float32, device=audio.device)
+    frames = torch.empty(n_utt, dtype=torch.int32, device=audio.device)
+    L.check(lib.asr_frontend_features(
+        C.byref(cfg), _ptr(audio), _ptr(offsets), _ptr(lengths), hl, n_utt, int(n_pad),
+        _ptr(tables['window']), _ptr(tables['mel']), _ptr(tables['mel_range']),
+        _ptr(tables.get('dct')), _ptr(out), int(t_out), _ptr(frames), _ptr(ws), nbytes,
+        _stream()), 'asr_frontend_features')
+    return out, frames

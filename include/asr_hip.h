@@ -1,0 +1,238 @@
+/* asr_hip.h -- C ABI of libasr_hip.so: the MI355X (gfx950) kernels behind the
+ * asr-study acoustic-training hot path (MFCC/log-mel -> BiLSTM stack -> CTC).
+ *
+ * The reference (igormq/asr-study) has NO native/FFI boundary: every op on this
+ * path is a Keras-1.2.2 / TensorFlow-1.3.0 / NumPy call made from Python.  Each
+ * entry point below therefore cites the reference call site whose arithmetic it
+ * replaces (paths relative to the reference checkout); INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C types only; device pointers are raw addresses (from
+ *    torch.Tensor.data_ptr() on the Python side); no torch types anywhere.
+ *  - the CALLER owns all memory.  Scratch space is sized by the matching
+ *    *_workspace_bytes() query and passed in; the library never allocates
+ *    persistent device memory.
+ *  - all work is enqueued on the given hipStream_t (passed as void*); no entry
+ *    point synchronises the device unless its comment says so.
+ *  - every function returns 0 on success or a negative asr_status; the message
+ *    is available from asr_last_error() (thread-local).
+ *  - activations are TIME-MAJOR slabs (T, Npad, feat) float32, Npad = batch
+ *    rounded up to a multiple of 16 (rows n >= N are padding and carry zeros).
+ *  - fused gate layout: every (.., 4H) gate axis is ordered unit-major,
+ *    gate-minor: column = unit*4 + gate, gate in {0:i, 1:f, 2:c, 3:o}
+ *    (Keras' consume_less='gpu' layout is gate-major: column = gate*H + unit;
+ *    core/layers.py:447-450.  The Python host converts at the checkpoint edge.)
+ */
+#ifndef ASR_HIP_H
+#define ASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* asr_stream_t; /* hipStream_t */
+
+enum asr_status {
+  ASR_OK = 0,
+  ASR_ERR_INVALID = -1,   /* bad argument / unsupported shape            */
+  ASR_ERR_WORKSPACE = -2, /* workspace too small                         */
+  ASR_ERR_LAUNCH = -3,    /* HIP launch or runtime error                 */
+  ASR_ERR_TIMEOUT = -4,   /* persistent kernel gave up on a bounded spin */
+  ASR_ERR_RESIDENCY = -5  /* persistent grid would not be co-resident    */
+};
+
+const char* asr_last_error(void);
+int asr_version(void);
+/* Device facts the host needs for sizing persistent grids (CU count etc). */
+int asr_device_info(int* num_cus, int* lds_bytes_per_cu, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------ */
+/* K1-K3  Front-end.  Replaces preprocessing/audio.py:223-253 (FBank._call:  */
+/* preemphasis, framing, Hamming, |rFFT|^2/nfft, energy, mel filterbank),    */
+/* :339-367 (MFCC._call: log, DCT-II ortho, lifter, c0<-log energy, deltas), */
+/* :404-442 (LogFbank._call), :77-150 (_postprocessing: stride / context)    */
+/* and :70-75 (_standarize) together with preprocessing/audio_utils.py       */
+/* :17-50,:98-120,:143-173.                                                  */
+/* ------------------------------------------------------------------------ */
+typedef struct asr_frontend_cfg {
+  int kind;          /* 0 = MFCC, 1 = LogFbank                               */
+  int frame_len;     /* round_half_up(win_len*fs)   (400)                    */
+  int frame_step;    /* round_half_up(win_step*fs)  (160)                    */
+  int nfft;          /* 512 (must be 512 in this build)                      */
+  int num_filt;      /* 40 / 80 (<= 128)                                     */
+  int num_cep;       /* 13 (MFCC only, <= 64)                                */
+  int append_energy; /* MFCC: c0 <- log(energy+eps); LogFbank: extra column  */
+  int d, dd;         /* append deltas / delta-deltas                         */
+  int stride;        /* keep every stride-th frame                           */
+  int num_context;   /* +-context frame stacking (zero rows off the edges)   */
+  int mean_norm, var_norm;
+  float pre_emph;    /* 0.97                                                 */
+  float eps;         /* 1e-8                                                 */
+} asr_frontend_cfg;
+
+/* Number of frames for a signal of `samples` samples (audio_utils.py:29-32). */
+int asr_frontend_num_frames(int samples, int frame_len, int frame_step);
+/* Feature columns produced per frame BEFORE context stacking ((1+d+dd)*base). */
+int asr_frontend_num_feats(const asr_frontend_cfg* cfg);
+size_t asr_frontend_workspace_bytes(const asr_frontend_cfg* cfg, int n_utt,
+                                    int max_frames);
+/* audio: concatenated float32 samples; offsets[i]/lengths[i] (device int32)
+ * delimit utterance i.  window (frame_len), mel (num_filt x (nfft/2+1), dense
+ * row-major, from audio.py:255-277 computed on the host in float64), mel_range
+ * (num_filt x {first, last+1} non-zero bin of each filter, device int32), dct
+ * (num_filt x num_cep: scipy DCT-II 'ortho' with the lifter folded in; MFCC
+ * only) are float32 device tables.  out is the (T_out, n_pad, F_out) time-major
+ * slab (row stride n_pad*F_out), zero-filled past each utterance's frames
+ * (pad_sequences(padding='post'), datasets/dataset_generator.py:227);
+ * out_frames[i] (device int32) receives the frame count after striding.
+ * host_lengths mirrors `lengths` on the host (grid sizing; no device sync). */
+int asr_frontend_features(const asr_frontend_cfg* cfg, const float* audio,
+                          const int* offsets, const int* lengths,
+                          const int* host_lengths, int n_utt, int n_pad,
+                          const float* window, const float* mel,
+                          const int* mel_range, const float* dct, float* out,
+                          int t_out,
+                          int* out_frames, void* workspace, size_t ws_bytes,
+                          asr_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* K4/K6  fp32 MFMA GEMM.  Replaces K.dot(x*B_W, W) (core/layers.py:439,     */
+/* hoisted out of the time loop), TimeDistributed(Dense) (core/models.py     */
+/* :278-279) and their tf.gradients.                                         */
+/*   C[M,N] = alpha * (opA(A) (.) a_scale) @ opB(B) + beta * C (+ bias[N])   */
+/*   then C (.)= c_scale.  trans_a: A is stored (K,M) row-major; trans_b: B  */
+/*   is stored (N,K) row-major.  a_scale / c_scale: optional (period, M or K */
+/*   / N) variational-dropout masks indexed by (row % period); pass NULL.    */
+/* split_k > 1 needs workspace of split_k*M*N floats (deterministic reduce). */
+/* ------------------------------------------------------------------------ */
+typedef struct asr_gemm_args {
+  int M, N, K;
+  int trans_a, trans_b;
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;
+  float alpha, beta;
+  const float* bias;       /* (N) added to every row, or NULL                */
+  const float* a_scale;    /* (period x Kdim-or-Mdim) mask on A rows or NULL */
+  int a_scale_period;      /* row index modulo this selects the mask row     */
+  int a_scale_ld;
+  const float* c_scale;    /* (period x N) mask on C rows, or NULL           */
+  int c_scale_period;
+  int c_scale_ld;
+  int split_k;             /* 0/1 = none                                     */
+} asr_gemm_args;
+size_t asr_gemm_workspace_bytes(const asr_gemm_args* a);
+int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes,
+             asr_stream_t stream);
+/* out[n] (+)= sum_m X[m, n]  (bias gradients).                              */
+int asr_colsum(const float* X, int M, int N, int ldx, float* out, float beta,
+               asr_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* K5  Recurrent LSTM sequence kernels (both directions of one Bidirectional */
+/* layer per call).  Replace core/layers.py:432-469 (LSTM.step) iterated by  */
+/* Keras K.rnn, and its BPTT.  Gate math: i,f,o = hard_sigmoid = clip(.2x+.5, */
+/* 0,1); c = f*c + i*tanh(z_c); h = o*tanh(c); h0 = c0 = 0; the reverse      */
+/* direction walks the PADDED slab from T-1 down to 0 (no Masking).          */
+/* ------------------------------------------------------------------------ */
+typedef struct asr_lstm_args {
+  int T, n_pad, H;     /* n_pad % 16 == 0, H % 4 == 0                        */
+  int mode;            /* 0 = persistent (default), 1 = one launch per step  */
+  const float* U;      /* (2, H, 4H)  [dir][k][unit*4+gate]                  */
+  const float* mask_u; /* (2, n_pad, H) variational mask B_U or NULL         */
+  /* forward: zx (T, n_pad, 2, 4H) = x@W+b precomputed; outputs y (T, n_pad, */
+  /* 2H) = [h_fwd | h_bwd], cell (T, n_pad, 2, H), gates (T, n_pad, 2, 4H)   */
+  /* post-activation (kept for BPTT).                                        */
+  const float* zx;
+  float* y;
+  float* cell;
+  float* gates;
+  /* backward: dy (T, n_pad, 2H) in; dz (T, n_pad, 2, 4H) out.               */
+  const float* dy;
+  float* dz;
+} asr_lstm_args;
+size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
+int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,
+                     asr_stream_t stream);
+int asr_lstm_seq_bwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,
+                     asr_stream_t stream);
+/* Synchronises `stream`, then returns 0 or ASR_ERR_TIMEOUT if a persistent
+ * kernel that used this workspace abandoned a bounded spin (results invalid). */
+int asr_lstm_status(const void* workspace, asr_stream_t stream);
+/* Launch plan the library would use (diagnostics / DESIGN.md numbers).       */
+int asr_lstm_plan(const asr_lstm_args* a, int backward, int* k_split,
+                  int* k_per_lane, int* blocks, int* chains_per_launch);
+
+/* ------------------------------------------------------------------------ */
+/* K7  CTC loss + gradient.  Replaces core/ctc_utils.py:60-70 ->             */
+/* tf.nn.ctc_loss (blank = C-1, internal softmax, ctc_merge_repeated=True).  */
+/* logits/grad: (T, n_pad, C) time-major.  labels (N, l_max) int32 padded,   */
+/* label_len/seq_len (N) int32, all on the device.  loss[n] = -log p(l|x);   */
+/* grad = grad_scale * d loss_n / d logits, 0 for t >= seq_len[n] and for    */
+/* padding rows n >= N.  An infeasible target yields loss = +inf, grad = 0   */
+/* (the host raises the TF error before launching).                          */
+/* ------------------------------------------------------------------------ */
+size_t asr_ctc_workspace_bytes(int T, int N, int n_pad, int C, int l_max);
+int asr_ctc_loss_grad(const float* logits, const int* labels,
+                      const int* label_len, const int* seq_len, int T, int N,
+                      int n_pad, int C, int l_max, float grad_scale,
+                      float* loss, float* grad, void* workspace,
+                      size_t ws_bytes, asr_stream_t stream);
+
+/* K8  Greedy decode.  Replaces core/ctc_utils.py:42 ->                      */
+/* tf.nn.ctc_greedy_decoder (first-max argmax, merge repeats, drop blank).   */
+/* decoded (N, T) int32 padded with -1; decoded_len (N).                     */
+int asr_ctc_greedy(const float* logits, const int* seq_len, int T, int N,
+                   int n_pad, int C, int* decoded, int* decoded_len,
+                   asr_stream_t stream);
+
+/* K9  Beam search (host side of the library; logits already on the host).   */
+/* Replaces core/ctc_utils.py:48-50 -> tf.nn.ctc_beam_search_decoder         */
+/* (top_paths=1, merge_repeated as given).  logits (T, n_pad, C) HOST float. */
+int asr_ctc_beam_search_host(const float* logits_host, const int* seq_len_host,
+                             int T, int N, int n_pad, int C, int beam_width,
+                             int merge_repeated, int* decoded, int* decoded_len,
+                             float* log_score);
+
+/* K10 Edit distance (host).  Replaces core/metrics.py:8 -> tf.edit_distance */
+/* (normalize=True).  Ragged inputs as (N, max) padded + lengths.            */
+int asr_edit_distance_host(const int* hyp, const int* hyp_len, int hyp_ld,
+                           const int* truth, const int* truth_len, int truth_ld,
+                           int N, float* out_normalized);
+
+/* ------------------------------------------------------------------------ */
+/* K11 Optimiser.  Replaces Keras Adam/SGD with clipnorm (train.py:133-137)  */
+/* and the l2 regularisers (core/models.py:263-264,279).  params/grads/m/v   */
+/* are flat float32 buffers of n elements; segments (n_seg x {int64 offset,  */
+/* int64 len, float l2, float pad}) give the per-tensor l2 coefficient.      */
+/* Step 1 writes norm_out[0] = ||g + 2*l2*p||_2 and norm_out[1] = sum l2*p^2 */
+/* (both float64, device).  Step 2 applies the update using norm_out[0]      */
+/* without a host round trip.                                                */
+/* ------------------------------------------------------------------------ */
+typedef struct asr_segment {
+  int64_t offset;
+  int64_t len;
+  float l2;
+  float reserved;
+} asr_segment;
+size_t asr_optim_workspace_bytes(int64_t n);
+int asr_grad_norm(const float* params, const float* grads, int64_t n,
+                  const asr_segment* segments_dev, int n_seg, double* norm_out,
+                  void* workspace, size_t ws_bytes, asr_stream_t stream);
+int asr_adam_step(float* params, const float* grads, float* m, float* v,
+                  int64_t n, const asr_segment* segments_dev, int n_seg,
+                  const double* norm_dev, float clipnorm, float lr, float beta1,
+                  float beta2, float eps, int step, asr_stream_t stream);
+int asr_sgd_step(float* params, const float* grads, float* vel, int64_t n,
+                 const asr_segment* segments_dev, int n_seg,
+                 const double* norm_dev, float clipnorm, float lr,
+                 float momentum, asr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_HIP_H */

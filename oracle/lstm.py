@@ -76,6 +76,7 @@ def lstm_backward(dhs, cache):
     dt = x.dtype
     dW = np.zeros_like(W); dU = np.zeros_like(U); db = np.zeros(4 * H, dt)
     dxs = np.zeros_like(xs)
+    dzs = np.zeros((T, N, 4 * H), dt)
     dh_next = np.zeros((N, H), dt)
     dc_next = np.zeros((N, H), dt)
     order = list(range(T - 1, -1, -1) if reverse else range(T))
@@ -98,6 +99,7 @@ def lstm_backward(dhs, cache):
             df * hard_sigmoid_grad(z[:, H:2 * H]),
             dg * (1.0 - g * g),
             do * hard_sigmoid_grad(z[:, 3 * H:])], axis=1)
+        dzs[t] = dz
         hm = h_prev if BU is None else h_prev * BU
         dW += xs[t].T @ dz
         dU += hm.T @ dz
@@ -106,6 +108,7 @@ def lstm_backward(dhs, cache):
         dhm = dz @ U.T
         dh_next = dhm if BU is None else dhm * BU
     dx = dxs if BW is None else dxs * BW[None]
+    cache['dzs'] = dzs          # gate pre-activation gradients (kernel parity tests)
     return dx, dW, dU, db
 
 

@@ -1,0 +1,87 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU, exports every
+symbol include/asr_hip.h declares, and its host-side entry points (beam search,
+edit distance) agree with the oracle.  No device compute here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from asr_study_amd import _lib as L
+from oracle import decode as OD
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return L.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, 'include', 'asr_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(asr_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libasr_hip.so does not export %s' % name
+        assert name in L.SIGNATURES, 'no ctypes signature for %s' % name
+    assert lib.asr_version() >= 100
+
+
+def test_frontend_frame_count(lib):
+    for n, want in ((160000, 999), (16000, 99), (400, 1), (401, 2), (2, 1)):
+        assert lib.asr_frontend_num_frames(n, 400, 160) == want
+
+
+def test_edit_distance_host(lib):
+    from asr_study_amd import ops
+    hyps = [[1, 2, 3], [], [5], [1, 1, 1, 1], []]
+    truths = [[1, 3], [1, 2], [], [1], []]
+    got = ops.edit_distance_host(hyps, truths)
+    want = [OD.normalized_edit_distance(h, t) for h, t in zip(hyps, truths)]
+    assert np.allclose(got, want) or (np.isinf(got[2]) and np.isinf(want[2]))
+    assert got[0] == 0.5 and got[1] == 1.0 and np.isinf(got[2]) and got[3] == 3.0 and got[4] == 0
+
+
+@pytest.mark.parametrize('beam_width', [1, 4, 25, 100])
+def test_beam_search_host_matches_oracle(lib, beam_width):
+    from asr_study_amd import ops
+    rs = np.random.RandomState(beam_width)
+    T, N, n_pad, C = 40, 5, 16, 8
+    logits = (rs.randn(T, n_pad, C) * 3).astype(np.float32)
+    seq = np.array([40, 31, 1, 17, 40], np.int32)
+    paths, score = ops.ctc_beam_search_host(logits, seq, N, beam_width, True)
+    for n in range(N):
+        want, sc = OD.beam_search_decode_one(logits[:seq[n], n], beam_width,
+                                             merge_repeated=True, dtype=np.float64)
+        assert paths[n] == want[0], (n, paths[n], want[0])
+        assert abs(score[n] - sc[0]) < 1e-3 * max(1.0, abs(sc[0]))
+    plain, _ = ops.ctc_beam_search_host(logits, seq, N, beam_width, False)
+    for n in range(N):
+        want, _ = OD.beam_search_decode_one(logits[:seq[n], n], beam_width,
+                                            merge_repeated=False, dtype=np.float64)
+        assert plain[n] == want[0]
+
+
+def test_beam_search_host_28_classes_width_100(lib):
+    from asr_study_amd import ops
+    rs = np.random.RandomState(7)
+    T, N, n_pad, C = 60, 2, 16, 28
+    logits = (rs.randn(T, n_pad, C) * 2).astype(np.float32)
+    seq = np.array([60, 45], np.int32)
+    paths, _ = ops.ctc_beam_search_host(logits, seq, N, 100, True)
+    for n in range(N):
+        want, _ = OD.beam_search_decode_one(logits[:seq[n], n], 100, merge_repeated=True,
+                                            dtype=np.float64)
+        assert paths[n] == want[0]
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(L.AsrHipError):
+        L.load()
