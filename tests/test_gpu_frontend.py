@@ -1,0 +1,74 @@
+"""-m gpu: MFCC / log-mel front-end through the product classes vs the golden
+vectors generated from the reference's own code (tests/golden) and the oracle.
+Tolerance: 2e-4 abs on the standardised (unit-variance) features."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend as OF
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+CONFIGS = {
+    'mfcc39': ('MFCC', {}),
+    'mfcc26': ('MFCC', {'dd': False}),
+    'mfcc13': ('MFCC', {'d': False, 'dd': False}),
+    'logfbank40': ('LogFbank', {}),
+    'logfbank80': ('LogFbank', {'num_filt': 80}),
+    'logfbank41_d_dd': ('LogFbank', {'append_energy': True, 'd': True, 'dd': True}),
+    'mfcc39_s2c2': ('MFCC', {'stride': 2, 'num_context': 2}),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CONFIGS))
+def test_against_reference_golden(name, golden_dir):
+    from asr_study_amd.preprocessing import audio
+    from tests.gpu_util import report
+    cls, kw = CONFIGS[name]
+    feat = getattr(audio, cls)(**kw)
+    g = np.load(os.path.join(golden_dir, 'frontend_%s.npz' % name))
+    worst = 0.0
+    for key in g.files:
+        parts = key.split('_')
+        n, seed = int(parts[0][1:]), int(parts[1][1:])
+        x = np.random.RandomState(seed).randn(n)
+        y = feat(x)
+        assert y.shape == g[key].shape, (key, y.shape, g[key].shape)
+        worst = max(worst, report('%s %s' % (name, key), y, g[key]))
+    assert worst < TOL
+
+
+def test_ragged_batch_into_time_major_slab():
+    from asr_study_amd.preprocessing import audio
+    rs = np.random.RandomState(0)
+    lens = [16000, 300, 52345, 401, 160000, 8000]
+    sigs = [rs.randn(n) for n in lens]
+    feat = audio.MFCC()
+    slab, frames = feat.batch(sigs)              # (T, n_pad, 39) CUDA, frames (N,)
+    torch.cuda.synchronize()
+    slab = slab.cpu().numpy()
+    frames = frames.cpu().numpy()
+    assert slab.shape[1] == 16 and slab.shape[2] == 39
+    for i, s in enumerate(sigs):
+        want = OF.extract('mfcc', s)
+        assert frames[i] == want.shape[0]
+        assert np.abs(slab[:frames[i], i] - want).max() < TOL
+        assert np.all(slab[frames[i]:, i] == 0)           # pad_sequences 'post'
+    assert np.all(slab[:, len(sigs):] == 0)               # batch padding rows
+
+
+def test_no_norm_and_properties():
+    from asr_study_amd.preprocessing import audio
+    x = np.random.RandomState(5).randn(20000)
+    y = audio.LogFbank(num_filt=80)(x)
+    # empty mel filters 1 and 7 -> constant column -> exactly 0
+    assert np.all(y[:, 1] == 0) and np.all(y[:, 7] == 0)
+    assert np.abs(y.mean(0)).max() < 1e-4
+    live = [c for c in range(80) if c not in (1, 7)]
+    assert np.abs(y[:, live].std(0) - 1).max() < 1e-3
+    y2 = audio.MFCC(mean_norm=False, var_norm=False)(x)
+    want = OF.extract('mfcc', x, mean_norm=False, var_norm=False)
+    assert np.abs(y2 - want).max() < 5e-4 * max(1.0, np.abs(want).max())

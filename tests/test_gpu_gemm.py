@@ -1,0 +1,85 @@
+"""-m gpu: fp32 MFMA GEMM through the C ABI vs float64 NumPy (exact-fp32 MFMA:
+tolerance = fp32 accumulation round-off, 2e-6 * K * max|a||b|)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import to_dev, report
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # M, N, K, trans_a, trans_b, split_k
+    (300, 200, 64, False, False, 0),
+    (257, 130, 39, False, False, 0),      # first-layer K=39, unaligned lda
+    (128, 128, 16, True, False, 0),
+    (77, 28, 100, False, True, 0),        # dense C=28 style, trans_b
+    (39, 1024, 999, True, False, 4),      # dW style: K long, split-K
+    (512, 96, 700, True, True, 3),
+    (1000, 260, 28, False, True, 0),      # K=28 (dlogits @ Wd^T)
+]
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb,sk', CASES)
+def test_gemm_variants(M, N, K, ta, tb, sk):
+    from asr_study_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    A = rs.randn(K, M) if ta else rs.randn(M, K)
+    B = rs.randn(N, K) if tb else rs.randn(K, N)
+    C0 = rs.randn(M, N)
+    bias = rs.randn(N)
+    want = 0.75 * ((A.T if ta else A) @ (B.T if tb else B)) + 0.5 * C0 + bias
+    Cd = to_dev(C0.astype(np.float32))
+    ops.gemm(to_dev(A.astype(np.float32)), to_dev(B.astype(np.float32)), Cd, M, N, K,
+             trans_a=ta, trans_b=tb, alpha=0.75, beta=0.5, bias=to_dev(bias.astype(np.float32)),
+             split_k=sk)
+    torch.cuda.synchronize()
+    err = report('gemm %dx%dx%d ta=%d tb=%d sk=%d' % (M, N, K, ta, tb, sk), Cd.cpu().numpy(), want)
+    assert err < 3e-6 * K * 12 + 1e-5
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric B catches swapped row/col in the C write."""
+    from asr_study_amd import ops
+    M = N = K = 96
+    B = np.arange(K * N, dtype=np.float32).reshape(K, N) / 100.0
+    Cd = torch.zeros((M, N), dtype=torch.float32, device='cuda:0')
+    ops.gemm(to_dev(np.eye(M, dtype=np.float32)), to_dev(B), Cd, M, N, K)
+    torch.cuda.synchronize()
+    assert np.array_equal(Cd.cpu().numpy(), B)
+
+
+def test_gemm_masks_and_strided_views():
+    """Variational-dropout masks on A rows / C rows and sub-matrix offsets (the
+    dU = H_prev^T dZ pattern: A is a column slice of y shifted by one time step)."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(0)
+    T, NB, H = 9, 16, 20
+    y = rs.randn(T * NB, 2 * H).astype(np.float32)            # (T*N, 2H)
+    dz = rs.randn(T * NB, 2 * 4 * H).astype(np.float32)       # (T*N, 2, 4H)
+    mask = ((rs.rand(NB, H) > 0.3) / 0.7).astype(np.float32)
+    # dU_fwd = sum_t (y[t-1,:, :H] * mask)^T dz[t, :, 0:4H]
+    want = np.zeros((H, 4 * H))
+    for t in range(1, T):
+        hm = y[(t - 1) * NB:t * NB, :H].astype(np.float64) * mask
+        want += hm.T @ dz[t * NB:(t + 1) * NB, :4 * H]
+    out = torch.zeros((H, 4 * H), dtype=torch.float32, device='cuda:0')
+    ops.gemm(to_dev(y), to_dev(dz), out, H, 4 * H, (T - 1) * NB, trans_a=True, trans_b=False,
+             lda=2 * H, ldb=8 * H, ldc=4 * H, a_scale=to_dev(mask), a_scale_period=NB,
+             b_off=NB * 8 * H, split_k=2)
+    torch.cuda.synchronize()
+    assert report('gemm dU-style', out.cpu().numpy(), want) < 1e-3
+    # dX = (dz @ W^T) * maskW   (c_scale, trans_b)
+    W = rs.randn(24, 8 * H).astype(np.float32)
+    mw = ((rs.rand(NB, 24) > 0.2) / 0.8).astype(np.float32)
+    want = (dz.astype(np.float64) @ W.T.astype(np.float64)) * np.tile(mw, (T, 1))
+    out = torch.zeros((T * NB, 24), dtype=torch.float32, device='cuda:0')
+    ops.gemm(to_dev(dz), to_dev(W), out, T * NB, 24, 8 * H, trans_b=True, c_scale=to_dev(mw),
+             c_scale_period=NB)
+    torch.cuda.synchronize()
+    assert report('gemm dX-style', out.cpu().numpy(), want) < 1e-3
+    # colsum
+    cs = torch.zeros(8 * H, dtype=torch.float32, device='cuda:0')
+    ops.colsum(to_dev(dz), T * NB, 8 * H, 8 * H, cs)
+    torch.cuda.synchronize()
+    assert report('colsum', cs.cpu().numpy(), dz.astype(np.float64).sum(0)) < 1e-4

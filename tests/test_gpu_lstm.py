@@ -1,0 +1,96 @@
+"""-m gpu: recurrent LSTM kernels (forward + BPTT, persistent and per-step modes)
+through the C ABI vs the float64 oracle.  Tolerance: activations atol 1e-4
+(north_star: "LSTM activations within 1e-4 fp32"); gate gradients atol 1e-4
+relative to max|dz|."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lstm as OL
+from tests.gpu_util import (to_dev, pad_batch, report, gate_major_to_unit_major)
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(T, N, F, H, seed, use_mask):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(T, N, F)
+    p = {d: OL.init_lstm(rs, F, H, np.float64) for d in ('fwd', 'bwd')}
+    for d in p:
+        p[d]['b'] = p[d]['b'] + rs.randn(4 * H) * 0.3
+        p[d]['U'] = p[d]['U'] * 0.8
+    masks = {d: None for d in p}
+    if use_mask:
+        masks = {d: ((rs.rand(N, H) > 0.2) / 0.8) for d in p}
+    return rs, x, p, masks
+
+
+def _oracle(x, p, masks, dhs=None):
+    out = {}
+    for d, rev in (('fwd', False), ('bwd', True)):
+        hs, cache = OL.lstm_forward(x, p[d]['W'], p[d]['U'], p[d]['b'], rev, None, masks[d])
+        out[d] = dict(hs=hs, cache=cache)
+        if dhs is not None:
+            OL.lstm_backward(dhs[d], cache)
+    return out
+
+
+def _pack_inputs(x, p, masks, H, n_pad):
+    T, N, F = x.shape
+    zx = np.zeros((T, n_pad, 2, 4 * H), np.float32)
+    U = np.zeros((2, H, 4 * H), np.float32)
+    mk = np.ones((2, n_pad, H), np.float32)
+    for di, d in enumerate(('fwd', 'bwd')):
+        z = x @ p[d]['W'] + p[d]['b']                     # (T,N,4H) gate-major
+        zx[:, :N, di] = gate_major_to_unit_major(z, H)
+        # padding rows get the bias only (x = 0), like the real pipeline
+        zx[:, N:, di] = gate_major_to_unit_major(p[d]['b'][None, None], H)
+        U[di] = gate_major_to_unit_major(p[d]['U'], H)
+        if masks[d] is not None:
+            mk[di, :N] = masks[d]
+    return zx, U, mk
+
+
+@pytest.mark.parametrize('T,N,F,H,mode,use_mask', [
+    (30, 5, 7, 16, 1, False),        # per-step launches
+    (30, 5, 7, 16, 0, False),        # persistent
+    (61, 20, 9, 100, 0, True),       # cfg1 width (H=100: ragged K split), masks
+    (200, 32, 12, 256, 0, False),    # cfg2 width
+    (25, 16, 8, 512, 0, False),      # cfg3 width
+    (25, 16, 8, 256, 1, True),
+])
+def test_forward_and_backward(T, N, F, H, mode, use_mask):
+    from asr_study_amd import ops
+    rs, x, p, masks = _case(T, N, F, H, T + H, use_mask)
+    n_pad = ops.pad16(N)
+    dhs = {d: rs.randn(T, N, H) for d in ('fwd', 'bwd')}
+    want = _oracle(x, p, masks, dhs)
+    zx, U, mk = _pack_inputs(x, p, masks, H, n_pad)
+    zx_d, U_d = to_dev(zx), to_dev(U)
+    mk_d = to_dev(mk) if use_mask else None
+    y = torch.full((T, n_pad, 2 * H), 3.0, dtype=torch.float32, device='cuda:0')
+    cell = torch.full((T, n_pad, 2, H), 3.0, dtype=torch.float32, device='cuda:0')
+    gates = torch.full((T, n_pad, 2, 4 * H), 3.0, dtype=torch.float32, device='cuda:0')
+    print('plan fwd', ops.lstm_plan(T, n_pad, H, 0), 'bwd', ops.lstm_plan(T, n_pad, H, 1))
+    ops.lstm_seq_fwd(zx_d, U_d, y, cell, gates, T, n_pad, H, mask_u=mk_d, mode=mode, check=True)
+    yh, ch, gh = y.cpu().numpy(), cell.cpu().numpy(), gates.cpu().numpy()
+    tag = 'T%d N%d H%d m%d' % (T, N, H, mode)
+    for di, d in enumerate(('fwd', 'bwd')):
+        assert report('lstm h %s %s' % (d, tag), yh[:, :N, di * H:(di + 1) * H], want[d]['hs']) < 1e-4
+        assert report('lstm c %s %s' % (d, tag), ch[:, :N, di], want[d]['cache']['cs']) < 1e-4
+        assert report('lstm gates %s %s' % (d, tag), gh[:, :N, di],
+                      gate_major_to_unit_major(want[d]['cache']['gates'], H)) < 1e-4
+    # ---- BPTT: feed the oracle's upstream gradient, compare gate gradients
+    dy = np.zeros((T, n_pad, 2 * H), np.float32)
+    dy[:, :N, :H] = dhs['fwd']
+    dy[:, :N, H:] = dhs['bwd']
+    dz = torch.full((T, n_pad, 2, 4 * H), 5.0, dtype=torch.float32, device='cuda:0')
+    ops.lstm_seq_bwd(to_dev(dy), U_d, cell, gates, dz, T, n_pad, H, mask_u=mk_d, mode=mode,
+                     check=True)
+    dzh = dz.cpu().numpy()
+    for di, d in enumerate(('fwd', 'bwd')):
+        w = gate_major_to_unit_major(want[d]['cache']['dzs'], H)
+        scale = max(1.0, np.abs(w).max())
+        assert report('lstm dz %s %s' % (d, tag), dzh[:, :N, di], w) < 1e-4 * scale
+    # padding rows received zero upstream gradient -> exactly zero gate gradients
+    assert np.all(dzh[:, N:] == 0)

@@ -1,0 +1,45 @@
+"""-m gpu: global-norm clip + Adam / SGD through the C ABI vs oracle/optim.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import optim as OO
+from tests.gpu_util import to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('clip', [0.0, 3.0, 1e6])
+def test_adam_and_sgd(clip):
+    from asr_study_amd import ops
+    rs = np.random.RandomState(0)
+    sizes = [1000, 37, 4096, 5]
+    l2s = [1e-2, 0.0, 1e-3, 0.0]
+    n = sum(sizes)
+    p0 = rs.randn(n).astype(np.float32)
+    offs = np.cumsum([0] + sizes[:-1])
+    segs, nseg = ops.make_segments([(o, s, l) for o, s, l in zip(offs, sizes, l2s)], 'cuda:0')
+    l2vec = np.concatenate([np.full(s, l, np.float32) for s, l in zip(sizes, l2s)])
+    for kind in ('adam', 'sgd'):
+        p_ref = [p0.astype(np.float64).copy()]
+        opt = OO.Adam(lr=1e-2, clipnorm=clip) if kind == 'adam' else OO.SGD(lr=1e-2, momentum=0.9, clipnorm=clip)
+        p = to_dev(p0.copy())
+        m = torch.zeros_like(p); v = torch.zeros_like(p)
+        norm = torch.zeros(2, dtype=torch.float64, device='cuda:0')
+        for step in range(1, 4):
+            g = rs.randn(n).astype(np.float32)
+            g_tot = g.astype(np.float64) + 2 * l2vec * p_ref[0]
+            want_norm = np.sqrt(np.sum(g_tot ** 2))
+            want_pen = np.sum(l2vec * p_ref[0] ** 2)
+            opt.step(p_ref, [g_tot])
+            gd = to_dev(g)
+            ops.grad_norm(p, gd, segs, nseg, norm)
+            if kind == 'adam':
+                ops.adam_step(p, gd, m, v, segs, nseg, norm, clip, 1e-2, step)
+            else:
+                ops.sgd_step(p, gd, m, segs, nseg, norm, clip, 1e-2, 0.9)
+            torch.cuda.synchronize()
+            nh = norm.cpu().numpy()
+            assert abs(nh[0] - want_norm) < 1e-5 * want_norm
+            assert abs(nh[1] - want_pen) < 1e-5 * max(1.0, want_pen)
+            assert np.abs(p.cpu().numpy() - p_ref[0]).max() < 2e-5
