@@ -16,7 +16,13 @@
 //     gradient buffer, reused in place) and the per-step emission gathers are
 //     software-pipelined several steps ahead of the dependent chain;
 //   * the gradient kernel is fully parallel over (t, n): one wave per frame,
-//     class bins in LDS.
+//     class bins in LDS;
+//   * float32 log-space values of magnitude T*ln(C) ~ 3300 would only resolve
+//     posteriors to ~1e-3 (TF's float kernel has that property); here every 4
+//     steps the row is re-centred on its maximum (one wave-max; the removed amount
+//     is accumulated in float64 for the loss), so alpha~/beta~ stay O(10), and the
+//     gradient kernel normalises each frame's posteriors by their own sum (= Z
+//     exactly), which cancels the drift accumulated along the recursion.
 #include "common.h"
 
 namespace {
@@ -65,7 +71,7 @@ ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ la
                       const int* __restrict__ label_len, const int* __restrict__ seq_len,
                       int T, int N, int n_pad, int C, int l_max,
                       float* __restrict__ alpha, float* __restrict__ beta,
-                      float* __restrict__ loss, int do_beta) {
+                      double* __restrict__ logz, float* __restrict__ loss, int do_beta) {
   constexpr int UNR = 4;
   const int lane = threadIdx.x;
   const int n = do_beta ? (blockIdx.x >> 1) : blockIdx.x;
@@ -94,6 +100,19 @@ ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ la
 #pragma unroll
   for (int p = 0; p < PPL; ++p) { sb[p] = kNegInf; sl[p] = kNegInf; }
 
+  double off = 0.0;        // amount removed from the log-space row so far
+  auto recentre = [&]() {
+    float m = kNegInf;
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) m = fmaxf(m, fmaxf(sb[p], sl[p]));
+    m = asr_wave_max(m);
+    if (m > kNegInf) {
+#pragma unroll
+      for (int p = 0; p < PPL; ++p) { sb[p] -= m; sl[p] -= m; }
+      off += (double)m;
+    }
+  };
+
   const size_t row_stride = (size_t)n_pad * C;
   const float* lp_n = logp + (size_t)n * C;
   const int ngroups = (Tn + UNR - 1) / UNR;
@@ -116,6 +135,7 @@ ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ la
     for (int g = 0; g < ngroups; ++g) {
       float nb[UNR], nl[UNR][PPL];
       load_group(g + 1 < ngroups ? g + 1 : g, nb, nl);
+      recentre();
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int t = g * UNR + u;
@@ -155,7 +175,9 @@ ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ la
     if (lane == 0) {
       const float e1 = fin[2 * L];                          // final blank
       const float e2 = L > 0 ? fin[2 * (L - 1) + 1] : kNegInf;  // last label
-      loss[n] = -asr_lse2(e1, e2);
+      const double lz = (double)asr_lse2(e1, e2) + off;
+      logz[n] = lz;
+      loss[n] = (float)(-lz);
     }
   } else {
     // ----- beta (excludes the emission at t).  Virtual frame Tn has emission 0
@@ -185,6 +207,7 @@ ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ la
     for (int g = 0; g < ngroups; ++g) {
       float nb[UNR], nl[UNR][PPL];
       load_group(g + 1 < ngroups ? g + 1 : g, nb, nl);
+      recentre();
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int t = Tn - 1 - (g * UNR + u);
@@ -223,7 +246,7 @@ ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ la
 template <int PPL>
 __global__ void __launch_bounds__(256)
 ctc_grad_kernel(const float* __restrict__ alpha, const float* __restrict__ beta,
-                const float* __restrict__ loss, const int* __restrict__ labels,
+                const double* __restrict__ logz, const int* __restrict__ labels,
                 const int* __restrict__ label_len, const int* __restrict__ seq_len,
                 int T, int N, int n_pad, int C, int l_max, float scale,
                 float* __restrict__ grad) {
@@ -239,18 +262,24 @@ ctc_grad_kernel(const float* __restrict__ alpha, const float* __restrict__ beta,
   const int SP = 2 * 64 * PPL;
   bool active = in_range && n < N;
   int L = 0;
-  float logZ = kNegInf;
   if (active) {
     int Tn = seq_len[n];
     Tn = Tn < 1 ? 1 : (Tn > T ? T : Tn);
     active = t < Tn;
     L = label_len[n];
-    logZ = -loss[n];
-    if (!(logZ > kNegInf)) active = false;   // infeasible target: zero gradient
+    const double lz = logz[n];
+    if (!(lz > -1.0e300)) active = false;    // infeasible target: zero gradient
   }
   for (int c = lane; c < C; c += 64) bins[c] = 0.f;
   __syncthreads();
   float bsum = 0.f;
+  // log-posteriors alpha~ + beta~ of this lane's states; normalised by THEIR sum
+  // over all states of the frame (= Z exactly), which cancels the rounding drift
+  // accumulated along the 999-step recursions and needs no offsets.
+  float vb[PPL], vl[PPL];
+  float vmax = kNegInf;
+#pragma unroll
+  for (int p = 0; p < PPL; ++p) { vb[p] = kNegInf; vl[p] = kNegInf; }
   if (active) {
     const float2* a2 = reinterpret_cast<const float2*>(alpha + ((size_t)t * N + n) * SP) + lane * PPL;
     const float2* b2 = reinterpret_cast<const float2*>(beta + ((size_t)t * N + n) * SP) + lane * PPL;
@@ -260,15 +289,35 @@ ctc_grad_kernel(const float* __restrict__ alpha, const float* __restrict__ beta,
       if (q <= L) {
         const float2 a = a2[p];
         const float2 b = b2[p];
-        const float vb = a.x + b.x - logZ;
-        if (vb > kNegInf) bsum += __expf(vb);
-        if (q < L) {
-          const float vl = a.y + b.y - logZ;
-          if (vl > kNegInf) {
-            int lab = labels[(size_t)n * l_max + q];
-            lab = (lab < 0 || lab >= C) ? blank : lab;
-            atomicAdd(&bins[lab], __expf(vl));
-          }
+        vb[p] = a.x + b.x;
+        if (q < L) vl[p] = a.y + b.y;
+        vmax = fmaxf(vmax, fmaxf(vb[p], vl[p]));
+      }
+    }
+  }
+  vmax = asr_wave_max(vmax);
+  float zsum = 0.f;
+  if (active && vmax > kNegInf) {
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      vb[p] = vb[p] > kNegInf ? __expf(vb[p] - vmax) : 0.f;
+      vl[p] = vl[p] > kNegInf ? __expf(vl[p] - vmax) : 0.f;
+      zsum += vb[p] + vl[p];
+    }
+  }
+  zsum = asr_wave_sum(zsum);
+  if (!(zsum > 0.f)) active = false;
+  if (active) {
+    const float inv = 1.f / zsum;
+#pragma unroll
+    for (int p = 0; p < PPL; ++p) {
+      const int q = lane * PPL + p;
+      if (q <= L) {
+        bsum += vb[p] * inv;
+        if (q < L && vl[p] > 0.f) {
+          int lab = labels[(size_t)n * l_max + q];
+          lab = (lab < 0 || lab >= C) ? blank : lab;
+          atomicAdd(&bins[lab], vl[p] * inv);
         }
       }
     }
@@ -349,8 +398,9 @@ extern "C" size_t asr_ctc_workspace_bytes(int T, int N, int n_pad, int C, int l_
   if (ppl == 0 || T <= 0 || N <= 0) return 0;
   const size_t sp = (size_t)2 * 64 * ppl;
   const int n_pad16 = n_pad > N ? n_pad : N;
-  // alpha + beta + (log-softmax scratch for the loss-only path)
+  // alpha + beta + logZ (float64) + (log-softmax scratch, loss-only path)
   return asr_align_up((size_t)T * N * sp * sizeof(float), 256) * 2 +
+         asr_align_up((size_t)N * sizeof(double), 256) +
          asr_align_up((size_t)T * n_pad16 * C * sizeof(float), 256);
 }
 
@@ -369,15 +419,17 @@ extern "C" int asr_ctc_loss_grad(const float* logits, const int* labels,
   const size_t sp = (size_t)2 * 64 * ppl;
   const size_t ab_bytes = asr_align_up((size_t)T * N * sp * sizeof(float), 256);
   const size_t lp_bytes = asr_align_up((size_t)T * n_pad * C * sizeof(float), 256);
-  const size_t need = ab_bytes * 2 + (grad ? 0 : lp_bytes);
+  const size_t lz_bytes = asr_align_up((size_t)N * sizeof(double), 256);
+  const size_t need = ab_bytes * 2 + lz_bytes + (grad ? 0 : lp_bytes);
   if (!workspace || ws_bytes < need) {
     asr_set_error("ctc: workspace %zu < %zu bytes", ws_bytes, need);
     return ASR_ERR_WORKSPACE;
   }
-  float* alpha = reinterpret_cast<float*>(workspace);
-  float* beta = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ab_bytes);
-  float* logp = grad ? grad
-                     : reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 2 * ab_bytes);
+  char* wsb = reinterpret_cast<char*>(workspace);
+  float* alpha = reinterpret_cast<float*>(wsb);
+  float* beta = reinterpret_cast<float*>(wsb + ab_bytes);
+  double* logz = reinterpret_cast<double*>(wsb + 2 * ab_bytes);
+  float* logp = grad ? grad : reinterpret_cast<float*>(wsb + 2 * ab_bytes + lz_bytes);
   const int rows = T * n_pad;
   hipLaunchKernelGGL(ctc_logsoftmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream,
                      logits, logp, rows, C);
@@ -387,7 +439,7 @@ extern "C" int asr_ctc_loss_grad(const float* logits, const int* labels,
 #define LAUNCH_AB(P)                                                                \
   hipLaunchKernelGGL(ctc_alpha_beta_kernel<P>, grid_ab, dim3(64), 0, stream, logp,  \
                      labels, label_len, seq_len, T, N, n_pad, C, l_max, alpha, beta, \
-                     loss, do_beta)
+                     logz, loss, do_beta)
   switch (ppl) {
     case 1: LAUNCH_AB(1); break;
     case 2: LAUNCH_AB(2); break;
@@ -402,8 +454,8 @@ extern "C" int asr_ctc_loss_grad(const float* logits, const int* labels,
     const size_t shm = (size_t)4 * C * sizeof(float);
 #define LAUNCH_G(P)                                                                  \
   hipLaunchKernelGGL(ctc_grad_kernel<P>, grid_g, dim3(256), shm, stream, alpha, beta, \
-                     loss, labels, label_len, seq_len, T, N, n_pad, C, l_max,         \
-                     grad_scale, grad)
+                     logz, labels, label_len, seq_len, T, N, n_pad, C,                \
+                     l_max, grad_scale, grad)
     switch (ppl) {
       case 1: LAUNCH_G(1); break;
       case 2: LAUNCH_G(2); break;

@@ -1,10 +1,10 @@
 """-m gpu: CTC loss/grad and greedy decode through the C ABI vs the float64 oracle.
 
-Tolerances (stated per BASELINE.json north_star "CTC loss within 1e-4 fp32"):
-loss rtol 1e-4; gradient atol scales with the float32 resolution of the log-space
-alpha/beta magnitudes (~T*ln C): 1e-5 for short sequences, 3e-3 at T=999 (the
-float32 TF kernel the reference calls has the same property, see
-tests/test_oracle_ctc.py::test_float32_close_to_float64); decode indices exact."""
+Tolerances (BASELINE.json north_star: "CTC loss ... within 1e-4 fp32"): loss rtol
+1e-4, gradient atol 1e-4 (entries are in [-1, 1]) at every size including T=999 --
+the kernel re-centres its log-space rows (float64 offsets), so it does not inherit
+the ~1e-3 posterior noise of a plain float32 log-space recursion
+(tests/test_oracle_ctc.py::test_float32_close_to_float64); decode indices exact."""
 import numpy as np
 import pytest
 import torch
@@ -57,7 +57,7 @@ def test_small_ragged(seed):
     l64, g64 = OC.ctc_loss_grad(logits.astype(np.float32), labels, seq_len)
     loss, grad, _ = _run(logits, labels, seq_len, scale=0.5)
     np.testing.assert_allclose(loss, l64, rtol=1e-4)
-    assert report('ctc small grad', grad[:, :N], 0.5 * g64) < 2e-5
+    assert report('ctc small grad', grad[:, :N], 0.5 * g64) < 1e-4
     for n in range(N):
         assert np.all(grad[seq_len[n]:, n] == 0)
     loss_only, _, _ = _run(logits, labels, seq_len, want_grad=False)
@@ -72,7 +72,7 @@ def test_long_labels_multi_pair_per_lane():
     l64, g64 = OC.ctc_loss_grad(logits.astype(np.float32), labels, [T] * N)
     loss, grad, _ = _run(logits, labels, [T] * N)
     np.testing.assert_allclose(loss, l64, rtol=1e-4)
-    assert report('ctc long-label grad', grad[:, :N], g64) < 2e-3
+    assert report('ctc long-label grad', grad[:, :N], g64) < 1e-4
 
 
 def test_infeasible_gives_inf_loss_zero_grad():
@@ -92,7 +92,7 @@ def test_full_size_cfg3_slab():
     l64, g64 = OC.ctc_loss_grad(logits, labels, seq_len)
     loss, grad, _ = _run(logits, labels, seq_len)
     np.testing.assert_allclose(loss, l64, rtol=1e-4)
-    assert report('ctc cfg3 grad', grad, g64) < 3e-3
+    assert report('ctc cfg3 grad', grad, g64) < 1e-4
     # size-independent properties: rows sum to 0 inside, exactly 0 outside
     assert np.abs(grad[:700].sum(-1)).max() < 1e-3
     assert np.all(grad[700:, 5] == 0)
