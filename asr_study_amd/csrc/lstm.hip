@@ -9,38 +9,37 @@
 // i.e. a (16 x H)x(H x 4H) product per batch tile that cannot start before the
 // previous step has finished: a latency problem, not a throughput one.
 //
-// Design (CDNA4), second iteration (the first one let every wave gather its own
-// K slice as 8-byte {value,tag} granules: 8 MB of fabric reads per step at cfg2,
-// 11 us/step; measured, see profiles/):
+// Design (CDNA4), third iteration (measured history in DESIGN.md: v1 per-wave
+// 8-byte granules 11.4 us/step; v2 1024-thread WGs 5.2/2.8 us/step fwd/bwd):
 //  * A layer is a set of independent CHAINS (direction, 16-row batch tile).  A
-//    chain is split over 1024-thread workgroups (one per CU) by hidden units; each
-//    wave keeps its slice of U stationary in VGPRs as the MFMA A-operand for the
-//    whole sequence (v_mfma_f32_16x16x4_f32: exact fp32; C/D layout row =
-//    4*(lane>>4)+reg, col = lane&15, so with gate columns ordered unit*4+gate a
-//    lane ends up with the four gates of ONE (unit, sample): gate math is
-//    lane-local).
-//  * Forward: workgroups exchange h_t (H x 16 words per chain and step).  The
-//    whole workgroup gathers the chain's h ONCE into LDS (one 16-byte
-//    agent-scope load per thread), every wave reads its MFMA B-operand from LDS,
-//    K is split over 4 waves and reduced through LDS.
+//    chain is split over 256-thread workgroups by hidden units (16 per WG); the
+//    four waves of a WG sit one per SIMD (one MFMA pipe each) and keep their slice
+//    of U stationary in VGPRs as the MFMA A-operand for the whole sequence
+//    (v_mfma_f32_16x16x4_f32: exact fp32; C/D layout row = 4*(lane>>4)+reg, col =
+//    lane&15, so with gate columns ordered unit*4+gate a lane ends up with the four
+//    gates of ONE (unit, sample): gate math is lane-local, no cross-wave reduce).
+//  * Forward: workgroups exchange h_t (H x 16 words per chain and step).  The WG
+//    gathers the chain's h ONCE into a double-buffered LDS tile (16-byte loads),
+//    every wave reads its MFMA B-operand from LDS; one barrier per step.
 //  * Backward: a workgroup owns 16 units = 64 gate columns j.  It multiplies its
-//    own dz_J (local) with U[:, J] for ALL H outputs and publishes the partial
-//    dh tiles; each consumer sums the partials addressed to its units.  Exchange
-//    volume is H x 16 words per producer -- the same as forward, instead of the
-//    4H-wide dz vector.
+//    own dz_J (local) with U[:, J] for ALL H outputs and publishes the partial dh
+//    tiles; each consumer sums the partials addressed to its units.  Exchange
+//    volume is H x 16 words per producer -- the same as forward, not the 4H-wide dz.
 //  * Hand-off protocol: every exchanged fp32 word carries the step tag in its
-//    mantissa LSB (value perturbed by <= 1 ulp = 6e-8 relative); words are written
-//    with agent-scope (sc1, write-through) stores and polled with agent-scope
-//    16-byte loads; a word is its own flag, no fences, no dependence on
-//    workgroup placement (MI355X guide, Guideline 16 / R2 "the data IS the flag").
-//    Two slots (step parity) suffice: a producer is at most one step ahead of its
-//    slowest consumer, so a slot holds either step s or s-2, which differ in bit
-//    (s>>1)&1.  The buffer is memset to 0xFF (tag 1) before each launch.
+//    mantissa LSB (value perturbed by <= 1 ulp; the consumer clears the bit); a
+//    16-byte group is its own flag -- no fences, no flags, placement independent
+//    (MI355X guide, Guideline 16 / R2 "the data IS the flag").  Two slots (step
+//    parity) suffice: a producer is at most one step ahead of its slowest
+//    consumer, so a slot holds step s or s-2, which differ in bit (s>>1)&1.  The
+//    buffer is memset to 0xFF (tag 1) before each launch.  Transport: agent-scope
+//    (sc1, write-through) stores + sc1 loads.  If -- and only if -- every
+//    workgroup of a chain reports the same XCC id at kernel start, the chain
+//    switches to plain stores + L1-bypassing (nt) loads served by that XCD's L2;
+//    the choice changes speed only, never results.
 //  * Every spin is bounded by the wall clock; a give-up is recorded in the
 //    workspace status word and the kernel finishes without polling.
-//  * mode 1 launches one step per kernel (exchange through the same buffer, made
-//    visible by the kernel boundary, no polling): the always-safe fallback with
-//    bit-identical arithmetic.
+//  * mode 1 launches one step per kernel (same buffer, visibility from the kernel
+//    boundary, no polling): the always-safe fallback with identical arithmetic.
 #include "common.h"
 
 namespace {
@@ -48,18 +47,20 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
-constexpr int kWaves = 16;                 // 1024-thread workgroups
-constexpr int kThreads = kWaves * 64;
-constexpr int kMaxR = 32;                  // MFMA steps per wave and tile
+constexpr int kThreads = 256;              // 4 waves, one per SIMD
 constexpr int kSc1 = 16;                   // buffer-op cache policy: SC1 (agent scope)
+constexpr int kNt = 2;                     // buffer-op cache policy: NT (bypass L1)
 
 struct LstmParams {
   int T, n_pad, H, NB;
-  int KS, UGW, R;          // fwd: K split, unit groups per WG, MFMAs per wave
+  int R;                   // fwd: MFMA steps per wave (= ceil4(H/4))
   int P;                   // workgroups per chain
+  int nch;                 // chains in this launch
   int s_begin, s_count;
   int chain_begin;
   int poll;                // 1: persistent (poll tags); 0: one step per launch
+  int allow_fast;          // may use the same-XCD transport
+  int dbg;                 // ablation switches (ASR_LSTM_DBG), 0 in production
   const float* U;
   const float* mask_u;
   const float* zx;
@@ -71,7 +72,8 @@ struct LstmParams {
   float* dc_state;
   unsigned* xbuf;          // exchange buffer (words)
   long long xchain_words;  // words per chain (2 slots)
-  int* status;
+  int* xcc;                // [chains][P] XCC id + 1 of every workgroup
+  int* status;             // [0] timeout flag, [1] chains on the fast transport
 };
 
 constexpr long long kSpinTicks = 60LL * 1000 * 1000;   // 0.6 s of the 100 MHz wall clock
@@ -88,129 +90,209 @@ __device__ __forceinline__ float fast_tanh(float x) {
 __device__ __forceinline__ unsigned tag_word(float v, unsigned tag) {
   return (__float_as_uint(v) & ~1u) | tag;
 }
+__device__ __forceinline__ bool tags_ok(const u32x4& v, unsigned tag) {
+  return ((v[0] & 1u) == tag) & ((v[1] & 1u) == tag) & ((v[2] & 1u) == tag) &
+         ((v[3] & 1u) == tag);
+}
+template <bool FAST>
+__device__ __forceinline__ u32x4 xload(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, FAST ? kNt : kSc1);
+}
+template <bool FAST>
+__device__ __forceinline__ void xstore(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, byte_off, 0, FAST ? 0 : kSc1);
+}
 
-// Polls one 16-byte group of exchanged words until all four carry `tag`.
-__device__ __forceinline__ u32x4 poll_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off,
-                                           unsigned tag, int poll, bool& dead, int* status) {
-  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, kSc1);
-  if (!poll || dead) return v;
+// Loads NL 16-byte groups (byte offsets off[i]) and re-polls the stale ones until
+// every word carries `tag`.
+template <bool FAST, int NL>
+__device__ __forceinline__ void gather_groups(__amdgpu_buffer_rsrc_t rsrc,
+                                              const unsigned (&off)[NL], const bool (&use)[NL],
+                                              unsigned tag, int poll, bool& dead, int* status,
+                                              u32x4 (&v)[NL], int nosleep = 0) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+    if (use[i]) v[i] = xload<FAST>(rsrc, off[i]);
+  if (!poll || dead) return;
   long long t0 = 0;
   bool timing = false;
-  while (((v[0] & 1u) != tag) | ((v[1] & 1u) != tag) | ((v[2] & 1u) != tag) |
-         ((v[3] & 1u) != tag)) {
+  for (;;) {
+    bool all_ok = true;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (use[i] && !tags_ok(v[i], tag)) all_ok = false;
+    if (all_ok) return;
     if (!timing) { t0 = wall_clock64(); timing = true; }
     else if (wall_clock64() - t0 > kSpinTicks) {
       dead = true;
       atomicExch(status, 1);
-      break;
+      return;
     }
-    __builtin_amdgcn_s_sleep(1);
-    v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, kSc1);
+    if (!nosleep) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (use[i] && !tags_ok(v[i], tag)) v[i] = xload<FAST>(rsrc, off[i]);
   }
-  return v;
+}
+
+// Decides the transport of this workgroup's chain: true iff all P workgroups of the
+// chain run on the same XCD (they all read the same table, so they all agree).
+__device__ bool chain_on_one_xcd(const LstmParams& p, int chain, int wg, int* lds_i) {
+  if (!p.poll || !p.allow_fast) return false;
+  int* tab = p.xcc + (size_t)chain * p.P;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    // HW_REG_XCC_ID = 20, bits [3:0]
+    const int id = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf);
+    __hip_atomic_store(tab + wg, id + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  bool ok = true;
+  for (int i = tid; i < p.P; i += kThreads) {
+    int v = 0;
+    const long long t0 = wall_clock64();
+    for (;;) {
+      v = __hip_atomic_load(tab + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v != 0) break;
+      if (wall_clock64() - t0 > kSpinTicks) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    lds_i[i] = ok ? v : -1;
+  }
+  __syncthreads();
+  bool same = lds_i[0] > 0;
+  for (int i = 1; i < p.P; ++i) same = same && (lds_i[i] == lds_i[0]);
+  __syncthreads();
+  if (same && tid == 0 && wg == 0) atomicAdd(p.status + 1, 1);
+  return same;
+}
+
+// blockIdx -> (chain slot, workgroup).  Workgroups of one chain use block ids that
+// are congruent mod 8, which the dispatcher is observed to place on one XCD.
+__device__ __forceinline__ bool map_block(const LstmParams& p, int& chain_local, int& wg) {
+  const int xslot = blockIdx.x & 7;
+  const int i = blockIdx.x >> 3;
+  wg = i % p.P;
+  chain_local = (i / p.P) * 8 + xslot;
+  return chain_local < p.nch;
 }
 
 // ---------------------------------------------------------------------------
-// forward.  WG = UGW unit groups (4 units each) x KS K-splits.
-__global__ void __launch_bounds__(kThreads)
-lstm_fwd_kernel(LstmParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// forward.  WG = 4 waves = 4 unit groups (4 units each); each wave spans all of K.
+template <int MAXR, bool FAST>
+__device__ __forceinline__ void fwd_body(const LstmParams& p, int chain, int wg, float* lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, nl = lane & 15;
   const int H = p.H, H4 = 4 * H, H2 = 2 * H;
   const int UG = H >> 2;
-  const int KS = p.KS, R = p.R;
-  const int wg = blockIdx.x % p.P;
-  const int chain = p.chain_begin + blockIdx.x / p.P;
+  const int R = p.R;
   const int dir = chain / p.NB, bt = chain % p.NB;
-  const int ugl = w / KS, kq = w % KS;
-  const int ug = wg * p.UGW + ugl;
+  const int ug = wg * 4 + w;
   const bool ug_ok = ug < UG;
   const int n = bt * 16 + nl;
   const int u = 4 * ug + g;
-  const int kbase = (kq * 4 + g) * R;            // this lane's K slice [kbase, kbase+R)
-  const int HS = H + 4;                          // LDS row stride of the h tile
-  float* hbuf = lds;                             // [16][HS]
-  float4* red = reinterpret_cast<float4*>(lds + 16 * HS);   // [UGW][KS-1][64]
+  const int kbase = g * R;                        // this lane's K slice [kbase, kbase+R)
+  const int HS = 4 * R + 4;                       // LDS row stride of the h tile (>= H+4)
+  float* hbuf0 = lds;                             // [2][16][HS]
+  const int hb_words = 16 * HS;
 
-  float uf[kMaxR];
+  float uf[MAXR];
 #pragma unroll
-  for (int kk = 0; kk < kMaxR; ++kk) {
+  for (int kk = 0; kk < MAXR; ++kk) {
     const int k = kbase + kk;
     uf[kk] = (ug_ok && kk < R && k < H) ? p.U[((size_t)(dir * H + k)) * H4 + 16 * ug + nl] : 0.f;
   }
-  const bool owner = ug_ok && kq == 0;           // this wave finishes the cell update
   float mask = 1.f;
-  if (owner && p.mask_u) mask = p.mask_u[((size_t)dir * p.n_pad + n) * H + u];
+  if (ug_ok && p.mask_u) mask = p.mask_u[((size_t)dir * p.n_pad + n) * H + u];
   float c = 0.f;
   bool dead = false;
-  unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;    // [2][16][H]
+  unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;    // [2][UG][16][4]
   const int slot_words = 16 * H;
   const int s_end = p.s_begin + p.s_count;
 
-  if (owner && p.s_begin > 0) {
+  if (ug_ok && p.s_begin > 0) {
     const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
     c = p.cell[(((size_t)tpp * p.n_pad + n) * 2 + dir) * H + u];
   }
-  // input projection rows are streamed from HBM two steps ahead of their use
+  // zero the K padding of the LDS tiles once (columns >= H are never written)
+  for (int e = tid; e < 2 * hb_words; e += kThreads) hbuf0[e] = 0.f;
+  __syncthreads();
   auto load_zx = [&](int ss) -> float4 {
-    if (!owner || ss >= s_end) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!ug_ok || ss >= s_end || (p.dbg & 1)) return make_float4(0.f, 0.f, 0.f, 0.f);
     const int tt = dir == 0 ? ss : p.T - 1 - ss;
     return *reinterpret_cast<const float4*>(
         p.zx + (((size_t)tt * p.n_pad + n) * 2 + dir) * H4 + 4 * u);
   };
-  float4 zx_n1 = load_zx(p.s_begin);
-  float4 zx_n2 = load_zx(p.s_begin + 1);
+  float4 zx_next = load_zx(p.s_begin);
+  constexpr int NL = (MAXR * 4 * 16 / 4 + kThreads - 1) / kThreads;   // 16-B groups / thread
+  const bool prof = (p.dbg & 32) && wg == 0 && chain == p.chain_begin && lane == 0;
+  long long pt[5] = {0, 0, 0, 0, 0}, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
   for (int s = p.s_begin; s < s_end; ++s) {
+    if (prof) tk0 = wall_clock64();
     const int t = dir == 0 ? s : p.T - 1 - s;
-    const float4 zx4 = zx_n1;
-    zx_n1 = zx_n2;
+    const float4 zx4 = zx_next;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      // ---- gather h_{s-1} (already masked by the producer) into LDS, once per WG
-      const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
+      // ---- gather h_{s-1} (already masked by its producer) into LDS, once per WG
+      float* hbuf = hbuf0 + (s & 1) * hb_words;
+      const unsigned tag = (unsigned)((s - 1 - p.s_begin) >> 1) & 1u;
       __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)((s - 1) & 1) * slot_words, 0, slot_words * 4, 0x00020000);
-      for (int e = 4 * tid; e < slot_words; e += 4 * kThreads) {
-        const u32x4 v = poll_b128(rsrc, (unsigned)e * 4u, tag, p.poll, dead, p.status);
-        const int row = e / H, col = e - row * H;
-        *reinterpret_cast<float4*>(hbuf + row * HS + col) =
-            make_float4(__uint_as_float(v[0] & ~1u), __uint_as_float(v[1] & ~1u),
-                        __uint_as_float(v[2] & ~1u), __uint_as_float(v[3] & ~1u));
+      unsigned off[NL];
+      bool use[NL];
+      u32x4 v[NL];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int grp = tid + i * kThreads;       // group = (unit group, sample)
+        use[i] = grp < UG * 16;
+        off[i] = (unsigned)grp * 16u;
+      }
+      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64);
+      if (prof) tk1 = wall_clock64();
+      // next step's input projection: issued behind the poll (so the poll's in-order
+      // wait never includes its HBM latency), consumed one whole compute phase later
+      zx_next = load_zx(s + 1);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if (use[i]) {
+          const int grp = tid + i * kThreads;
+          const int gu = grp >> 4, gn = grp & 15;
+          *reinterpret_cast<float4*>(hbuf + gn * HS + 4 * gu) =
+              make_float4(__uint_as_float(v[i][0] & ~1u), __uint_as_float(v[i][1] & ~1u),
+                          __uint_as_float(v[i][2] & ~1u), __uint_as_float(v[i][3] & ~1u));
+        }
       }
       __syncthreads();
-      zx_n2 = load_zx(s + 2);
-      if (ug_ok) {
+      if (prof) tk2 = wall_clock64();
+      if (ug_ok && !(p.dbg & 4)) {
         const float* hrow = hbuf + nl * HS + kbase;
+        // all B operands first (back-to-back ds_read_b128, counted lgkmcnt waits),
+        // then one uninterrupted MFMA chain
+        float4 hv[MAXR / 4];
 #pragma unroll
-        for (int kk = 0; kk < kMaxR; kk += 4) {
-          if (kk < R) {
-            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kbase + kk < H) hv = *reinterpret_cast<const float4*>(hrow + kk);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[kk], hv.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[kk + 1], hv.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[kk + 2], hv.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[kk + 3], hv.w, acc1, 0, 0, 0);
+        for (int q = 0; q < MAXR / 4; ++q)
+          hv[q] = (4 * q < R) ? *reinterpret_cast<const float4*>(hrow + 4 * q)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < MAXR / 4; ++q) {
+          if (4 * q < R) {
+            // four independent accumulators: the 40-cycle dependent latency of the
+            // 32-cycle-issue MFMA never stalls the pipe
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q], hv[q].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q + 1], hv[q].y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q + 2], hv[q].z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q + 3], hv[q].w, acc3, 0, 0, 0);
           }
         }
       }
     } else {
-      zx_n2 = load_zx(s + 2);
+      zx_next = load_zx(s + 1);
     }
-    f32x4 a = acc0 + acc1;
-    if (KS > 1) {
-      if (kq > 0) red[(ugl * (KS - 1) + kq - 1) * 64 + lane] = make_float4(a[0], a[1], a[2], a[3]);
-      __syncthreads();
-      if (kq == 0) {
-        for (int q = 0; q < KS - 1; ++q) {
-          const float4 r = red[(ugl * (KS - 1) + q) * 64 + lane];
-          a[0] += r.x; a[1] += r.y; a[2] += r.z; a[3] += r.w;
-        }
-      }
-    }
-    if (owner) {
+    const f32x4 a = (acc0 + acc1) + (acc2 + acc3);
+    if (prof) { asm volatile("" :: "v"(a[0])); tk3 = wall_clock64(); }
+    if (ug_ok) {
       const float gi = hard_sigmoid(a[0] + zx4.x);
       const float gf = hard_sigmoid(a[1] + zx4.y);
       const float gg = fast_tanh(a[2] + zx4.z);
@@ -219,8 +301,8 @@ lstm_fwd_kernel(LstmParams p) {
       const float h = go * fast_tanh(c);
       if (s + 1 < p.T) {
         // lanes nl, nl+16, nl+32, nl+48 hold units 4ug..4ug+3 of sample nl: collect
-        // them in lane nl so the hand-off is ONE 16-byte write-through store per row
-        const unsigned wtag = (unsigned)(s >> 1) & 1u;
+        // them in lane nl so the wave publishes ONE contiguous 256-byte tile
+        const unsigned wtag = (unsigned)((s - p.s_begin) >> 1) & 1u;
         const unsigned w0 = tag_word(h * mask, wtag);
         u32x4 o;
         o[0] = w0;
@@ -230,33 +312,51 @@ lstm_fwd_kernel(LstmParams p) {
         if (lane < 16) {
           __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
               xch + (size_t)(s & 1) * slot_words, 0, slot_words * 4, 0x00020000);
-          __builtin_amdgcn_raw_buffer_store_b128(o, wr, (unsigned)(nl * H + 4 * ug) * 4u, 0, kSc1);
+          xstore<FAST>(o, wr, (unsigned)(ug * 16 + nl) * 16u);
         }
       }
-      const size_t row = (size_t)t * p.n_pad + n;
-      p.y[row * H2 + dir * H + u] = h;
-      p.cell[(row * 2 + dir) * H + u] = c;
-      *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
-          make_float4(gi, gf, gg, go);
+      if (!(p.dbg & 2)) {
+        const size_t row = (size_t)t * p.n_pad + n;
+        p.y[row * H2 + dir * H + u] = h;
+        p.cell[(row * 2 + dir) * H + u] = c;
+        *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
+            make_float4(gi, gf, gg, go);
+      }
+    }
+    if (prof && s > 0) {
+      const long long tk4 = wall_clock64();
+      pt[0] += tk1 - tk0; pt[1] += tk2 - tk1; pt[2] += tk3 - tk2; pt[3] += tk4 - tk3;
     }
   }
+  if (prof) {
+    long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
+    for (int i = 0; i < 4; ++i) out[i] = pt[i];
+  }
+}
+
+template <int MAXR>
+__global__ void __launch_bounds__(kThreads)
+lstm_fwd_kernel(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int chain_local, wg;
+  if (!map_block(p, chain_local, wg)) return;
+  const int chain = p.chain_begin + chain_local;
+  const bool fast = chain_on_one_xcd(p, chain, wg, reinterpret_cast<int*>(lds));
+  if (fast) fwd_body<MAXR, true>(p, chain, wg, lds);
+  else fwd_body<MAXR, false>(p, chain, wg, lds);
 }
 
 // ---------------------------------------------------------------------------
 // backward (BPTT).  WG `cw` of a chain owns units [16 cw, 16 cw + 16) = gate
 // columns j in [64 cw, 64 cw + 64).  TPW = output tiles (16 units) per wave.
-template <int TPW>
-__global__ void __launch_bounds__(kThreads)
-lstm_bwd_kernel(LstmParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+template <int TPW, bool FAST>
+__device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw, float* lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, nl = lane & 15;
   const int H = p.H, H4 = 4 * H, H2 = 2 * H;
   const int P = p.P;                              // = ceil(H / 16)
-  const int cw = blockIdx.x % P;
-  const int chain = p.chain_begin + blockIdx.x / P;
   const int dir = chain / p.NB, bt = chain % p.NB;
   constexpr int DZS = 68;                         // LDS row stride of the dz tile
   float* dzl = lds;                               // [16 n][DZS] own gate gradients
@@ -266,7 +366,7 @@ lstm_bwd_kernel(LstmParams p) {
   float uf[TPW][16];
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const int mt = w + kWaves * i;
+    const int mt = w + 4 * i;
     const int krow = 16 * mt + nl;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
@@ -274,11 +374,10 @@ lstm_bwd_kernel(LstmParams p) {
       uf[i][kk] = (mt < P && krow < H && j < H4) ? p.U[((size_t)(dir * H + krow)) * H4 + j] : 0.f;
     }
   }
-  // cell-backward threads: tid < 256 -> (n = tid/16, ul = tid%16)
-  const bool cellthr = tid < 256;
+  // every thread owns one (sample, unit) of the cell backward: n = tid/16, ul = tid%16
   const int cn = bt * 16 + (tid >> 4);
   const int cu = 16 * cw + (tid & 15);
-  const bool cvalid = cellthr && cu < H;
+  const bool cvalid = cu < H;
   float cmask = 1.f;
   if (cvalid && p.mask_u) cmask = p.mask_u[((size_t)dir * p.n_pad + cn) * H + cu];
   float dc = 0.f;
@@ -287,42 +386,70 @@ lstm_bwd_kernel(LstmParams p) {
   unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;   // [2][P cons][P prod][256]
   const size_t slot_words = (size_t)P * P * 256;
   const int s_end = p.s_begin + p.s_count;
+  constexpr int NL = TPW;                          // P*64 groups / 256 threads <= TPW
+  const bool prof = (p.dbg & 32) && cw == 0 && chain == p.chain_begin && lane == 0;
+  long long pt[5] = {0, 0, 0, 0, 0}, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+
+  // slab loads (dy, c_t, c_prev, gates) run one step ahead of their use and are
+  // issued right AFTER a step's gather, so the poll's in-order wait never covers
+  // their HBM latency
+  float nx_dy = 0.f, nx_c = 0.f, nx_cp = 0.f;
+  float4 nx_g = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_slabs = [&](int ss) {
+    nx_dy = 0.f; nx_c = 0.f; nx_cp = 0.f; nx_g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!cvalid || ss >= s_end) return;
+    const int tt = dir == 0 ? p.T - 1 - ss : ss;
+    const int tcc = dir == 0 ? tt - 1 : tt + 1;
+    const size_t row = (size_t)tt * p.n_pad + cn;
+    nx_dy = p.dy[row * H2 + dir * H + cu];
+    nx_c = p.cell[(row * 2 + dir) * H + cu];
+    if (ss + 1 < p.T) nx_cp = p.cell[(((size_t)tcc * p.n_pad + cn) * 2 + dir) * H + cu];
+    nx_g = *reinterpret_cast<const float4*>(p.gates + (row * 2 + dir) * H4 + 4 * cu);
+  };
+  load_slabs(p.s_begin);
 
   for (int s = p.s_begin; s < s_end; ++s) {
+    if (prof) tk0 = wall_clock64();
     const int t = dir == 0 ? p.T - 1 - s : s;     // reverse of the forward order
-    const int tc = dir == 0 ? t - 1 : t + 1;      // forward-order predecessor
-    const bool has_cprev = (s + 1 < p.T);
-    // ---- independent loads of this step (cell-backward threads)
-    float dyv = 0.f, cv = 0.f, cpv = 0.f;
-    float4 gt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cvalid) {
-      const size_t row = (size_t)t * p.n_pad + cn;
-      dyv = p.dy[row * H2 + dir * H + cu];
-      cv = p.cell[(row * 2 + dir) * H + cu];
-      if (has_cprev) cpv = p.cell[(((size_t)tc * p.n_pad + cn) * 2 + dir) * H + cu];
-      gt = *reinterpret_cast<const float4*>(p.gates + (row * 2 + dir) * H4 + 4 * cu);
-    }
+    // ---- this step's slab values were loaded during the previous step
+    const float dyv = nx_dy, cv = nx_c, cpv = nx_cp;
+    const float4 gt = nx_g;
     float dh_rec = 0.f;
     if (s > 0) {
       // ---- gather the partial dh tiles addressed to this WG: [P prod][16 n][16 u]
-      const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
+      const unsigned tag = (unsigned)((s - 1 - p.s_begin) >> 1) & 1u;
       __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)((s - 1) & 1) * slot_words + (size_t)cw * P * 256, 0, P * 256 * 4,
           0x00020000);
-      for (int e = 4 * tid; e < P * 256; e += 4 * kThreads) {
-        const u32x4 v = poll_b128(rsrc, (unsigned)e * 4u, tag, p.poll, dead, p.status);
-        *reinterpret_cast<float4*>(part + e) =
-            make_float4(__uint_as_float(v[0] & ~1u), __uint_as_float(v[1] & ~1u),
-                        __uint_as_float(v[2] & ~1u), __uint_as_float(v[3] & ~1u));
+      unsigned off[NL];
+      bool use[NL];
+      u32x4 v[NL];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int grp = tid + i * kThreads;
+        use[i] = grp < P * 64;
+        off[i] = (unsigned)grp * 16u;
+      }
+      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64);
+      if (prof) tk1 = wall_clock64();
+      load_slabs(s + 1);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if (use[i]) {
+          *reinterpret_cast<float4*>(part + 4 * (tid + i * kThreads)) =
+              make_float4(__uint_as_float(v[i][0] & ~1u), __uint_as_float(v[i][1] & ~1u),
+                          __uint_as_float(v[i][2] & ~1u), __uint_as_float(v[i][3] & ~1u));
+        }
       }
       __syncthreads();
-      if (cellthr) {
-        // element (n, ul) of every producer tile sits at [n*16 + ul] == tid
-        for (int pr = 0; pr < P; ++pr) dh_rec += part[pr * 256 + tid];
-      }
+      if (prof) tk2 = wall_clock64();
+      // element (n, ul) of every producer tile sits at [n*16 + ul] == tid
+      for (int pr = 0; pr < P; ++pr) dh_rec += part[pr * 256 + tid];
+    } else {
+      load_slabs(s + 1);
     }
     // ---- cell backward for own units -> dz (LDS for the MFMA, global for the GEMMs)
-    if (cellthr) {
+    {
       float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (cvalid) {
         const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
@@ -341,6 +468,7 @@ lstm_bwd_kernel(LstmParams p) {
       *reinterpret_cast<float4*>(dzl + (tid >> 4) * DZS + 4 * (tid & 15)) = z4;
     }
     __syncthreads();
+    if (prof) tk3 = wall_clock64();
     // ---- partial dh_{prev}[k] = sum_{j in J} U[k][j] dz[j] for ALL k; publish per tile
     if (s + 1 < p.T) {
       float bv[16];
@@ -352,51 +480,84 @@ lstm_bwd_kernel(LstmParams p) {
           bv[4 * q] = d4.x; bv[4 * q + 1] = d4.y; bv[4 * q + 2] = d4.z; bv[4 * q + 3] = d4.w;
         }
       }
-      const unsigned wtag = (unsigned)(s >> 1) & 1u;
+      const unsigned wtag = (unsigned)((s - p.s_begin) >> 1) & 1u;
       __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)(s & 1) * slot_words, 0, (unsigned)(slot_words * 4), 0x00020000);
+      // straight-line: tile i's publish is issued as soon as its 16 MFMAs retire and
+      // never waits for an earlier tile's store (distinct registers, no branches; a
+      // tile index past the chain is dropped by the buffer bounds check)
+      u32x4 o[TPW];
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
-        const int mt = w + kWaves * i;
-        if (mt < P) {
-          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const int mt = w + 4 * i;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kk = 0; kk < 16; kk += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][kk], bv[kk], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][kk + 1], bv[kk + 1], acc1, 0, 0, 0);
-          }
-          const f32x4 a = acc0 + acc1;
-          // lane (g, nl) holds units 4g..4g+3 of consumer tile mt for sample nl
-          u32x4 o;
-          o[0] = tag_word(a[0], wtag); o[1] = tag_word(a[1], wtag);
-          o[2] = tag_word(a[2], wtag); o[3] = tag_word(a[3], wtag);
-          const unsigned off = (unsigned)((((size_t)mt * P + cw) * 256 + nl * 16 + 4 * g) * 4);
-          __builtin_amdgcn_raw_buffer_store_b128(o, wr, off, 0, kSc1);
+        for (int kk = 0; kk < 16; kk += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][kk], bv[kk], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][kk + 1], bv[kk + 1], acc1, 0, 0, 0);
         }
+        const f32x4 a = acc0 + acc1;
+        // lane (g, nl) holds units 4g..4g+3 of consumer tile mt for sample nl
+        o[i][0] = tag_word(a[0], wtag); o[i][1] = tag_word(a[1], wtag);
+        o[i][2] = tag_word(a[2], wtag); o[i][3] = tag_word(a[3], wtag);
+        const unsigned off = mt < P
+            ? (unsigned)((((size_t)mt * P + cw) * 256 + nl * 16 + 4 * g) * 4)
+            : 0xFFFFFFF0u;
+        xstore<FAST>(o[i], wr, off);
       }
     }
+    // part[] is overwritten by the next gather, which every thread starts only after
+    // the barrier above; dzl is rewritten only after the next step's first barrier,
+    // which every wave reaches after its MFMA reads of this step.
+    if (prof && s > 0) {
+      const long long tk4 = wall_clock64();
+      pt[0] += tk1 - tk0; pt[1] += tk2 - tk1; pt[2] += tk3 - tk2; pt[3] += tk4 - tk3;
+    }
+  }
+  if (prof) {
+    long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
+    for (int i = 0; i < 4; ++i) out[i] = pt[i];
   }
   if (cvalid && p.dc_state) p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu] = dc;
 }
 
+template <int TPW>
+__global__ void __launch_bounds__(kThreads)
+lstm_bwd_kernel(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int chain_local, cw;
+  if (!map_block(p, chain_local, cw)) return;
+  const int chain = p.chain_begin + chain_local;
+  const bool fast = chain_on_one_xcd(p, chain, cw, reinterpret_cast<int*>(lds));
+  if (fast) bwd_body<TPW, true>(p, chain, cw, lds);
+  else bwd_body<TPW, false>(p, chain, cw, lds);
+}
+
 // ---------------------------------------------------------------------------
 struct Plan {
-  int KS, UGW, R, P, TPW;
+  int R, P, TPW, MAXR;
   size_t shm;
   size_t xchain_words;
   int chains_per_launch;
 };
 
-int even_up4(int x) { return (x + 3) & ~3; }
+int up4(int x) { return (x + 3) & ~3; }
 
 typedef void (*kern_t)(LstmParams);
 
+kern_t pick_fwd(int maxr) {
+  switch (maxr) {
+    case 32: return lstm_fwd_kernel<32>;
+    case 64: return lstm_fwd_kernel<64>;
+    default: return lstm_fwd_kernel<128>;
+  }
+}
 kern_t pick_bwd(int tpw) {
   switch (tpw) {
     case 1: return lstm_bwd_kernel<1>;
     case 2: return lstm_bwd_kernel<2>;
-    case 3: return lstm_bwd_kernel<3>;
-    default: return lstm_bwd_kernel<4>;
+    case 4: return lstm_bwd_kernel<4>;
+    default: return lstm_bwd_kernel<8>;
   }
 }
 
@@ -405,7 +566,7 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-int make_plan(const asr_lstm_args* a, bool bwd, Plan* out) {
+int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   const int H = a->H;
   const int chains = 2 * (a->n_pad / 16);
   int dev = 0;
@@ -415,39 +576,31 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out) {
   const int num_cu = prop.multiProcessorCount;
   Plan pl;
   kern_t k;
+  pl.P = (H + 15) / 16;
   if (!bwd) {
-    // K split so that R (MFMAs per wave) <= 32, preferring R near 16
-    int KS = env_int("ASR_LSTM_FWD_KS", 0);
-    if (KS != 1 && KS != 2 && KS != 4 && KS != 8 && KS != 16) {
-      KS = 4;
-      while (KS < 16 && even_up4((H + 4 * KS - 1) / (4 * KS)) > kMaxR) KS *= 2;
-      while (KS > 1 && even_up4((H + 2 * KS - 1) / (2 * KS)) <= 16) KS /= 2;
-    }
-    pl.KS = KS;
-    pl.UGW = kWaves / KS;
-    pl.R = even_up4((H + 4 * KS - 1) / (4 * KS));
-    if (pl.R > kMaxR) {
-      asr_set_error("lstm fwd: H=%d too large for the register-resident U slice", H);
+    pl.R = up4((H + 3) / 4);
+    if (pl.R > 128) {
+      asr_set_error("lstm fwd: H=%d too large for the register-resident U slice (max 512)", H);
       return ASR_ERR_INVALID;
     }
-    const int UG = H / 4;
-    pl.P = (UG + pl.UGW - 1) / pl.UGW;
+    pl.MAXR = pl.R <= 32 ? 32 : pl.R <= 64 ? 64 : 128;
     pl.TPW = 0;
-    pl.shm = (size_t)16 * (H + 4) * 4 + (size_t)pl.UGW * (KS > 1 ? KS - 1 : 0) * 64 * 16;
+    pl.shm = (size_t)2 * 16 * (4 * pl.R + 4) * 4;
     pl.xchain_words = (size_t)2 * 16 * H;
-    k = lstm_fwd_kernel;
+    k = pick_fwd(pl.MAXR);
   } else {
-    pl.KS = 1; pl.UGW = 0; pl.R = 16;
-    pl.P = (H + 15) / 16;
-    pl.TPW = (pl.P + kWaves - 1) / kWaves;
-    if (pl.TPW > 4) {
-      asr_set_error("lstm bwd: H=%d too large (max 1024)", H);
+    pl.R = 16; pl.MAXR = 0;
+    const int tpw = (pl.P + 3) / 4;
+    if (tpw > 8) {
+      asr_set_error("lstm bwd: H=%d too large (max 512)", H);
       return ASR_ERR_INVALID;
     }
+    pl.TPW = tpw <= 1 ? 1 : tpw <= 2 ? 2 : tpw <= 4 ? 4 : 8;
     pl.shm = (size_t)(16 * 68 + pl.P * 256) * 4;
     pl.xchain_words = (size_t)2 * pl.P * pl.P * 256;
     k = pick_bwd(pl.TPW);
   }
+  if (pl.shm < (size_t)pl.P * 4 + 16) pl.shm = (size_t)pl.P * 4 + 16;
   if (pl.shm > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)pl.shm) != hipSuccess) {
@@ -463,9 +616,10 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out) {
     asr_set_error("lstm: kernel does not fit a CU (LDS %zu B)", pl.shm);
     return ASR_ERR_RESIDENCY;
   }
-  // 1024-thread workgroups: count ONE per CU (the occupancy API may over-report)
+  // Residency: count ONE workgroup per CU (the occupancy API may over-report, and one
+  // wave per SIMD is what the design wants anyway).
   const long cap = (long)num_cu;
-  if (cap < pl.P) {
+  if (cap < (long)pl.P) {
     asr_set_error("lstm: a chain needs %d co-resident workgroups, device has %d CUs", pl.P,
                   num_cu);
     return ASR_ERR_RESIDENCY;
@@ -474,6 +628,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out) {
   if (cpl > chains) cpl = chains;
   pl.chains_per_launch = (int)cpl;
   *out = pl;
+  if (kout) *kout = k;
   return ASR_OK;
 }
 
@@ -484,6 +639,11 @@ size_t xbuf_bytes(const asr_lstm_args* a, bool bwd) {
   const size_t P = (a->H + 15) / 16;
   const size_t words = bwd ? (size_t)2 * P * P * 256 : (size_t)2 * 16 * a->H;
   return asr_align_up(chains * words * 4, 256);
+}
+size_t xcc_bytes(const asr_lstm_args* a) {
+  const size_t chains = (size_t)2 * (a->n_pad / 16);
+  const size_t P = (a->H + 15) / 16;
+  return asr_align_up(chains * P * sizeof(int), 256);
 }
 
 int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
@@ -500,33 +660,39 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
     return ASR_ERR_WORKSPACE;
   }
   Plan pl;
-  const int rc = make_plan(a, bwd, &pl);
+  kern_t k;
+  const int rc = make_plan(a, bwd, &pl, &k);
   if (rc != ASR_OK) return rc;
   char* ws = reinterpret_cast<char*>(workspace);
   const size_t xb = xbuf_bytes(a, bwd);
+  const size_t cb_ = xcc_bytes(a);
   LstmParams p;
   p.T = a->T; p.n_pad = a->n_pad; p.H = a->H; p.NB = a->n_pad / 16;
-  p.KS = pl.KS; p.UGW = pl.UGW; p.R = pl.R; p.P = pl.P;
+  p.R = pl.R; p.P = pl.P;
   p.U = a->U; p.mask_u = a->mask_u; p.zx = a->zx; p.y = a->y; p.cell = a->cell;
   p.gates = a->gates; p.dy = a->dy; p.dz = a->dz;
   p.status = reinterpret_cast<int*>(ws);
-  p.xbuf = reinterpret_cast<unsigned*>(ws + kStatusBytes);
+  p.xcc = reinterpret_cast<int*>(ws + kStatusBytes);
+  p.xbuf = reinterpret_cast<unsigned*>(ws + kStatusBytes + cb_);
   p.xchain_words = (long long)pl.xchain_words;
-  p.dc_state = reinterpret_cast<float*>(ws + kStatusBytes + xb);
-  ASR_CHECK_HIP(hipMemsetAsync(ws, 0, kStatusBytes, stream));
-  ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes, 0xFF, xb, stream));
+  p.dc_state = reinterpret_cast<float*>(ws + kStatusBytes + cb_ + xb);
+  ASR_CHECK_HIP(hipMemsetAsync(ws, 0, kStatusBytes + cb_, stream));
+  ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes + cb_, 0xFF, xb, stream));
   const int chains = 2 * p.NB;
-  kern_t k = bwd ? pick_bwd(pl.TPW) : (kern_t)lstm_fwd_kernel;
   const bool stepwise = a->mode == 1;
   p.poll = stepwise ? 0 : 1;
+  p.allow_fast = env_int("ASR_LSTM_FAST", 1);
+  p.dbg = env_int("ASR_LSTM_DBG", 0);
   const int steps_per_launch = stepwise ? 1 : a->T;
   for (int s0 = 0; s0 < a->T; s0 += steps_per_launch) {
     for (int cb = 0; cb < chains; cb += pl.chains_per_launch) {
       const int nch = (chains - cb) < pl.chains_per_launch ? (chains - cb) : pl.chains_per_launch;
       p.chain_begin = cb;
+      p.nch = nch;
       p.s_begin = s0;
       p.s_count = (a->T - s0) < steps_per_launch ? (a->T - s0) : steps_per_launch;
-      hipLaunchKernelGGL(k, dim3(nch * pl.P), dim3(kThreads), pl.shm, stream, p);
+      const int groups = (nch + 7) / 8;
+      hipLaunchKernelGGL(k, dim3(groups * 8 * pl.P), dim3(kThreads), pl.shm, stream, p);
       ASR_CHECK_LAUNCH();
     }
   }
@@ -537,7 +703,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
 
 extern "C" size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward) {
   if (!a || a->n_pad <= 0 || a->H <= 0) return 0;
-  return kStatusBytes + xbuf_bytes(a, backward != 0) +
+  return kStatusBytes + xcc_bytes(a) + xbuf_bytes(a, backward != 0) +
          asr_align_up((size_t)2 * a->n_pad * a->H * sizeof(float), 256);
 }
 
@@ -555,10 +721,10 @@ extern "C" int asr_lstm_seq_bwd(const asr_lstm_args* a, void* workspace, size_t 
 // workspace abandoned a bounded spin.
 extern "C" int asr_lstm_status(const void* workspace, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  int st = 0;
-  ASR_CHECK_HIP(hipMemcpyAsync(&st, workspace, sizeof(int), hipMemcpyDeviceToHost, stream));
+  int st[2] = {0, 0};
+  ASR_CHECK_HIP(hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, stream));
   ASR_CHECK_HIP(hipStreamSynchronize(stream));
-  if (st != 0) {
+  if (st[0] != 0) {
     asr_set_error("lstm: persistent kernel timed out waiting for a peer workgroup");
     return ASR_ERR_TIMEOUT;
   }
@@ -568,11 +734,31 @@ extern "C" int asr_lstm_status(const void* workspace, asr_stream_t stream_) {
 extern "C" int asr_lstm_plan(const asr_lstm_args* a, int backward, int* ks, int* r,
                              int* blocks, int* chains_per_launch) {
   Plan pl;
-  const int rc = make_plan(a, backward != 0, &pl);
+  const int rc = make_plan(a, backward != 0, &pl, nullptr);
   if (rc != ASR_OK) return rc;
-  if (ks) *ks = pl.KS;
-  if (r) *r = pl.R;
+  if (ks) *ks = 1;
+  if (r) *r = backward ? pl.TPW * 16 : pl.R;
   if (blocks) *blocks = pl.P * pl.chains_per_launch;
   if (chains_per_launch) *chains_per_launch = pl.chains_per_launch;
   return ASR_OK;
+}
+
+// Debug (ASR_LSTM_DBG & 32): per-phase wall-clock ticks (100 MHz) of workgroup 0,
+// 4 phases x 4 waves, accumulated over the steps of the last call.
+extern "C" int asr_lstm_profile(const void* workspace, asr_stream_t stream_, long long* out16) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_HIP(hipMemcpyAsync(out16, reinterpret_cast<const char*>(workspace) + 64,
+                               16 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+  ASR_CHECK_HIP(hipStreamSynchronize(stream));
+  return ASR_OK;
+}
+
+// Synchronises `stream`; returns how many chains of the last call on this workspace
+// used the same-XCD (L2) transport, or a negative asr_status.
+extern "C" int asr_lstm_fast_chains(const void* workspace, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int st[2] = {0, 0};
+  ASR_CHECK_HIP(hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, stream));
+  ASR_CHECK_HIP(hipStreamSynchronize(stream));
+  return st[1];
 }

@@ -127,6 +127,16 @@ def lstm_status(ws):
     L.check(L.load().asr_lstm_status(_ptr(ws), _stream()), 'asr_lstm_status')
 
 
+def lstm_fast_chains(ws):
+    return L.load().asr_lstm_fast_chains(_ptr(ws), _stream())
+
+
+def lstm_profile(ws):
+    out = (C.c_longlong * 16)()
+    L.check(L.load().asr_lstm_profile(_ptr(ws), _stream(), out), 'asr_lstm_profile')
+    return [[out[4 * w + i] for i in range(4)] for w in range(4)]
+
+
 def lstm_plan(T, n_pad, H, backward):
     lib = L.load()
     a = L.LstmArgs()

@@ -61,9 +61,15 @@ def main():
             tf = timeit(lambda: ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mode=mode),
                         reps=reps, warm=1)
             ops.lstm_status(ops.WS.get('lstm_fwd', 0, torch.device(dev)))
+            print('fast chains fwd:', ops.lstm_fast_chains(ops.WS.get('lstm_fwd', 0, torch.device(dev))))
             tb = timeit(lambda: ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mode=mode),
                         reps=reps, warm=1)
             ops.lstm_status(ops.WS.get('lstm_bwd', 0, torch.device(dev)))
+            if int(os.environ.get('ASR_LSTM_DBG', '0')) & 32:
+                for nm in ('lstm_fwd', 'lstm_bwd'):
+                    pr = ops.lstm_profile(ops.WS.get(nm, 0, torch.device(dev)))
+                    print(nm, 'us/step per wave [wait, barrier, A, B]:',
+                          [[round(x / 100.0 / (T - 1), 2) for x in row] for row in pr])
             fl = 2.0 * 2 * T * n_pad * H * 4 * H
             print('lstm mode%d fwd %.3f ms (%.2f us/step, %.2f TF/s)  bwd %.3f ms (%.2f us/step)'
                   % (mode, tf, tf * 1e3 / T, fl / tf / 1e9, tb, tb * 1e3 / T))
