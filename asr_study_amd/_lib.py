@@ -111,6 +111,9 @@ def load():
             'libasr_hip.so not found at %s -- build it with '
             '`python -c "import __graft_entry__ as g; g.build()"` or '
             '`python asr_study_amd/build.py`; the hot path has no CPU fallback.' % LIB_PATH)
+    # torch bundles its own HIP runtime; it must be in the process before this
+    # library so that both resolve to the SAME libamdhip64 (one device context).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is missing

@@ -1,0 +1,562 @@
+"""Execution engine behind ``ctc_model()``: runs the stage list on the HIP kernels.
+
+Replaces what Keras 1.2.2 + TensorFlow 1.3.0 do for the reference once
+``model.compile`` / ``fit_generator`` / ``evaluate_generator`` are called
+(train.py:140-143, 213-217, 223-227; eval.py:76-80): forward, CTC loss, BPTT,
+global-norm clip + Adam/SGD, greedy/beam decode and LER.  Everything numeric goes
+through the C ABI (asr_study_amd.ops); torch provides device buffers, streams and
+the RCCL all-reduce only.
+
+Data layout: activations are time-major slabs (T, n_pad, features) with the batch
+rounded up to a multiple of 16 (padding rows stay zero / get zero gradient).  All
+parameters live in ONE flat float32 buffer (so the optimiser and the all-reduce are
+single launches); LSTM gate axes are stored unit-major/gate-minor (see
+include/asr_hip.h) and hidden sizes are rounded up to a multiple of 4 with zero
+weights (eyben's 78/27-unit layers).  get_weights()/set_weights() speak the
+reference's Keras layout: per Bidirectional layer [W (in,4H), U (H,4H), b (4H)] for
+the forward then the backward copy, gate blocks i,f,c,o; Dense [W, b].
+"""
+import math
+import time
+
+import numpy as np
+import torch
+
+from .. import ops
+from . import optimizers as _opt
+
+
+def _pad4(n):
+    return (int(n) + 3) // 4 * 4
+
+
+def _gm2um(a, H, Hp):
+    """(..., 4H) gate-major -> (..., 4Hp) unit-major/gate-minor, zero padded."""
+    sh = a.shape[:-1]
+    g = a.reshape(sh + (4, H))
+    out = np.zeros(sh + (Hp, 4), a.dtype)
+    out[..., :H, :] = np.swapaxes(g, -1, -2)
+    return out.reshape(sh + (4 * Hp,))
+
+
+def _um2gm(a, H, Hp):
+    sh = a.shape[:-1]
+    u = a.reshape(sh + (Hp, 4))[..., :H, :]
+    return np.ascontiguousarray(np.swapaxes(u, -1, -2)).reshape(sh + (4 * H,))
+
+
+class Stage(object):
+    pass
+
+
+class Model(object):
+    """The object ``ctc_model(inputs, output)`` returns (core/models.py:31-52)."""
+
+    def __init__(self, spec, num_features, device=None, seed=0, lstm_mode=0):
+        self.device = torch.device(device or 'cuda:0')
+        self.spec = spec
+        self.num_features = int(num_features)
+        self.lstm_mode = lstm_mode
+        self.optimizer = None
+        self.metrics_names = ['loss', 'ctc_loss', 'decoder_loss', 'decoder_ler']
+        self.decoder = dict(is_greedy=True)
+        self.stop_training = False
+        self._bufs = {}
+        self._step = 0
+        self._rng = torch.Generator(device=self.device)
+        self._rng.manual_seed(int(seed) + 12345)
+        self._layout(seed)
+
+    # ------------------------------------------------------------------ params
+    def _layout(self, seed):
+        rs = np.random.RandomState(seed)
+        off = 0
+        self.stages = []
+        segs = []
+        f_real, f_pad = self.num_features, self.num_features
+        init = []
+
+        def take(n):
+            nonlocal off
+            o = off
+            off += _pad4(n)
+            return o
+
+        for st in self.spec:
+            s = Stage()
+            s.kind = st['type']
+            s.f_in, s.f_in_pad = f_real, f_pad
+            if s.kind in ('noise', 'dropout'):
+                s.value = st['value']
+            elif s.kind == 'dense':
+                s.n_out = st['n_out']
+                s.l2 = st.get('l2', 0.0)
+                s.oW = take(f_pad * s.n_out)
+                s.ob = take(s.n_out)
+                segs += [(s.oW, _pad4(f_pad * s.n_out), s.l2), (s.ob, _pad4(s.n_out), 0.0)]
+                lim = math.sqrt(6.0 / (f_real + s.n_out))
+                W = rs.uniform(-lim, lim, size=(f_real, s.n_out))
+                init.append((s, 'dense', [W.astype(np.float32), np.zeros(s.n_out, np.float32)]))
+                f_real = f_pad = s.n_out
+                s.in_map = None
+            elif s.kind == 'bilstm':
+                s.H = st['H']
+                s.Hp = _pad4(s.H)
+                s.dropout_W, s.dropout_U = st.get('dropout_W', 0.0), st.get('dropout_U', 0.0)
+                s.l2_W, s.l2_U = st.get('l2_W', 0.0), st.get('l2_U', 0.0)
+                s.oW = take(f_pad * 8 * s.Hp)
+                s.oU = take(2 * s.Hp * 4 * s.Hp)
+                s.ob = take(8 * s.Hp)
+                segs += [(s.oW, _pad4(f_pad * 8 * s.Hp), s.l2_W),
+                         (s.oU, _pad4(2 * s.Hp * 4 * s.Hp), s.l2_U),
+                         (s.ob, _pad4(8 * s.Hp), 0.0)]
+                ws = []
+                for _ in range(2):      # Keras-1.2.2 consume_less='gpu' init
+                    lim = math.sqrt(6.0 / (f_real + 4 * s.H))
+                    W = rs.uniform(-lim, lim, size=(f_real, 4 * s.H))
+                    a = rs.normal(0.0, 1.0, (s.H, 4 * s.H))
+                    u, _, v = np.linalg.svd(a, full_matrices=False)
+                    U = 1.1 * (u if u.shape == (s.H, 4 * s.H) else v)
+                    b = np.zeros(4 * s.H)
+                    b[s.H:2 * s.H] = 1.0
+                    ws += [W.astype(np.float32), U.astype(np.float32), b.astype(np.float32)]
+                init.append((s, 'bilstm', ws))
+                f_real, f_pad = 2 * s.H, 2 * s.Hp
+            else:
+                raise ValueError(s.kind)
+            s.f_out, s.f_out_pad = f_real, f_pad
+            self.stages.append(s)
+        self.num_classes = f_real
+        self.n_params = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self._segments = sorted(segs)
+        self._segs_dev, self._nseg = ops.make_segments(self._segments, self.device)
+        self._norm = torch.zeros(2, dtype=torch.float64, device=self.device)
+        weights = []
+        for s, kind, ws in init:
+            weights += ws
+        self.set_weights(weights)
+
+    def _real_rows(self, s):
+        """Map of the padded input-feature rows of a stage to its real rows."""
+        prev = None
+        for st in self.stages:
+            if st is s:
+                break
+            if st.kind in ('dense', 'bilstm'):
+                prev = st
+        if prev is not None and prev.kind == 'bilstm' and prev.Hp != prev.H:
+            idx = np.concatenate([np.arange(prev.H), prev.Hp + np.arange(prev.H)])
+        else:
+            idx = np.arange(s.f_in)
+        return idx
+
+    def set_weights(self, weights):
+        """weights: flat list in the reference's Keras order (see module doc)."""
+        host = self.params.detach().cpu().numpy().copy()
+        it = iter(weights)
+        for s in self.stages:
+            if s.kind == 'dense':
+                W, b = np.asarray(next(it), np.float32), np.asarray(next(it), np.float32)
+                rows = self._real_rows(s)
+                Wp = np.zeros((s.f_in_pad, s.n_out), np.float32)
+                Wp[rows] = W
+                host[s.oW:s.oW + Wp.size] = Wp.ravel()
+                host[s.ob:s.ob + s.n_out] = b
+            elif s.kind == 'bilstm':
+                rows = self._real_rows(s)
+                Wp = np.zeros((s.f_in_pad, 2, 4 * s.Hp), np.float32)
+                Up = np.zeros((2, s.Hp, 4 * s.Hp), np.float32)
+                bp = np.zeros((2, 4 * s.Hp), np.float32)
+                for d in range(2):
+                    W, U, b = [np.asarray(next(it), np.float32) for _ in range(3)]
+                    Wp[rows, d] = _gm2um(W, s.H, s.Hp)
+                    Up[d, :s.H] = _gm2um(U, s.H, s.Hp)
+                    bp[d] = _gm2um(b, s.H, s.Hp)
+                host[s.oW:s.oW + Wp.size] = Wp.ravel()
+                host[s.oU:s.oU + Up.size] = Up.ravel()
+                host[s.ob:s.ob + bp.size] = bp.ravel()
+        self.params.copy_(torch.from_numpy(host))
+
+    def _unpack(self, flat):
+        out = []
+        for s in self.stages:
+            if s.kind == 'dense':
+                rows = self._real_rows(s)
+                W = flat[s.oW:s.oW + s.f_in_pad * s.n_out].reshape(s.f_in_pad, s.n_out)[rows]
+                out += [W.copy(), flat[s.ob:s.ob + s.n_out].copy()]
+            elif s.kind == 'bilstm':
+                rows = self._real_rows(s)
+                Wp = flat[s.oW:s.oW + s.f_in_pad * 8 * s.Hp].reshape(s.f_in_pad, 2, 4 * s.Hp)
+                Up = flat[s.oU:s.oU + 2 * s.Hp * 4 * s.Hp].reshape(2, s.Hp, 4 * s.Hp)
+                bp = flat[s.ob:s.ob + 8 * s.Hp].reshape(2, 4 * s.Hp)
+                for d in range(2):
+                    out += [_um2gm(Wp[rows, d], s.H, s.Hp), _um2gm(Up[d, :s.H], s.H, s.Hp),
+                            _um2gm(bp[d], s.H, s.Hp)]
+        return out
+
+    def get_weights(self):
+        return self._unpack(self.params.detach().cpu().numpy())
+
+    def get_gradients(self):
+        """Last computed gradients (before clipping, without the l2 term), in the
+        same order/layout as get_weights()."""
+        return self._unpack(self.grads.detach().cpu().numpy())
+
+    def count_params(self):
+        return int(sum(w.size for w in self.get_weights()))
+
+    # ------------------------------------------------------------------ compile
+    def compile(self, loss=None, optimizer=None, metrics=None, loss_weights=None):
+        """Keras signature (train.py:140-143).  ``loss``/``metrics`` are accepted for
+        surface compatibility: the objective is always 1*mean(ctc) + 0*decoder + l2."""
+        if isinstance(optimizer, str):
+            optimizer = _opt.get(optimizer)
+        self.optimizer = optimizer
+        if optimizer is not None:
+            optimizer.bind(self)
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, name, shape):
+        key = (name, tuple(int(x) for x in shape))
+        b = self._bufs.get(key)
+        if b is None:
+            # drop stale shapes of the same name to bound memory
+            for k in [k for k in self._bufs if k[0] == name]:
+                del self._bufs[k]
+            b = torch.empty(key[1], dtype=torch.float32, device=self.device)
+            self._bufs[key] = b
+        return b
+
+    def _view(self, off, n):
+        return self.params[off:off + n]
+
+    def _gview(self, off, n):
+        return self.grads[off:off + n]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training=False, masks=None):
+        """x: (T, n_pad, F) float32 CUDA slab -> logits (T, n_pad, C).
+
+        masks: optional explicit variational-dropout masks (parity tests):
+        {stage_index: (BW (2, n_pad, f_in_pad), BU (2, n_pad, Hp))}.
+        """
+        T, n_pad, F = x.shape
+        assert F == self.num_features and n_pad % 16 == 0
+        rows = T * n_pad
+        a = x
+        self._acts = []
+        for si, s in enumerate(self.stages):
+            rec = {'in': a}
+            if s.kind == 'noise':
+                if training and s.value > 0:
+                    noise = torch.randn(a.shape, generator=self._rng, device=self.device)
+                    a = a + s.value * noise
+            elif s.kind == 'dropout':
+                if training and s.value > 0:
+                    keep = (torch.rand(a.shape, generator=self._rng, device=self.device)
+                            >= s.value).to(torch.float32) / (1.0 - s.value)
+                    rec['mask'] = keep
+                    a = a * keep
+            elif s.kind == 'dense':
+                out = self._buf('dense%d' % si, (T, n_pad, s.n_out))
+                ops.gemm(a, self.params, out, rows, s.n_out, s.f_in_pad, b_off=s.oW,
+                         bias=self._view(s.ob, s.n_out))
+                a = out
+            elif s.kind == 'bilstm':
+                Hp = s.Hp
+                BW = BU = None
+                if masks is not None and si in masks:
+                    BW, BU = masks[si]
+                elif training and (s.dropout_W > 0 or s.dropout_U > 0):
+                    BW, BU = self._draw_masks(s, n_pad)
+                rec['BW'], rec['BU'] = BW, BU
+                zx = self._buf('zx', (T, n_pad, 2, 4 * Hp))
+                bias = self._view(s.ob, 8 * Hp)
+                if BW is None:
+                    ops.gemm(a, self.params, zx, rows, 8 * Hp, s.f_in_pad, b_off=s.oW, bias=bias)
+                else:       # each direction has its own input mask (two Keras layers)
+                    for d in range(2):
+                        ops.gemm(a, self.params, zx, rows, 4 * Hp, s.f_in_pad,
+                                 ldb=8 * Hp, ldc=8 * Hp, b_off=s.oW + d * 4 * Hp,
+                                 c_off=d * 4 * Hp, bias=bias[d * 4 * Hp:(d + 1) * 4 * Hp],
+                                 a_scale=BW[d], a_scale_period=n_pad)
+                y = self._buf('y%d' % si, (T, n_pad, 2 * Hp))
+                cell = self._buf('cell%d' % si, (T, n_pad, 2, Hp))
+                gates = self._buf('gates%d' % si, (T, n_pad, 2, 4 * Hp))
+                U = self._view(s.oU, 2 * Hp * 4 * Hp)
+                rec['ws'] = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
+                                             mode=self.lstm_mode)
+                rec.update(y=y, cell=cell, gates=gates)
+                a = y
+            rec['out'] = a
+            self._acts.append(rec)
+        return a
+
+    def _draw_masks(self, s, n_pad):
+        def draw(shape, p):
+            if p <= 0:
+                return torch.ones(shape, dtype=torch.float32, device=self.device)
+            keep = torch.rand(shape, generator=self._rng, device=self.device) >= p
+            return keep.to(torch.float32) / (1.0 - p)
+        return (draw((2, n_pad, s.f_in_pad), s.dropout_W), draw((2, n_pad, s.Hp), s.dropout_U))
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dlogits):
+        """dlogits (T, n_pad, C) -> fills self.grads (raw, no l2, no clip)."""
+        T, n_pad, _ = dlogits.shape
+        rows = T * n_pad
+        da = dlogits
+        split = max(1, min(32, rows // 2048))
+        for si in range(len(self.stages) - 1, -1, -1):
+            s = self.stages[si]
+            rec = self._acts[si]
+            a_in = rec['in']
+            first = not any(st.kind in ('dense', 'bilstm') for st in self.stages[:si])
+            if s.kind == 'noise':
+                continue
+            if s.kind == 'dropout':
+                if 'mask' in rec:
+                    da = da * rec['mask']
+                continue
+            if s.kind == 'dense':
+                ops.gemm(a_in, da, self.grads, s.f_in_pad, s.n_out, rows, trans_a=True,
+                         c_off=s.oW, split_k=split)
+                ops.colsum(da, rows, s.n_out, s.n_out, self._gview(s.ob, s.n_out))
+                if not first:
+                    dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
+                    ops.gemm(da, self.params, dx, rows, s.f_in_pad, s.n_out, trans_b=True,
+                             b_off=s.oW)
+                    da = dx
+            elif s.kind == 'bilstm':
+                Hp = s.Hp
+                BW, BU = rec['BW'], rec['BU']
+                dz = self._buf('dz', (T, n_pad, 2, 4 * Hp))
+                U = self._view(s.oU, 2 * Hp * 4 * Hp)
+                rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp,
+                                               mask_u=BU, mode=self.lstm_mode)
+                y = rec['y']
+                # dU[d] = (h_prev (.) B_U)^T dz[d]: h_prev is y shifted by one step in the
+                # direction's processing order (zero at its first step)
+                kk = (T - 1) * n_pad
+                for d in range(2):
+                    a_off = d * Hp + (0 if d == 0 else n_pad * 2 * Hp)
+                    b_off = d * 4 * Hp + (n_pad * 8 * Hp if d == 0 else 0)
+                    if kk > 0:
+                        ops.gemm(y, dz, self.grads, Hp, 4 * Hp, kk, trans_a=True, lda=2 * Hp,
+                                 ldb=8 * Hp, ldc=4 * Hp, a_off=a_off, b_off=b_off,
+                                 c_off=s.oU + d * Hp * 4 * Hp, split_k=split,
+                                 a_scale=None if BU is None else BU[d],
+                                 a_scale_period=n_pad)
+                    else:
+                        self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
+                # dW = (x (.) B_W)^T dz, db = colsum(dz)
+                if BW is None:
+                    ops.gemm(a_in, dz, self.grads, s.f_in_pad, 8 * Hp, rows, trans_a=True,
+                             c_off=s.oW, split_k=split)
+                else:
+                    for d in range(2):
+                        ops.gemm(a_in, dz, self.grads, s.f_in_pad, 4 * Hp, rows, trans_a=True,
+                                 ldb=8 * Hp, ldc=8 * Hp, b_off=d * 4 * Hp,
+                                 c_off=s.oW + d * 4 * Hp, split_k=split, a_scale=BW[d],
+                                 a_scale_period=n_pad)
+                ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp))
+                if not first:
+                    dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
+                    if BW is None:
+                        ops.gemm(dz, self.params, dx, rows, s.f_in_pad, 8 * Hp, trans_b=True,
+                                 b_off=s.oW)
+                    else:   # dx = sum_d B_W[d] (.) (dz_d @ W_d^T)
+                        for d in range(2):
+                            ops.gemm(dz, self.params, dx, rows, s.f_in_pad, 4 * Hp, trans_b=True,
+                                     lda=8 * Hp, ldb=8 * Hp, a_off=d * 4 * Hp,
+                                     b_off=s.oW + d * 4 * Hp, beta=0.0 if d == 0 else 1.0,
+                                     c_scale=BW[d], c_scale_period=n_pad)
+                    da = dx
+        return da
+
+    # ------------------------------------------------------------------ batches
+    def _prep_labels(self, labels, seq_len, T):
+        N = len(labels)
+        lmax = max([len(l) for l in labels] + [1])
+        lab = np.zeros((N, lmax), np.int32)
+        for n, l in enumerate(labels):
+            l = np.asarray(l, np.int64).reshape(-1)
+            need = len(l) + int(np.sum(l[1:] == l[:-1])) if len(l) else 0
+            if need > int(seq_len[n]):
+                raise ValueError('Not enough time for target transition sequence '
+                                 '(required: %d, available: %d) in sample %d'
+                                 % (need, int(seq_len[n]), n))
+            lab[n, :len(l)] = l
+        dev = self.device
+        return (torch.from_numpy(lab).to(dev),
+                torch.tensor([len(l) for l in labels], dtype=torch.int32, device=dev),
+                torch.as_tensor(np.asarray(seq_len, np.int32)).to(dev))
+
+    def to_slab(self, x_ntf):
+        """(N, T, F) batch-major host/GPU array (the reference's layout) -> (T, n_pad, F)."""
+        t = torch.as_tensor(np.asarray(x_ntf, np.float32)) if not torch.is_tensor(x_ntf) else x_ntf
+        t = t.to(self.device, dtype=torch.float32)
+        N, T, F = t.shape
+        n_pad = ops.pad16(N)
+        slab = torch.zeros((T, n_pad, F), dtype=torch.float32, device=self.device)
+        slab[:, :N] = t.permute(1, 0, 2)
+        return slab
+
+    def _unpack_inputs(self, inputs):
+        x, labels, lens = inputs[0], inputs[1], inputs[2]
+        if hasattr(labels, 'tocsr'):            # scipy.sparse (the reference's batches)
+            csr = labels.tocsr()
+            N = x.shape[0] if not torch.is_tensor(x) or x.dim() == 3 else len(lens)
+            labels = [csr.data[csr.indptr[i]:csr.indptr[i + 1]] if i < csr.shape[0] else []
+                      for i in range(len(np.asarray(lens).reshape(-1)))]
+        lens = np.asarray(lens).reshape(-1)
+        if torch.is_tensor(x) and x.dim() == 3 and x.shape[1] % 16 == 0 and \
+                getattr(x, '_asr_time_major', False):
+            slab = x
+        elif isinstance(x, tuple) and x[0] == 'slab':
+            slab = x[1]
+        else:
+            slab = self.to_slab(x)
+        return slab, [np.asarray(l).reshape(-1) for l in labels], lens
+
+    def loss_and_grads(self, slab, labels, seq_len, training=True, masks=None, n_global=None):
+        """One forward + CTC + backward.  Returns per-sample CTC loss (device) and
+        logits; self.grads holds d(mean ctc)/d params."""
+        N = len(labels)
+        T = slab.shape[0]
+        lab, lab_len, sl = self._prep_labels(labels, seq_len, T)
+        logits = self.forward(slab, training=training, masks=masks)
+        dlog = self._buf('dlogits', logits.shape)
+        ctc = ops.ctc_loss_grad(logits, lab, lab_len, sl, N, grad=dlog,
+                                grad_scale=1.0 / float(n_global or N))
+        self.backward(dlog)
+        return ctc, logits, sl
+
+    def _allreduce(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grads)
+            return dist.get_world_size()
+        return 1
+
+    def train_on_batch(self, inputs, outputs=None, masks=None, sync=True):
+        """One optimisation step on a batch ``[x, labels, inputs_length]``.
+
+        Returns [loss, ctc_loss, decoder_loss, decoder_ler] when ``sync`` (like
+        Keras), else the device tensors needed to compute them later."""
+        assert self.optimizer is not None, 'compile() first'
+        slab, labels, lens = self._unpack_inputs(inputs)
+        N = len(labels)
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        ctc, logits, sl = self.loss_and_grads(slab, labels, lens, training=True, masks=masks,
+                                              n_global=N * world)
+        self._allreduce()
+        self._step += 1
+        self.optimizer.step(self)
+        dec, dlen = ops.ctc_greedy(logits, sl, N)
+        if not sync:
+            return ctc, dec, dlen
+        return self._metrics(ctc, dec, dlen, labels)
+
+    def _metrics(self, ctc, dec, dlen, labels, hyps=None):
+        ctc_h = ctc.cpu().numpy().astype(np.float64)
+        pen = float(self._norm[1].item()) if self.optimizer is not None else 0.0
+        if hyps is None:
+            dec_h, dlen_h = dec.cpu().numpy(), dlen.cpu().numpy()
+            hyps = [dec_h[n, :dlen_h[n]].tolist() for n in range(len(labels))]
+        ler = float(np.mean(ops.edit_distance_host(hyps, [list(l) for l in labels])))
+        ctc_mean = float(np.mean(ctc_h))
+        return [ctc_mean + pen, ctc_mean, 0.0, ler]
+
+    def test_on_batch(self, inputs, outputs=None):
+        slab, labels, lens = self._unpack_inputs(inputs)
+        N = len(labels)
+        lab, lab_len, sl = self._prep_labels(labels, lens, slab.shape[0])
+        logits = self.forward(slab, training=False)
+        ctc = ops.ctc_loss_grad(logits, lab, lab_len, sl, N, grad=None)
+        hyps = None
+        dec = dlen = None
+        if self.decoder.get('is_greedy', True):
+            dec, dlen = ops.ctc_greedy(logits, sl, N)
+        else:
+            hyps, _ = ops.ctc_beam_search_host(
+                logits.cpu().numpy(), lens, N, self.decoder.get('beam_width', 100),
+                self.decoder.get('merge_repeated', True))
+        # l2 penalty of the current weights (reported in 'loss', as Keras does)
+        if self.optimizer is None or self._step == 0:
+            w2 = 0.0
+            flat = self.params
+            for off, n, l2 in self._segments:
+                if l2:
+                    w2 += l2 * float((flat[off:off + n].double() ** 2).sum().item())
+            self._norm[1] = w2
+        return self._metrics(ctc, dec, dlen, labels, hyps)
+
+    def predict(self, x, inputs_length=None):
+        """Decoded label sequences for a batch (greedy or beam, per self.decoder)."""
+        slab = x if (torch.is_tensor(x) and x.dim() == 3 and x.shape[1] % 16 == 0) else self.to_slab(x)
+        N = len(inputs_length) if inputs_length is not None else slab.shape[1]
+        lens = np.asarray(inputs_length if inputs_length is not None else [slab.shape[0]] * N).reshape(-1)
+        logits = self.forward(slab, training=False)
+        sl = torch.as_tensor(lens.astype(np.int32)).to(self.device)
+        if self.decoder.get('is_greedy', True):
+            dec, dlen = ops.ctc_greedy(logits, sl, N)
+            dec, dlen = dec.cpu().numpy(), dlen.cpu().numpy()
+            return [dec[n, :dlen[n]].tolist() for n in range(N)]
+        hyps, _ = ops.ctc_beam_search_host(logits.cpu().numpy(), lens, N,
+                                           self.decoder.get('beam_width', 100),
+                                           self.decoder.get('merge_repeated', True))
+        return hyps
+
+    # ------------------------------------------------------------------ loops
+    def fit_generator(self, generator, samples_per_epoch, nb_epoch, verbose=1, callbacks=None,
+                      validation_data=None, nb_val_samples=None, max_q_size=10, nb_worker=1,
+                      initial_epoch=0, **kwargs):
+        """Keras-1.2.2 signature (train.py:213-217).  One host thread feeds batches
+        (the reference uses one generator thread, nb_worker=1)."""
+        callbacks = callbacks or []
+        history = []
+        for cb in callbacks:
+            cb.set_model(self)
+            cb.on_train_begin()
+        for epoch in range(initial_epoch, nb_epoch):
+            t0 = time.time()
+            seen, sums = 0, np.zeros(4)
+            while seen < samples_per_epoch:
+                inputs, outputs = next(generator)
+                n = len(np.asarray(inputs[2]).reshape(-1))
+                m = self.train_on_batch(inputs, outputs)
+                sums += np.array(m) * n
+                seen += n
+            logs = dict(zip(self.metrics_names, (sums / max(seen, 1)).tolist()))
+            if validation_data is not None:
+                val = self.evaluate_generator(validation_data, nb_val_samples)
+                for k, v in zip(self.metrics_names, val):
+                    logs['val_' + k] = v
+            if verbose:
+                shown = ' - '.join('%s: %.4f' % (k, logs[k]) for k in
+                                   ('loss', 'decoder_ler', 'val_loss', 'val_decoder_ler')
+                                   if k in logs)
+                print('Epoch %d/%d - %.0fs - %s' % (epoch + 1, nb_epoch, time.time() - t0, shown))
+            history.append(logs)
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in callbacks:
+            cb.on_train_end()
+        return history
+
+    def evaluate_generator(self, generator, val_samples, max_q_size=10, nb_worker=1, **kwargs):
+        """Returns [loss, ctc_loss, decoder_loss, <decoder>_ler] averaged with batch-size
+        weights (train.py:223-227, eval.py:76-80)."""
+        seen, sums = 0, np.zeros(4)
+        while seen < val_samples:
+            inputs, outputs = next(generator)
+            n = len(np.asarray(inputs[2]).reshape(-1))
+            sums += np.array(self.test_on_batch(inputs, outputs)) * n
+            seen += n
+        return (sums / max(seen, 1)).tolist()

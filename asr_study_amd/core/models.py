@@ -1,0 +1,105 @@
+"""Model factories with the reference's names and hyper-parameters
+(core/models.py): ``ctc_model``, ``graves2006``, ``eyben``, ``brsmv1``.
+
+``train.py`` resolves them by name -- ``get_from_module('core.models', 'brsmv1')
+(**hparams)`` (train.py:127-129) -- and gets back an object with the Keras
+``compile / fit_generator / evaluate_generator / metrics_names / optimizer.lr``
+surface; here that object is core.engine.Model, which runs on the HIP kernels.
+``maas`` and ``deep_speech`` reference un-imported Keras names in the reference
+(NameError at call time) and are not provided.
+"""
+from . import ctc_utils
+from .engine import Model
+from .layers import (Input, GaussianNoise, TimeDistributed, Dense, LSTM, Bidirectional,
+                     Dropout, merge, l2)
+
+
+def ctc_model(inputs, output, **kwargs):
+    """Given the symbolic input and the (N, T, C) logit tensor of a user-built
+    topology, returns the trainable CTC model: inputs ``[inputs, labels,
+    inputs_length]``, outputs ``[ctc, decoder]`` (core/models.py:31-52).
+
+    kwargs: ``is_greedy`` / ``beam_width`` / ``merge_repeated`` for the decoder
+    (core/ctc_utils.py:8-52), ``device``, ``seed``.
+    """
+    root, chain = output.chain()
+    if root is not inputs:
+        raise ValueError('output is not connected to inputs')
+    spec = []
+    for layer in chain:
+        if isinstance(layer, GaussianNoise):
+            spec.append({'type': 'noise', 'value': layer.sigma})
+        elif isinstance(layer, Dropout):
+            spec.append({'type': 'dropout', 'value': layer.p})
+        elif isinstance(layer, TimeDistributed):
+            spec.append({'type': 'dense', 'n_out': layer.dense.output_dim, 'l2': layer.dense.l2})
+        elif isinstance(layer, Bidirectional):
+            r = layer.lstm
+            spec.append({'type': 'bilstm', 'H': r.output_dim, 'dropout_W': r.dropout_W,
+                         'dropout_U': r.dropout_U, 'l2_W': r.l2_W, 'l2_U': r.l2_U})
+        else:
+            raise NotImplementedError(type(layer).__name__)
+    model = Model(spec, inputs.features, device=kwargs.get('device'),
+                  seed=kwargs.get('seed', 0))
+    model.decoder = ctc_utils.decoder_config(**{k: v for k, v in kwargs.items()
+                                                if k in ('is_greedy', 'beam_width',
+                                                         'merge_repeated', 'top_paths')})
+    return model
+
+
+def graves2006(num_features=26, num_hiddens=100, num_classes=28, std=.6, **kw):
+    """Graves et al. 2006 (core/models.py:55-73)."""
+    x = Input(name='inputs', shape=(None, num_features))
+    o = x
+    o = GaussianNoise(std)(o)
+    o = Bidirectional(LSTM(num_hiddens, return_sequences=True, consume_less='gpu'))(o)
+    o = TimeDistributed(Dense(num_classes))(o)
+    return ctc_model(x, o, **kw)
+
+
+def eyben(num_features=39, num_hiddens=[78, 120, 27], num_classes=28, **kw):
+    """Eyben et al. 2009 (core/models.py:76-103)."""
+    assert len(num_hiddens) == 3
+    x = Input(name='inputs', shape=(None, num_features))
+    o = x
+    if num_hiddens[0]:
+        o = TimeDistributed(Dense(num_hiddens[0]))(o)
+    if num_hiddens[1]:
+        o = Bidirectional(LSTM(num_hiddens[1], return_sequences=True, consume_less='gpu'))(o)
+    if num_hiddens[2]:
+        o = Bidirectional(LSTM(num_hiddens[2], return_sequences=True, consume_less='gpu'))(o)
+    o = TimeDistributed(Dense(num_classes))(o)
+    return ctc_model(x, o, **kw)
+
+
+def brsmv1(num_features=39, num_classes=28, num_hiddens=256, num_layers=5,
+           dropout=0.2, zoneout=0., input_dropout=False, input_std_noise=.0,
+           weight_decay=1e-4, residual=None, layer_norm=None, mi=None,
+           activation='tanh', **kw):
+    """BRSM v1.0 (core/models.py:217-281), same defaults."""
+    x = Input(name='inputs', shape=(None, num_features))
+    o = x
+    if input_std_noise is not None:
+        o = GaussianNoise(input_std_noise)(o)
+    if residual is not None:
+        o = TimeDistributed(Dense(num_hiddens * 2, W_regularizer=l2(weight_decay)))(o)
+    if input_dropout:
+        o = Dropout(dropout)(o)
+    for i, _ in enumerate(range(num_layers)):
+        new_o = Bidirectional(LSTM(num_hiddens,
+                                   return_sequences=True,
+                                   W_regularizer=l2(weight_decay),
+                                   U_regularizer=l2(weight_decay),
+                                   dropout_W=dropout,
+                                   dropout_U=dropout,
+                                   zoneout_c=zoneout,
+                                   zoneout_h=zoneout,
+                                   mi=mi,
+                                   layer_norm=layer_norm,
+                                   activation=activation))(o)
+        if residual is not None:
+            o = merge([new_o, o], mode=residual)
+        else:
+            o = new_o
+    o = TimeDistributed(Dense(num_classes, W_regularizer=l2(weight_decay)))(o)
+    return ctc_model(x, o, **kw)

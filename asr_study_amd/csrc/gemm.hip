@@ -186,9 +186,9 @@ gemm_f32_mfma_kernel(TileSrc A, TileSrc B, int M, int N, int K, int k_per_split,
         } else {
           v *= ep.alpha;
           float* dst = ep.C + (size_t)row * ep.ldc + col;
-          if (ep.beta != 0.f) v += ep.beta * *dst;
           if (ep.bias) v += ep.bias[col];
           if (ep.c_scale) v *= ep.c_scale[(size_t)(row % ep.c_period) * ep.c_ld + col];
+          if (ep.beta != 0.f) v += ep.beta * *dst;
           *dst = v;
         }
       }
@@ -206,9 +206,9 @@ gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, 
     for (int s = 0; s < splits; ++s) v += partial[(size_t)s * total + e];
     v *= ep.alpha;
     float* dst = ep.C + (size_t)row * ep.ldc + col;
-    if (ep.beta != 0.f) v += ep.beta * *dst;
     if (ep.bias) v += ep.bias[col];
     if (ep.c_scale) v *= ep.c_scale[(size_t)(row % ep.c_period) * ep.c_ld + col];
+    if (ep.beta != 0.f) v += ep.beta * *dst;
     *dst = v;
   }
 }

@@ -103,8 +103,8 @@ int asr_frontend_features(const asr_frontend_cfg* cfg, const float* audio,
 /* K4/K6  fp32 MFMA GEMM.  Replaces K.dot(x*B_W, W) (core/layers.py:439,     */
 /* hoisted out of the time loop), TimeDistributed(Dense) (core/models.py     */
 /* :278-279) and their tf.gradients.                                         */
-/*   C[M,N] = alpha * (opA(A) (.) a_scale) @ opB(B) + beta * C (+ bias[N])   */
-/*   then C (.)= c_scale.  trans_a: A is stored (K,M) row-major; trans_b: B  */
+/*   C[M,N] = c_scale (.) (alpha * (opA(A) (.) a_scale) @ opB(B) + bias[N])  */
+/*            + beta * C.    trans_a: A is stored (K,M) row-major; trans_b: B */
 /*   is stored (N,K) row-major.  a_scale / c_scale: optional (period, M or K */
 /*   / N) variational-dropout masks indexed by (row % period); pass NULL.    */
 /* split_k > 1 needs workspace of split_k*M*N floats (deterministic reduce). */

@@ -1,0 +1,170 @@
+"""-m gpu: the whole hot path (BiLSTM stack -> Dense -> CTC -> BPTT -> clip+Adam)
+through the product's ctc_model()/brsmv1() surface vs the float64 oracle.
+Tolerances: logits/activations atol 1e-4, loss rtol 1e-4, gradients atol 1e-4 *
+max|grad|, greedy decode indices exact, weights after 3 Adam steps atol 2e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lstm as OL
+from oracle import optim as OO
+from oracle import decode as OD
+from tests.gpu_util import report
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_params(model_weights, n_layers, in_dense=False):
+    it = iter([w.astype(np.float64) for w in model_weights])
+    p = {'layers': []}
+    if in_dense:
+        p['in_dense'] = {'W': next(it), 'b': next(it)}
+    for _ in range(n_layers):
+        layer = {}
+        for d in ('fwd', 'bwd'):
+            layer[d] = {'W': next(it), 'U': next(it), 'b': next(it)}
+        p['layers'].append(layer)
+    p['dense'] = {'W': next(it), 'b': next(it)}
+    return p
+
+
+def _flat(tree):
+    return [a for _, a in OL.flatten(tree)]
+
+
+def _batch(rs, N, T, F, C, ragged=True):
+    x = rs.randn(N, T, F).astype(np.float32)
+    lens = np.full(N, T, np.int64)
+    if ragged:
+        lens[1::2] = rs.randint(T // 2, T, size=len(lens[1::2]))
+        for n in range(N):
+            x[n, lens[n]:] = 0.0                      # pad_sequences 'post'
+    labels = [rs.randint(0, C - 1, size=rs.randint(1, max(2, T // 6))).tolist() for _ in range(N)]
+    return x, labels, lens
+
+
+@pytest.mark.parametrize('H,wd,use_masks', [(12, 0.0, False), (10, 1e-2, True)])
+def test_brsmv1_small_forward_backward_adam(H, wd, use_masks):
+    from asr_study_amd.core import models, optimizers
+    rs = np.random.RandomState(H)
+    N, T, F, C, L = 5, 23, 9, 7, 2
+    model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
+                          dropout=0.0, weight_decay=wd, seed=3)
+    w = [a + rs.randn(*a.shape).astype(np.float32) * 0.2 for a in model.get_weights()]
+    model.set_weights(w)
+    for a, b in zip(model.get_weights(), w):           # layout round trip
+        assert np.array_equal(a, b)
+    model.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=0.5))
+    x, labels, lens = _batch(rs, N, T, F, C)
+    params = _oracle_params(w, L)
+    n_pad = 16
+    masks_o = masks_g = None
+    if use_masks:
+        masks_o, masks_g = [], {}
+        n_in = F
+        si = 1                                           # stage 0 is GaussianNoise
+        for li in range(L):
+            Hp = (H + 3) // 4 * 4
+            f_in_pad = n_in if li == 0 else 2 * Hp
+            mo = {}
+            BW = np.ones((2, n_pad, f_in_pad), np.float32)
+            BU = np.ones((2, n_pad, Hp), np.float32)
+            for di, d in enumerate(('fwd', 'bwd')):
+                bw = ((rs.rand(N, n_in) > 0.2) / 0.8)
+                bu = ((rs.rand(N, H) > 0.2) / 0.8)
+                mo[d] = (bw, bu)
+                if li == 0:
+                    BW[di, :N] = bw
+                else:       # padded feature layout [fwd Hp | bwd Hp]
+                    BW[di, :N, :H] = bw[:, :H]
+                    BW[di, :N, Hp:Hp + H] = bw[:, H:]
+                BU[di, :N, :H] = bu
+            masks_o.append(mo)
+            masks_g[si] = (torch.from_numpy(BW).cuda(), torch.from_numpy(BU).cuda())
+            n_in = 2 * H
+            si += 1
+    xt = np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float64)
+    want = OL.loss_and_grads(params, xt, labels, lens, weight_decay=0.0, masks=masks_o)
+    slab = model.to_slab(x)
+    ctc, logits, _ = model.loss_and_grads(slab, labels, lens, training=True, masks=masks_g)
+    torch.cuda.synchronize()
+    assert report('model logits', logits.cpu().numpy()[:, :N], want['logits']) < 1e-4
+    np.testing.assert_allclose(ctc.cpu().numpy(), want['ctc'], rtol=1e-4)
+    got_g = model.get_gradients()
+    for (name, g), gg in zip(OL.flatten(want['grads']), got_g):
+        scale = max(1e-3, np.abs(g).max())
+        assert report('grad ' + name, gg, g) < 1e-4 * scale + 1e-6, name
+    # greedy decode
+    from asr_study_amd.core import ctc_utils
+    hyp = ctc_utils.decode((logits, lens), is_greedy=True)
+    assert hyp == OD.greedy_decode(want['logits'], lens)
+    # three optimiser steps (clip + l2 + Adam) against the oracle
+    opt = OO.Adam(lr=1e-2, clipnorm=0.5)
+    p_flat = _flat(params)
+    for step in range(3):
+        out = OL.loss_and_grads(params, xt, labels, lens, weight_decay=wd, masks=masks_o)
+        opt.step(p_flat, _flat(out['grads']))
+        m = model.train_on_batch([('slab', slab), labels, lens], masks=masks_g)
+        assert abs(m[1] - float(np.mean(out['ctc']))) < 1e-4 * max(1.0, abs(m[1]))
+        assert abs(m[0] - out['loss']) < 2e-4 * max(1.0, abs(out['loss']))
+    for (name, a), b in zip(OL.flatten(params), model.get_weights()):
+        assert report('weights ' + name, b, a) < 5e-5, name
+
+
+def test_cfg1_graves_ragged_batch():
+    """BASELINE cfg1: F=26, 1 x BiLSTM(100), 28 classes, batch 4, T in [99, 999]."""
+    from asr_study_amd.core import models
+    rs = np.random.RandomState(1)
+    N, T, F, C, H = 4, 300, 26, 28, 100
+    model = models.graves2006(num_features=F, num_hiddens=H, num_classes=C, std=0.6, seed=1)
+    w = model.get_weights()
+    x, labels, lens = _batch(rs, N, T, F, C)
+    lens[0], lens[2] = T, 99
+    x[2, 99:] = 0
+    params = _oracle_params(w, 1)
+    xt = np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float64)
+    want = OL.loss_and_grads(params, xt, labels, lens)
+    slab = model.to_slab(x)
+    ctc, logits, _ = model.loss_and_grads(slab, labels, lens, training=False)
+    torch.cuda.synchronize()
+    assert report('cfg1 logits', logits.cpu().numpy()[:, :N], want['logits']) < 1e-4
+    np.testing.assert_allclose(ctc.cpu().numpy(), want['ctc'], rtol=1e-4)
+    for (name, g), gg in zip(OL.flatten(want['grads']), model.get_gradients()):
+        scale = max(1e-3, np.abs(g).max())
+        assert report('cfg1 grad ' + name, gg, g) < 1e-4 * scale + 1e-6, name
+    m = model.test_on_batch([('slab', slab), labels, lens])
+    assert abs(m[1] - float(np.mean(want['ctc']))) < 1e-3
+    hyp = OD.greedy_decode(want['logits'], lens)
+    assert abs(m[3] - OD.ler(hyp, labels)) < 1e-6
+
+
+def test_eyben_padded_hidden_sizes():
+    """H = 78 / 27 are not multiples of 4: the engine pads with zero units."""
+    from asr_study_amd.core import models
+    rs = np.random.RandomState(2)
+    N, T, F, C = 3, 40, 11, 6
+    model = models.eyben(num_features=F, num_hiddens=[13, 78, 27], num_classes=C, seed=2)
+    w = model.get_weights()
+    x, labels, lens = _batch(rs, N, T, F, C, ragged=False)
+    it = iter([a.astype(np.float64) for a in w])
+    params = {'in_dense': {'W': next(it), 'b': next(it)}, 'layers': []}
+    for _ in range(2):
+        params['layers'].append({d: {'W': next(it), 'U': next(it), 'b': next(it)}
+                                 for d in ('fwd', 'bwd')})
+    params['dense'] = {'W': next(it), 'b': next(it)}
+    xt = np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float64)
+    want = OL.loss_and_grads(params, xt, labels, lens)
+    ctc, logits, _ = model.loss_and_grads(model.to_slab(x), labels, lens, training=False)
+    torch.cuda.synchronize()
+    assert report('eyben logits', logits.cpu().numpy()[:, :N], want['logits']) < 1e-4
+    for (name, g), gg in zip(OL.flatten(want['grads']), model.get_gradients()):
+        scale = max(1e-3, np.abs(g).max())
+        assert report('eyben grad ' + name, gg, g) < 1e-4 * scale + 1e-6, name
+
+
+def test_infeasible_label_raises_like_tf():
+    from asr_study_amd.core import models
+    model = models.graves2006(num_features=5, num_hiddens=8, num_classes=4, std=0.0)
+    x = np.zeros((1, 3, 5), np.float32)
+    with pytest.raises(ValueError):
+        model.loss_and_grads(model.to_slab(x), [[1, 1, 1]], [3])
