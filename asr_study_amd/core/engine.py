@@ -424,15 +424,31 @@ class Model(object):
     def loss_and_grads(self, slab, labels, seq_len, training=True, masks=None, n_global=None):
         """One forward + CTC + backward.  Returns per-sample CTC loss (device) and
         logits; self.grads holds d(mean ctc)/d params."""
-        N = len(labels)
-        T = slab.shape[0]
-        lab, lab_len, sl = self._prep_labels(labels, seq_len, T)
+        lab, lab_len, sl = self._prep_labels(labels, seq_len, slab.shape[0])
+        return self.loss_and_grads_device(slab, lab, lab_len, sl, len(labels), training, masks,
+                                          n_global)
+
+    def loss_and_grads_device(self, slab, lab, lab_len, sl, N, training=True, masks=None,
+                              n_global=None):
+        """Same with labels (N, l_max) / label_len / seq_len already on the device."""
         logits = self.forward(slab, training=training, masks=masks)
         dlog = self._buf('dlogits', logits.shape)
         ctc = ops.ctc_loss_grad(logits, lab, lab_len, sl, N, grad=dlog,
                                 grad_scale=1.0 / float(n_global or N))
         self.backward(dlog)
         return ctc, logits, sl
+
+    def train_step_device(self, slab, lab, lab_len, sl, N, world=1):
+        """A full optimisation step with every input resident in HBM and no host
+        synchronisation: forward, CTC, BPTT, (RCCL all-reduce), clip + update, greedy
+        decode for the LER metric.  Returns device tensors (ctc, decoded, lengths)."""
+        ctc, logits, sl = self.loss_and_grads_device(slab, lab, lab_len, sl, N, training=True,
+                                                     n_global=N * world)
+        self._allreduce()
+        self._step += 1
+        self.optimizer.step(self)
+        dec, dlen = ops.ctc_greedy(logits, sl, N)
+        return ctc, dec, dlen
 
     def _allreduce(self):
         import torch.distributed as dist

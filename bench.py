@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio-seconds/second TRAINED on the acoustic hot path
+(MFCC/log-mel front-end -> BiLSTM stack fwd/bwd -> CTC loss/grad/greedy decode ->
+global-norm clip + Adam, + RCCL gradient all-reduce when N > 1), synthetic 16 kHz
+10 s utterances, random-init weights of the named topology.
+
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; weak scaling (per-GPU batch fixed).  Rank 0 prints ONE JSON
+line.  A "step" = one pass of the hot path over one mini-batch whose samples are
+already resident in HBM when the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1]: brsmv1 defaults, batch 32
+    'cfg2': dict(model='brsmv1', F=39, H=256, L=5, C=28, N=32, feat='mfcc',
+                 desc='brsmv1 5xBiLSTM(256), MFCC-39, 28-class CTC, batch 32 x 10 s @16 kHz'),
+    # BASELINE.json configs[2]: 5xBiLSTM(512), 80-dim log-mel, batch 64 (the conv
+    # front-end named there does not exist in the reference, SURVEY.md 8: not built)
+    'cfg3': dict(model='brsmv1', F=80, H=512, L=5, C=28, N=64, feat='logfbank80',
+                 desc='5xBiLSTM(512), log-mel-80, 28-class CTC, batch 64 x 10 s @16 kHz'),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-in MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+SAMPLES = 160000                  # 10 s @ 16 kHz -> T = 999 frames
+
+
+def cpu_baseline(cfg):
+    """The oracle (a NumPy port of the reference algorithm: per-timestep two-matmul
+    LSTM loop, CPU CTC, BPTT, Adam) timed on this host on a BOUNDED sample of the
+    same workload: same topology, 4 utterances of 2 s (T = 199)."""
+    from oracle import frontend as OF
+    from oracle import lstm as OL
+    from oracle import optim as OO
+    n, secs = 4, 2.0
+    rs = np.random.RandomState(0)
+    sigs = [rs.randn(int(16000 * secs)).astype(np.float32) for _ in range(n)]
+    labels = [rs.randint(0, 25, size=rs.randint(2, 20)).tolist() for _ in range(n)]
+    params = OL.init_model(seed=0, num_features=cfg['F'], num_hiddens=cfg['H'],
+                           num_layers=cfg['L'], num_classes=cfg['C'], dtype=np.float32)
+    opt = OO.Adam(lr=1e-3, clipnorm=400.0)
+    kind, kw = ('mfcc', {}) if cfg['feat'] == 'mfcc' else ('logfbank', {'num_filt': 80})
+
+    def step():
+        feats = [OF.extract(kind, s.astype(np.float64), **kw).astype(np.float32) for s in sigs]
+        x = np.stack(feats, axis=1)                       # (T, N, F)
+        out = OL.loss_and_grads(params, x, labels, [x.shape[0]] * n, weight_decay=1e-4)
+        opt.step([a for _, a in OL.flatten(params)], [a for _, a in OL.flatten(out['grads'])])
+    step()                                                # warm caches / BLAS threads
+    t0 = time.time()
+    reps = 0
+    while reps < 2 or time.time() - t0 < 10.0:
+        step()
+        reps += 1
+        if time.time() - t0 > 30.0:
+            break
+    dt = (time.time() - t0) / reps
+    try:
+        import threadpoolctl
+        threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {'value': round(n * secs / dt, 2), 'unit': 'audio-seconds/s', 'cores': int(threads),
+            'kind': 'port',
+            'sample': '%d utterances x %.0f s (T=199), same topology, %d step(s), NumPy/BLAS '
+                      'float32 oracle port incl. front-end, CTC, BPTT, Adam' % (n, secs, reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default=os.environ.get('ASR_BENCH_CONFIG', 'cfg2'),
+                    choices=sorted(CONFIGS))
+    ap.add_argument('--dropout', type=float, default=0.2)      # brsmv1 default
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the hot path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__
+    __graft_entry__.build()
+    from asr_study_amd import ops
+    from asr_study_amd.core import models, optimizers
+    from asr_study_amd.preprocessing import audio
+
+    N, F, H, L, C = cfg['N'], cfg['F'], cfg['H'], cfg['L'], cfg['C']
+    model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
+                          dropout=args.dropout, weight_decay=1e-4, seed=0, device=dev)
+    model.compile(optimizer=optimizers.Adam(lr=1e-3, clipnorm=400))
+    feat = audio.MFCC(device=dev) if cfg['feat'] == 'mfcc' else audio.LogFbank(num_filt=80, device=dev)
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    sig = np.empty(N * SAMPLES, np.float32)
+    for i in range(N):
+        sig[i * SAMPLES:(i + 1) * SAMPLES] = np.random.RandomState(1000 * rank + i).randn(SAMPLES)
+    audio_d = torch.from_numpy(sig).to(dev)
+    offs = (torch.arange(N, dtype=torch.int32) * SAMPLES).to(dev)
+    lens = torch.full((N,), SAMPLES, dtype=torch.int32, device=dev)
+    host_lens = [SAMPLES] * N
+    rs = np.random.RandomState(77 + rank)
+    lab_len = rs.randint(2, 50, size=N)
+    lab = np.zeros((N, 49), np.int32)
+    for n in range(N):
+        lab[n, :lab_len[n]] = rs.randint(0, 25, size=lab_len[n])
+    lab_d = torch.from_numpy(lab).to(dev)
+    lab_len_d = torch.from_numpy(lab_len.astype(np.int32)).to(dev)
+
+    lstm_ev = []
+
+    def step(record=False):
+        slab, frames = feat.batch_device(audio_d, offs, lens, host_lens)
+        if record:
+            orig = ops.lstm_seq_fwd
+
+            def timed(*a, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = orig(*a, **k)
+                e1.record()
+                lstm_ev.append((e0, e1))
+                return r
+            ops.lstm_seq_fwd = timed
+            try:
+                return model.train_step_device(slab, lab_d, lab_len_d, frames, N, world)
+            finally:
+                ops.lstm_seq_fwd = orig
+        return model.train_step_device(slab, lab_d, lab_len_d, frames, N, world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = step(record=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the persistent kernels must not have abandoned a spin
+    for name in ('lstm_fwd', 'lstm_bwd'):
+        ops.lstm_status(ops.WS.get(name, 0, dev))
+    ctc = out[0].cpu().numpy()
+    assert np.all(np.isfinite(ctc)), 'non-finite CTC loss in the benchmark step'
+
+    if rank == 0:
+        T = 999
+        n_pad = ops.pad16(N)
+        ms = dt / args.steps * 1e3
+        value = world * N * 10.0 / (dt / args.steps)
+        lstm_ms = float(np.mean([a.elapsed_time(b) for a, b in lstm_ev])) if lstm_ev else None
+        # dominant kernel: the persistent recurrent forward kernel (one launch per
+        # layer): algorithmic flops = 2 * T * n_pad * 2 dirs * H * 4H
+        flops = 2.0 * T * n_pad * 2 * H * 4 * H
+        ach = flops / (lstm_ms * 1e-3) / 1e12 if lstm_ms else None
+        line = {
+            'metric': 'audio-seconds/sec trained (MFCC+BiLSTM+CTC)',
+            'value': round(value, 1), 'unit': 'audio-seconds/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s: %s' % (args.config, cfg['desc']),
+                       'global_batch': world * N, 'utterance_seconds': 10.0, 'frames': T,
+                       'dropout': args.dropout, 'optimizer': 'adam(clipnorm=400)',
+                       'parallelism': 'dp%d' % world, 'params': model.count_params()},
+            'roofline': {'kernel': 'lstm_fwd_kernel (persistent recurrent BiLSTM layer)',
+                         'bound': 'mfma', 'achieved': round(ach, 3) if ach else None,
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
+                         'traffic': None,
+                         'avg_launch_ms': round(lstm_ms, 4) if lstm_ms else None,
+                         'flops_per_launch': flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
