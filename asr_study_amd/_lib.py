@@ -63,7 +63,9 @@ SIGNATURES = {
                                         void_p]),
     'asr_gemm_workspace_bytes': (C.c_size_t, [C.POINTER(GemmArgs)]),
     'asr_gemm': (C.c_int, [C.POINTER(GemmArgs), void_p, C.c_size_t, void_p]),
-    'asr_colsum': (C.c_int, [void_p, C.c_int, C.c_int, C.c_int, void_p, C.c_float, void_p]),
+    'asr_colsum_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'asr_colsum': (C.c_int, [void_p, C.c_int, C.c_int, C.c_int, void_p, C.c_float, void_p,
+                             C.c_size_t, void_p]),
     'asr_lstm_workspace_bytes': (C.c_size_t, [C.POINTER(LstmArgs), C.c_int]),
     'asr_lstm_seq_fwd': (C.c_int, [C.POINTER(LstmArgs), void_p, C.c_size_t, void_p]),
     'asr_lstm_seq_bwd': (C.c_int, [C.POINTER(LstmArgs), void_p, C.c_size_t, void_p]),

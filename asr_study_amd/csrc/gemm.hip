@@ -213,24 +213,50 @@ gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, 
   }
 }
 
-// out[n] = beta*out[n] + sum_m X[m][n]; block = 256 threads covers 64 columns x 4
-// row phases; rows are split over blockIdx.y and combined with atomics only when
-// gridDim.y > 1 (kept at 1 here: deterministic).
+// Column sums (bias gradients): out[n] = beta*out[n] + sum_m X[m][n].  HBM-bound:
+// X is read exactly once with 256-byte coalesced rows.  Stage 1: grid (N/64, RS);
+// each 256-thread block owns 64 columns x one slice of rows (4 row phases, float64
+// accumulators, LDS combine) and writes one float64 partial per column; stage 2
+// adds the RS partials in a fixed order (deterministic).
 __global__ void __launch_bounds__(256)
-colsum_kernel(const float* __restrict__ X, int M, int N, int ldx, float* __restrict__ out,
-              float beta) {
+colsum_partial_kernel(const float* __restrict__ X, int M, int N, int ldx, int rows_per_slice,
+                      double* __restrict__ partial) {
   __shared__ double part[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cx;
-  double s = 0.0;
-  if (col < N)
-    for (int m = ry; m < M; m += 4) s += (double)X[(size_t)m * ldx + col];
-  part[ry][cx] = s;
-  __syncthreads();
-  if (ry == 0 && col < N) {
-    const double t = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
-    out[col] = (beta != 0.f ? beta * out[col] : 0.f) + (float)t;
+  const int m0 = blockIdx.y * rows_per_slice;
+  int m1 = m0 + rows_per_slice;
+  if (m1 > M) m1 = M;
+  double s0 = 0.0, s1 = 0.0;
+  if (col < N) {
+    int m = m0 + ry;
+    for (; m + 4 < m1; m += 8) {
+      s0 += (double)X[(size_t)m * ldx + col];
+      s1 += (double)X[(size_t)(m + 4) * ldx + col];
+    }
+    for (; m < m1; m += 4) s0 += (double)X[(size_t)m * ldx + col];
   }
+  part[ry][cx] = s0 + s1;
+  __syncthreads();
+  if (ry == 0 && col < N)
+    partial[(size_t)blockIdx.y * N + col] = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+}
+
+__global__ void __launch_bounds__(256)
+colsum_final_kernel(const double* __restrict__ partial, int slices, int N,
+                    float* __restrict__ out, float beta) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  double t = 0.0;
+  for (int s = 0; s < slices; ++s) t += partial[(size_t)s * N + col];
+  out[col] = (beta != 0.f ? beta * out[col] : 0.f) + (float)t;
+}
+
+int colsum_slices(int M) {
+  int rs = (M + 127) / 128;
+  if (rs > 256) rs = 256;
+  if (rs < 1) rs = 1;
+  return rs;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -295,12 +321,26 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
   return ASR_OK;
 }
 
+extern "C" size_t asr_colsum_workspace_bytes(int M, int N) {
+  return asr_align_up((size_t)colsum_slices(M) * N * sizeof(double), 256);
+}
+
 extern "C" int asr_colsum(const float* X, int M, int N, int ldx, float* out, float beta,
-                          asr_stream_t stream_) {
+                          void* workspace, size_t ws_bytes, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  ASR_CHECK_ARG(X && out && M > 0 && N > 0 && ldx >= N, "colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, X, M, N, ldx,
-                     out, beta);
+  ASR_CHECK_ARG(X && out && workspace && M > 0 && N > 0 && ldx >= N, "colsum: bad arguments");
+  if (ws_bytes < asr_colsum_workspace_bytes(M, N)) {
+    asr_set_error("colsum: workspace too small");
+    return ASR_ERR_WORKSPACE;
+  }
+  const int rs = colsum_slices(M);
+  const int rows_per_slice = (M + rs - 1) / rs;
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, stream, X, M, N,
+                     ldx, rows_per_slice, partial);
+  ASR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, partial,
+                     rs, N, out, beta);
   ASR_CHECK_LAUNCH();
   return ASR_OK;
 }

@@ -83,8 +83,11 @@ def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ld
 
 def colsum(X, M, N, ldx, out, beta=0.0, x_off=0):
     lib = L.load()
+    nbytes = lib.asr_colsum_workspace_bytes(int(M), int(N))
+    ws = WS.get('colsum', nbytes, out.device)
     L.check(lib.asr_colsum(C.c_void_p(X.data_ptr() + 4 * int(x_off)), int(M), int(N),
-                           int(ldx), _ptr(out), float(beta), _stream()), 'asr_colsum')
+                           int(ldx), _ptr(out), float(beta), _ptr(ws), nbytes, _stream()),
+            'asr_colsum')
 
 
 # --------------------------------------------------------------------------- LSTM

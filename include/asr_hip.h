@@ -128,9 +128,11 @@ typedef struct asr_gemm_args {
 size_t asr_gemm_workspace_bytes(const asr_gemm_args* a);
 int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes,
              asr_stream_t stream);
-/* out[n] (+)= sum_m X[m, n]  (bias gradients).                              */
+/* out[n] = beta*out[n] + sum_m X[m, n]  (bias gradients; X read once,       */
+/* float64 accumulation, fixed-order two-stage reduce).                      */
+size_t asr_colsum_workspace_bytes(int M, int N);
 int asr_colsum(const float* X, int M, int N, int ldx, float* out, float beta,
-               asr_stream_t stream);
+               void* workspace, size_t ws_bytes, asr_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* K5  Recurrent LSTM sequence kernels (both directions of one Bidirectional */
