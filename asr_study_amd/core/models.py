@@ -54,7 +54,10 @@ def graves2006(num_features=26, num_hiddens=100, num_classes=28, std=.6, **kw):
     o = GaussianNoise(std)(o)
     o = Bidirectional(LSTM(num_hiddens, return_sequences=True, consume_less='gpu'))(o)
     o = TimeDistributed(Dense(num_classes))(o)
-    return ctc_model(x, o, **kw)
+    model = ctc_model(x, o, **kw)
+    model.config = {'name': 'graves2006', 'kwargs': dict(
+        num_features=num_features, num_hiddens=num_hiddens, num_classes=num_classes, std=std)}
+    return model
 
 
 def eyben(num_features=39, num_hiddens=[78, 120, 27], num_classes=28, **kw):
@@ -69,7 +72,10 @@ def eyben(num_features=39, num_hiddens=[78, 120, 27], num_classes=28, **kw):
     if num_hiddens[2]:
         o = Bidirectional(LSTM(num_hiddens[2], return_sequences=True, consume_less='gpu'))(o)
     o = TimeDistributed(Dense(num_classes))(o)
-    return ctc_model(x, o, **kw)
+    model = ctc_model(x, o, **kw)
+    model.config = {'name': 'eyben', 'kwargs': dict(
+        num_features=num_features, num_hiddens=list(num_hiddens), num_classes=num_classes)}
+    return model
 
 
 def brsmv1(num_features=39, num_classes=28, num_hiddens=256, num_layers=5,
@@ -102,4 +108,10 @@ def brsmv1(num_features=39, num_classes=28, num_hiddens=256, num_layers=5,
         else:
             o = new_o
     o = TimeDistributed(Dense(num_classes, W_regularizer=l2(weight_decay)))(o)
-    return ctc_model(x, o, **kw)
+    model = ctc_model(x, o, **kw)
+    model.config = {'name': 'brsmv1', 'kwargs': dict(
+        num_features=num_features, num_classes=num_classes, num_hiddens=num_hiddens,
+        num_layers=num_layers, dropout=dropout, zoneout=zoneout, input_dropout=input_dropout,
+        input_std_noise=input_std_noise, weight_decay=weight_decay, residual=residual,
+        layer_norm=layer_norm, mi=mi, activation=activation)}
+    return model

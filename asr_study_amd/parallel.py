@@ -1,0 +1,109 @@
+"""Mini-batch data parallelism: one process per GPU, RCCL all-reduce over xGMI.
+
+The reference has no distributed code at all; this module is the one
+parallelism the north star asks for.  Each global mini-batch is drawn identically on
+every rank (same seed -> same Keras index stream) and rank r keeps the utterances
+``r::world`` of the SORTED index array (HDF5 reads stay monotonic,
+datasets/dataset_generator.py:200).  Every rank pads to the GLOBAL T_max so the
+backward LSTM sees the same zero tail as a single-GPU run.  Gradients are summed
+with ONE fp32 all-reduce over the model's flat gradient buffer (27.7 MB at cfg2,
+110.6 MB at cfg3) and were already scaled by 1/N_global in the CTC kernel, so the
+sum IS the gradient of the global batch mean; clip + Adam then run replicated.
+``torch.distributed`` backend 'nccl' is RCCL on ROCm; 'gloo' serves the CPU tests.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialises torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE (torchrun).
+    Returns (rank, world).  No-op for single-process runs."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world <= 1:
+        return 0, 1
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    kw = {}
+    if backend == 'nccl':
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        kw['device_id'] = torch.device('cuda', local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def finalize():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def shard_indices(index_array, rank, world):
+    """Rank r's share of a batch: r::world of the sorted indices."""
+    return np.sort(np.asarray(index_array))[rank::world]
+
+
+def allreduce_sum_(flat):
+    """In-place sum over ranks of a flat tensor (the model's gradient buffer)."""
+    if world_size() > 1:
+        dist.all_reduce(flat)
+    return flat
+
+
+def broadcast_parameters(model, src=0):
+    if world_size() > 1:
+        dist.broadcast(model.params, src)
+
+
+def reduce_metrics(sums, count):
+    """Sum (metric_sums, sample_count) over ranks -> global batch-weighted means."""
+    t = torch.tensor(list(sums) + [float(count)], dtype=torch.float64)
+    if world_size() > 1:
+        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' \
+            else torch.device('cpu')
+        t = t.to(dev)
+        dist.all_reduce(t)
+        t = t.cpu()
+    return (t[:-1] / max(float(t[-1]), 1.0)).tolist()
+
+
+class ShardedFlow(object):
+    """Wraps a DatasetIterator: every rank advances the same index stream and keeps
+    its ``rank::world`` shard; inputs are padded to the global batch's T_max."""
+
+    def __init__(self, flow, rank, world):
+        self.flow, self.rank, self.world = flow, rank, world
+
+    @property
+    def len(self):
+        return self.flow.len
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        (x, labels, lens), (zeros, _) = next(self.flow)
+        n = len(np.asarray(lens).reshape(-1))
+        keep = np.arange(n)[self.rank::self.world]
+        if len(keep) == 0:
+            keep = np.arange(n)[:1]
+        csr = labels.tocsr()
+        lab = [csr.data[csr.indptr[i]:csr.indptr[i + 1]] for i in keep]
+        if isinstance(x, tuple) and x[0] == 'slab':
+            raise NotImplementedError('on-device features + sharding: shard before extraction')
+        x = np.asarray(x)[keep]                  # still padded to the GLOBAL T_max
+        return ([x, lab, np.asarray(lens).reshape(-1)[keep]], [zeros[keep], lab])
+
+    next = __next__

@@ -1,0 +1,71 @@
+"""Model (re)loading with the reference's surface (utils/core_utils.py).
+
+``load_model(fname, return_meta, mode)``: mode 'train' rebuilds the model as
+core.models defines it; mode 'eval' swaps the greedy decoder for beam search with
+the reference's defaults (is_greedy=False, beam_width=400: utils/core_utils.py
+:67-72) and renames the metric to beam_search_ler; ``setup_gpu`` selects the visible
+device(s) (:22-35)."""
+import os
+
+import numpy as np
+import yaml
+
+from ..datasets import h5lite
+from . import generic_utils as utils
+
+
+def setup_gpu(gpu, allow_growth=False, log_device_placement=False):
+    """--gpu '0' / '1,2' / 'all' / '-1' (utils/core_utils.py:22-35)."""
+    if gpu == '-1':
+        raise RuntimeError('this build has no CPU path: the hot path runs on the MI355X only')
+    if gpu and gpu != 'all':
+        os.environ.setdefault('HIP_VISIBLE_DEVICES', gpu)
+
+
+def load_meta(model_fname):
+    meta = {}
+    with h5lite.File(model_fname, 'r') as f:
+        g = f['meta']
+        meta['training_args'] = yaml.safe_load(g.attrs['training_args'])
+        for k in g.keys():
+            meta[k] = list(np.asarray(g[k][:]))
+    return meta
+
+
+def load_model(model_fname, return_meta=False, mode='train', **kwargs):
+    if mode not in ('train', 'predict', 'eval'):
+        raise ValueError('mode must be one of (train, predict, eval)')
+    from ..core import optimizers
+    with h5lite.File(model_fname, 'r') as f:
+        g = f['model_weights']
+        cfg = yaml.safe_load(g.attrs['model_config'])
+        shapes = yaml.safe_load(g.attrs['shapes'])
+        flat = g['weights'][:]
+        weights = [np.asarray(a, np.float32).reshape(s) for a, s in zip(flat, shapes)]
+        opt_state = None
+        if 'optimizer' in f:
+            o = f['optimizer']
+            opt_state = (yaml.safe_load(o.attrs['config']), o['state'][:],
+                         int(o.attrs['iterations']))
+    factory = utils.get_from_module('core.models', cfg['name'])
+    model = factory(**cfg.get('kwargs', {}))
+    model.config = cfg
+    model.set_weights(weights)
+    if mode == 'train' and opt_state is not None:
+        oc, state, it = opt_state
+        if oc['class'] == 'Adam':
+            opt = optimizers.Adam(lr=oc['lr'], clipnorm=oc['clipnorm'])
+        else:
+            opt = optimizers.SGD(lr=oc['lr'], momentum=oc['momentum'] or 0.0,
+                                 clipnorm=oc['clipnorm'])
+        model.compile(optimizer=opt)
+        opt.set_state([np.asarray(s, np.float32) for s in state], it)
+    if mode in ('eval', 'predict'):
+        if kwargs.get('decoder', True):
+            model.decoder = dict(is_greedy=kwargs.get('is_greedy', False),
+                                 beam_width=kwargs.get('beam_width', 400),
+                                 merge_repeated=True)
+        model.metrics_names = ['loss', 'ctc_loss', 'beam_search_loss', 'beam_search_ler']
+    if return_meta:
+        return model, load_meta(model_fname)
+    return model

@@ -1,0 +1,79 @@
+"""-m gpu: the reference's command-line surface end to end on a dummy dataset:
+make dataset (GPU MFCC -> HDF5) -> train.py (2 epochs, checkpoints) -> eval.py (beam
+search) ; and BASELINE cfg5: beam-search hypotheses / LER identical to the oracle on
+the held-out split."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dataset(tmp_path, fmt):
+    from asr_study_amd.datasets import h5lite
+    from asr_study_amd.datasets.dummy import Dummy
+    from asr_study_amd.preprocessing import audio, text
+    if fmt == 'h5' and not h5lite.available():
+        fmt = 'npz'
+    ds = Dummy(num_speakers=4, num_utterances_per_speaker=6, max_duration=1.2, min_duration=0.6,
+               max_label_length=8, split=[0.5, 0.25], seed=3)
+    fname = str(tmp_path / ('dummy.' + fmt))
+    ds.to_h5(fname, input_parser=audio.MFCC(dd=False), label_parser=text.simple_char_parser,
+             fmt=fmt)
+    return fname
+
+
+def test_train_eval_cli_roundtrip(tmp_path, capsys):
+    sys.path.insert(0, ROOT)
+    import train
+    import eval as eval_cli
+    fname = _dataset(tmp_path, 'h5')
+    out = str(tmp_path / 'run')
+    train.main(['--dataset', fname, '--model', 'graves2006', '--model_params', 'num_hiddens', '16',
+                'std', '0.0', '--num_epochs', '2', '--batch_size', '4', '--save', out,
+                '--seed', '1', '--lr', '0.01'])
+    assert os.path.exists(os.path.join(out, 'model.h5'))
+    assert os.path.exists(os.path.join(out, 'best.h5'))
+    txt = open(os.path.join(out, 'results.txt')).read()
+    assert 'LER' in txt and 'CTC Loss' in txt
+    m = eval_cli.main(['--model', os.path.join(out, 'best.h5'), '--dataset', fname,
+                       '--beam_width', '20'])
+    assert len(m) == 4 and np.isfinite(m[1]) and m[3] >= 0
+    printed = capsys.readouterr().out
+    assert 'beam_search_ler' in printed
+    # resume: two more epochs continue from the stored epoch count
+    train.main(['--load', os.path.join(out, 'model.h5'), '--dataset', fname, '--num_epochs', '3',
+                '--save', out, '--batch_size', '4'])
+    from asr_study_amd.utils.core_utils import load_meta
+    assert len(load_meta(os.path.join(out, 'model.h5'))['epochs']) == 3
+
+
+def test_cfg5_beam_search_ler_matches_oracle(tmp_path):
+    """Beam width 100 (README) and 400 (code default): identical top-1 strings and
+    LER to the oracle decoder run on the same logits."""
+    from asr_study_amd.core import models
+    from asr_study_amd.datasets.dataset_generator import DatasetGenerator
+    from asr_study_amd.preprocessing import text
+    from oracle import decode as OD
+    fname = _dataset(tmp_path, 'npz')
+    model = models.graves2006(num_features=26, num_hiddens=12, num_classes=28, std=0.0, seed=4)
+    gen = DatasetGenerator(None, text.simple_char_parser, batch_size=6, shuffle=False, seed=0)
+    flow = gen.flow_from_fname(fname, datasets='test')
+    (x, labels, lens), _ = next(flow)
+    slab = model.to_slab(x)
+    logits = model.forward(slab).cpu().numpy()
+    csr = labels.tocsr()
+    truth = [csr.data[csr.indptr[i]:csr.indptr[i + 1]].tolist() for i in range(len(lens))]
+    for width in (100, 400):
+        model.decoder = dict(is_greedy=False, beam_width=width, merge_repeated=True)
+        hyp = model.predict(slab, lens)
+        want = OD.beam_search_decode(logits[:, :len(lens)].astype(np.float64), lens,
+                                     beam_width=width) if width == 100 else None
+        if want is not None:
+            assert hyp == want
+        m = model.test_on_batch([('slab', slab), truth, lens])
+        assert abs(m[3] - OD.ler(hyp, truth)) < 1e-6
