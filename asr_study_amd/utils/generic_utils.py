@@ -78,10 +78,11 @@ def check_ext(fname, ext):
     return os.path.splitext(fname)[1] == ext
 
 
-def parse_nondefault_args(args, default_args):
+def parse_nondefault_args(args, default_args, argv=None):
     """Arguments the user actually passed (differ from the defaults or were named
     on the command line), as HParams (utils/generic_utils.py:105-115)."""
-    named = [a.split('-')[-1] for a in sys.argv if a.startswith('-')]
+    named = [a.split('-')[-1] for a in (sys.argv if argv is None else argv)
+             if a.startswith('-')]
     args_default = {k: v for k, v in vars(default_args).items() if k not in named}
     nondefault = {k: v for k, v in vars(args).items()
                   if k not in args_default or args_default[k] != v}

@@ -32,14 +32,16 @@ def main(argv=None):
     parser.add_argument('--beam_width', default=400, type=int)
     args = parser.parse_args(argv)
     args_nondefault = utils.parse_nondefault_args(
-        args, parser.parse_args(['--model', args.model, '--dataset', args.dataset]))
+        args, parser.parse_args(['--model', args.model, '--dataset', args.dataset]), argv)
 
     from asr_study_amd.datasets.dataset_generator import DatasetGenerator
     from asr_study_amd.utils.core_utils import setup_gpu, load_model
     setup_gpu(args.gpu, args.allow_growth)
     model, meta = load_model(args.model, return_meta=True, mode='eval',
                              beam_width=args.beam_width)
-    args = HParams(**meta['training_args']).update(vars(args_nondefault))
+    # defaults < arguments stored with the checkpoint < arguments given explicitly
+    # (the reference drops un-stored defaults such as --subset here, eval.py:60)
+    args = HParams(**vars(args)).update(meta['training_args']).update(vars(args_nondefault))
     input_parser = utils.get_from_module('preprocessing.audio', args.input_parser,
                                          params=args.input_parser_params)
     label_parser = utils.get_from_module('preprocessing.text', args.label_parser,

@@ -65,9 +65,9 @@ def main(argv=None):
 
     epoch_offset, meta = 0, None
     if args.load:
-        args_nondefault = utils.parse_nondefault_args(args, parser.parse_args([]))
+        args_nondefault = utils.parse_nondefault_args(args, parser.parse_args([]), argv)
         model, meta = load_model(args.load, return_meta=True)
-        args = HParams(**meta['training_args']).update(vars(args_nondefault))
+        args = HParams(**vars(args)).update(meta['training_args']).update(vars(args_nondefault))
         epoch_offset = len(meta['epochs'])
         if args_nondefault.lr:
             model.optimizer.lr = args.lr
