@@ -308,7 +308,7 @@ class Model(object):
         T, n_pad, _ = dlogits.shape
         rows = T * n_pad
         da = dlogits
-        split = max(1, min(32, rows // 2048))
+        split = 'auto'
         for si in range(len(self.stages) - 1, -1, -1):
             s = self.stages[si]
             rec = self._acts[si]

@@ -22,7 +22,7 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BM = 128, BN = 128, BK = 16, PAD = 4;
+constexpr int BM = 128, BN = 128, PAD = 4;
 constexpr int LDS_LD = BM + PAD;   // BM == BN
 
 struct TileSrc {
@@ -35,12 +35,13 @@ struct TileSrc {
   int vec_ok;          // 16-byte aligned rows
 };
 
-// Loads the (BK x 128) tile starting at (k0, mn0) into 2 float4 registers.
+// Loads the (BK x 128) tile starting at (k0, mn0) into BK/8 float4 registers.
+template <int BK>
 __device__ __forceinline__ void tile_load(const TileSrc& s, int k0, int mn0, int k_end,
-                                          float4 (&r)[2]) {
+                                          float4 (&r)[BK / 8]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < BK / 8; ++it) {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (s.mn_contig) {
       const int kk = (tid >> 5) + 8 * it;
@@ -62,8 +63,11 @@ __device__ __forceinline__ void tile_load(const TileSrc& s, int k0, int mn0, int
         }
       }
     } else {
-      const int mn = mn0 + (tid >> 2) + 64 * it;
-      const int k = k0 + 4 * (tid & 3);
+      // BK/4 float4 per row; thread -> (row, k-quad)
+      constexpr int QPR = BK / 4;                 // k-quads per row
+      const int e = tid + 256 * it;
+      const int mn = mn0 + e / QPR;
+      const int k = k0 + 4 * (e % QPR);
       if (mn < s.mn_total) {
         const float* src = s.p + (size_t)mn * s.ld + k;
         if (s.vec_ok && k + 3 < k_end) {
@@ -84,17 +88,20 @@ __device__ __forceinline__ void tile_load(const TileSrc& s, int k0, int mn0, int
   }
 }
 
-__device__ __forceinline__ void tile_store(int mn_contig, const float4 (&r)[2],
+template <int BK>
+__device__ __forceinline__ void tile_store(int mn_contig, const float4 (&r)[BK / 8],
                                            float (*S)[LDS_LD]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < BK / 8; ++it) {
     if (mn_contig) {
       const int kk = (tid >> 5) + 8 * it;
       *reinterpret_cast<float4*>(&S[kk][4 * (tid & 31)]) = r[it];
     } else {
-      const int mn = (tid >> 2) + 64 * it;
-      const int kb = 4 * (tid & 3);
+      constexpr int QPR = BK / 4;
+      const int e = tid + 256 * it;
+      const int mn = e / QPR;
+      const int kb = 4 * (e % QPR);
       S[kb + 0][mn] = r[it].x;
       S[kb + 1][mn] = r[it].y;
       S[kb + 2][mn] = r[it].z;
@@ -111,6 +118,7 @@ struct Epilogue {
   float* partial;      // split-K: raw accumulators go here ([split][M][N])
 };
 
+template <int BK>
 __global__ void __launch_bounds__(256)
 gemm_f32_mfma_kernel(TileSrc A, TileSrc B, int M, int N, int K, int k_per_split,
                      Epilogue ep) {
@@ -133,21 +141,21 @@ gemm_f32_mfma_kernel(TileSrc A, TileSrc B, int M, int N, int K, int k_per_split,
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[2], rb[2];
+  float4 ra[BK / 8], rb[BK / 8];
   const int nk = (k_end - k_begin + BK - 1) / BK;
   if (nk > 0) {
-    tile_load(A, k_begin, m0, k_end, ra);
-    tile_load(B, k_begin, n0, k_end, rb);
-    tile_store(A.mn_contig, ra, As[0]);
-    tile_store(B.mn_contig, rb, Bs[0]);
+    tile_load<BK>(A, k_begin, m0, k_end, ra);
+    tile_load<BK>(B, k_begin, n0, k_end, rb);
+    tile_store<BK>(A.mn_contig, ra, As[0]);
+    tile_store<BK>(B.mn_contig, rb, Bs[0]);
   }
   __syncthreads();
   const int lrow = lane >> 5, lcol = lane & 31;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      tile_load(A, k_begin + (kt + 1) * BK, m0, k_end, ra);
-      tile_load(B, k_begin + (kt + 1) * BK, n0, k_end, rb);
+      tile_load<BK>(A, k_begin + (kt + 1) * BK, m0, k_end, ra);
+      tile_load<BK>(B, k_begin + (kt + 1) * BK, n0, k_end, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
@@ -163,8 +171,8 @@ gemm_f32_mfma_kernel(TileSrc A, TileSrc B, int M, int N, int K, int k_per_split,
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      tile_store(A.mn_contig, ra, As[cur ^ 1]);
-      tile_store(B.mn_contig, rb, Bs[cur ^ 1]);
+      tile_store<BK>(A.mn_contig, ra, As[cur ^ 1]);
+      tile_store<BK>(B.mn_contig, rb, Bs[cur ^ 1]);
     }
     __syncthreads();
   }
@@ -286,6 +294,8 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
   ASR_CHECK_ARG(a->lda >= (a->trans_a ? a->M : a->K), "gemm: lda too small");
   ASR_CHECK_ARG(a->ldb >= (a->trans_b ? a->K : a->N), "gemm: ldb too small");
   ASR_CHECK_ARG(a->ldc >= a->N, "gemm: ldc too small");
+  static const int bk_env = [] { const char* v = getenv("ASR_GEMM_BK"); return v ? atoi(v) : 16; }();
+  const int BK = bk_env == 16 ? 16 : 32;
   int splits = a->split_k > 1 ? a->split_k : 1;
   int k_per_split = (a->K + splits - 1) / splits;
   k_per_split = (k_per_split + BK - 1) / BK * BK;
@@ -305,8 +315,12 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
     ep.partial = reinterpret_cast<float*>(workspace);
   }
   dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, splits);
-  hipLaunchKernelGGL(gemm_f32_mfma_kernel, grid, dim3(256), 0, stream, A, B, a->M, a->N,
-                     a->K, k_per_split, ep);
+  if (BK == 16)
+    hipLaunchKernelGGL(gemm_f32_mfma_kernel<16>, grid, dim3(256), 0, stream, A, B, a->M, a->N,
+                       a->K, k_per_split, ep);
+  else
+    hipLaunchKernelGGL(gemm_f32_mfma_kernel<32>, grid, dim3(256), 0, stream, A, B, a->M, a->N,
+                       a->K, k_per_split, ep);
   ASR_CHECK_LAUNCH();
   if (splits > 1) {
     Epilogue ep2 = ep;

@@ -75,6 +75,10 @@ def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ld
     a.c_scale = c_scale.data_ptr() if c_scale is not None else None
     a.c_scale_period = int(c_scale_period)
     a.c_scale_ld = int(c_scale.shape[-1]) if c_scale is not None else 0
+    if split_k == 'auto':
+        # long-K / small-output GEMMs (dW, dU): split K until ~1024 workgroups exist
+        tiles = ((int(M) + 127) // 128) * ((int(N) + 127) // 128)
+        split_k = max(1, min(64, (1024 + tiles - 1) // tiles, int(K) // 256))
     a.split_k = int(split_k)
     nbytes = lib.asr_gemm_workspace_bytes(C.byref(a))
     ws = WS.get('gemm', nbytes, Cm.device) if nbytes else None

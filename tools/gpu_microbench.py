@@ -88,9 +88,14 @@ def main():
     t = timeit(lambda: ops.gemm(z2, W, dx, rows, 2 * H, 8 * H, trans_b=True))
     print('gemm dX   %dx%dx%d: %.3f ms  %.1f TF/s' % (rows, 2 * H, 8 * H, t, 2.0 * rows * 8 * H * 2 * H / t / 1e9))
     dW = torch.empty(2 * H, 8 * H, device=dev)
-    for sk in (8, 16, 32):
+    for sk in (16, 32, 'auto'):
         t = timeit(lambda: ops.gemm(x, z2, dW, 2 * H, 8 * H, rows, trans_a=True, split_k=sk))
-        print('gemm dW   %dx%dx%d sk=%d: %.3f ms  %.1f TF/s' % (2 * H, 8 * H, rows, sk, t, 2.0 * rows * 8 * H * 2 * H / t / 1e9))
+        print('gemm dW   %dx%dx%d sk=%s: %.3f ms  %.1f TF/s' % (2 * H, 8 * H, rows, sk, t, 2.0 * rows * 8 * H * 2 * H / t / 1e9))
+    dU = torch.empty(H, 4 * H, device=dev)
+    yb = rnd(rows, 2 * H)
+    t = timeit(lambda: ops.gemm(yb, z2, dU, H, 4 * H, rows - n_pad, trans_a=True, lda=2 * H,
+                                ldb=8 * H, ldc=4 * H, b_off=n_pad * 8 * H, split_k='auto'))
+    print('gemm dU   %dx%dx%d auto: %.3f ms  %.1f TF/s' % (H, 4 * H, rows, t, 2.0 * rows * 4 * H * H / t / 1e9))
     db = torch.empty(8 * H, device=dev)
     t = timeit(lambda: ops.colsum(z2, rows, 8 * H, 8 * H, db))
     print('colsum    %dx%d: %.3f ms  %.1f GB/s' % (rows, 8 * H, t, rows * 8 * H * 4 / t / 1e6))
