@@ -103,6 +103,19 @@ __device__ __forceinline__ void xstore(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, uns
   __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, byte_off, 0, FAST ? 0 : kSc1);
 }
 
+// ---- split-fp16 arithmetic for the recurrent products ------------------------
+// x = hi + lo/2048 with hi = fp16(x), lo = fp16((x - hi) * 2048): 22 mantissa bits.
+// x*y ~= hi_x*hi_y + (hi_x*lo_y + lo_x*hi_y)/2048 (the lo*lo term is 2^-22 relative),
+// three v_mfma_f32_16x16x32_f16 (fp32 accumulate) instead of eight fp32 MFMAs.
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
+constexpr float kLoScale = 2048.f;
+
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * kLoScale);
+}
+
 // Loads NL 16-byte groups (byte offsets off[i]) and re-polls the stale ones until
 // every word carries `tag`.
 template <bool FAST, int NL>
@@ -346,6 +359,179 @@ lstm_fwd_kernel(LstmParams p) {
   else fwd_body<MAXR, false>(p, chain, wg, lds);
 }
 
+
+// forward, split-fp16 MFMA variant.  NKK = number of K=32 MFMA steps (H <= 32*NKK).
+template <int NKK, bool FAST>
+__device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int wg, float* lds) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, nl = lane & 15;
+  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
+  const int UG = H >> 2;
+  const int dir = chain / p.NB, bt = chain % p.NB;
+  const int ug = wg * 4 + w;
+  const bool ug_ok = ug < UG;
+  const int n = bt * 16 + nl;
+  const int u = 4 * ug + g;
+  constexpr int KP = 32 * NKK;                    // padded K
+  constexpr int HS = KP + 8;                      // LDS row stride (halfs)
+  _Float16* hb = reinterpret_cast<_Float16*>(lds);   // [2 slots][hi|lo][16][HS]
+  constexpr int tile_halfs = 16 * HS;
+
+  // stationary A fragments: column i = lane&15 of the gate tile, k = 32kk + 8g + e
+  h8 ufh[NKK], ufl[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * kk + 8 * g + e;
+      const float x = (ug_ok && k < H) ? p.U[((size_t)(dir * H + k)) * H4 + 16 * ug + nl] : 0.f;
+      _Float16 hi, lo;
+      split_f16(x, hi, lo);
+      ufh[kk][e] = hi; ufl[kk][e] = lo;
+    }
+  }
+  float mask = 1.f;
+  if (ug_ok && p.mask_u) mask = p.mask_u[((size_t)dir * p.n_pad + n) * H + u];
+  float c = 0.f;
+  bool dead = false;
+  unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;    // [2][UG][16][4]
+  const int slot_words = 16 * H;
+  const int s_end = p.s_begin + p.s_count;
+  if (ug_ok && p.s_begin > 0) {
+    const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
+    c = p.cell[(((size_t)tpp * p.n_pad + n) * 2 + dir) * H + u];
+  }
+  for (int e = tid; e < 4 * tile_halfs; e += kThreads) hb[e] = (_Float16)0.f;
+  __syncthreads();
+  auto load_zx = [&](int ss) -> float4 {
+    if (!ug_ok || ss >= s_end) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int tt = dir == 0 ? ss : p.T - 1 - ss;
+    return *reinterpret_cast<const float4*>(
+        p.zx + (((size_t)tt * p.n_pad + n) * 2 + dir) * H4 + 4 * u);
+  };
+  float4 zx_next = load_zx(p.s_begin);
+  constexpr int NL = (KP * 4 + kThreads - 1) / kThreads;       // 16-B groups per thread
+  const bool prof = (p.dbg & 32) && wg == 0 && chain == p.chain_begin && lane == 0;
+  long long pt[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+  for (int s = p.s_begin; s < s_end; ++s) {
+    if (prof) tk0 = wall_clock64();
+    const int t = dir == 0 ? s : p.T - 1 - s;
+    const float4 zx4 = zx_next;
+    f32x4 am0 = {0.f, 0.f, 0.f, 0.f}, am1 = am0, ac0 = am0, ac1 = am0;
+    if (s > 0) {
+      _Float16* th = hb + (size_t)(s & 1) * 2 * tile_halfs;      // hi tile, lo tile follows
+      _Float16* tl = th + tile_halfs;
+      const unsigned tag = (unsigned)((s - 1 - p.s_begin) >> 1) & 1u;
+      __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          xch + (size_t)((s - 1) & 1) * slot_words, 0, slot_words * 4, 0x00020000);
+      unsigned off[NL];
+      bool use[NL];
+      u32x4 v[NL];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int grp = tid + i * kThreads;
+        use[i] = grp < UG * 16;
+        off[i] = (unsigned)grp * 16u;
+      }
+      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64);
+      if (prof) tk1 = wall_clock64();
+      zx_next = load_zx(s + 1);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if (use[i]) {
+          const int grp = tid + i * kThreads;
+          const int gu = grp >> 4, gn = grp & 15;
+          h4 hi4, lo4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            _Float16 a, b;
+            split_f16(__uint_as_float(v[i][e] & ~1u), a, b);
+            hi4[e] = a; lo4[e] = b;
+          }
+          *reinterpret_cast<h4*>(th + gn * HS + 4 * gu) = hi4;
+          *reinterpret_cast<h4*>(tl + gn * HS + 4 * gu) = lo4;
+        }
+      }
+      __syncthreads();
+      if (prof) tk2 = wall_clock64();
+      if (ug_ok) {
+        const _Float16* rh = th + nl * HS + 8 * g;
+        const _Float16* rl = tl + nl * HS + 8 * g;
+        h8 bh[NKK], bl[NKK];
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+          bh[kk] = *reinterpret_cast<const h8*>(rh + 32 * kk);
+          bl[kk] = *reinterpret_cast<const h8*>(rl + 32 * kk);
+        }
+#pragma unroll
+        for (int kk = 0; kk < NKK; kk += 2) {
+          am0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[kk], bh[kk], am0, 0, 0, 0);
+          ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[kk], bl[kk], ac0, 0, 0, 0);
+          ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[kk], bh[kk], ac1, 0, 0, 0);
+          if (kk + 1 < NKK) {
+            am1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[kk + 1], bh[kk + 1], am1, 0, 0, 0);
+            ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[kk + 1], bl[kk + 1], ac0, 0, 0, 0);
+            ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[kk + 1], bh[kk + 1], ac1, 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      zx_next = load_zx(s + 1);
+    }
+    const f32x4 a = (am0 + am1) + (ac0 + ac1) * (1.f / kLoScale);
+    if (prof) { asm volatile("" :: "v"(a[0])); tk3 = wall_clock64(); }
+    if (ug_ok) {
+      const float gi = hard_sigmoid(a[0] + zx4.x);
+      const float gf = hard_sigmoid(a[1] + zx4.y);
+      const float gg = fast_tanh(a[2] + zx4.z);
+      const float go = hard_sigmoid(a[3] + zx4.w);
+      c = gf * c + gi * gg;
+      const float h = go * fast_tanh(c);
+      if (s + 1 < p.T) {
+        const unsigned wtag = (unsigned)((s - p.s_begin) >> 1) & 1u;
+        const unsigned w0 = tag_word(h * mask, wtag);
+        u32x4 o;
+        o[0] = w0;
+        o[1] = (unsigned)__shfl_down((int)w0, 16, 64);
+        o[2] = (unsigned)__shfl_down((int)w0, 32, 64);
+        o[3] = (unsigned)__shfl_down((int)w0, 48, 64);
+        if (lane < 16) {
+          __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+              xch + (size_t)(s & 1) * slot_words, 0, slot_words * 4, 0x00020000);
+          xstore<FAST>(o, wr, (unsigned)(ug * 16 + nl) * 16u);
+        }
+      }
+      const size_t row = (size_t)t * p.n_pad + n;
+      p.y[row * H2 + dir * H + u] = h;
+      p.cell[(row * 2 + dir) * H + u] = c;
+      *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
+          make_float4(gi, gf, gg, go);
+    }
+    if (prof && s > 0) {
+      const long long tk4 = wall_clock64();
+      pt[0] += tk1 - tk0; pt[1] += tk2 - tk1; pt[2] += tk3 - tk2; pt[3] += tk4 - tk3;
+    }
+  }
+  if (prof) {
+    long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
+    for (int i = 0; i < 4; ++i) out[i] = pt[i];
+  }
+}
+
+template <int NKK>
+__global__ void __launch_bounds__(kThreads)
+lstm_fwd_kernel_h(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int chain_local, wg;
+  if (!map_block(p, chain_local, wg)) return;
+  const int chain = p.chain_begin + chain_local;
+  const bool fast = chain_on_one_xcd(p, chain, wg, reinterpret_cast<int*>(lds));
+  if (fast) fwd_body_h<NKK, true>(p, chain, wg, lds);
+  else fwd_body_h<NKK, false>(p, chain, wg, lds);
+}
+
 // ---------------------------------------------------------------------------
 // backward (BPTT).  WG `cw` of a chain owns units [16 cw, 16 cw + 16) = gate
 // columns j in [64 cw, 64 cw + 64).  TPW = output tiles (16 units) per wave.
@@ -533,9 +719,207 @@ lstm_bwd_kernel(LstmParams p) {
   else bwd_body<TPW, false>(p, chain, cw, lds);
 }
 
+
+// backward, split-fp16 MFMA variant.  The gate gradients dz span many orders of
+// magnitude, so each batch column n is scaled by its own power of two (max |dz|
+// over the WG's 64 columns -> [2^8, 2^9)) before the fp16 split and the partial
+// sums are unscaled exactly afterwards.
+template <int TPW, bool FAST>
+__device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int cw, float* lds) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, nl = lane & 15;
+  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
+  const int P = p.P;
+  const int dir = chain / p.NB, bt = chain % p.NB;
+  constexpr int DZH = 72;                         // LDS row stride of the dz tiles (halfs)
+  float* part = lds;                              // [P][256] gathered partial dh
+  float* sinv = lds + (size_t)P * 256;            // [16] 1/scale per batch column
+  _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZH] hi
+  _Float16* dzl = dzh + 16 * DZH;                           // [16][DZH] lo
+
+  h8 ufh[TPW][2], ufl[TPW][2];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int mt = w + 4 * i;
+    const int krow = 16 * mt + nl;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 64 * cw + 32 * kk + 8 * g + e;
+        const float x = (mt < P && krow < H && j < H4)
+                            ? p.U[((size_t)(dir * H + krow)) * H4 + j] : 0.f;
+        _Float16 hi, lo;
+        split_f16(x, hi, lo);
+        ufh[i][kk][e] = hi; ufl[i][kk][e] = lo;
+      }
+    }
+  }
+  const int cn = bt * 16 + (tid >> 4);
+  const int cu = 16 * cw + (tid & 15);
+  const bool cvalid = cu < H;
+  float cmask = 1.f;
+  if (cvalid && p.mask_u) cmask = p.mask_u[((size_t)dir * p.n_pad + cn) * H + cu];
+  float dc = 0.f;
+  if (cvalid && p.s_begin > 0) dc = p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu];
+  bool dead = false;
+  unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;
+  const size_t slot_words = (size_t)P * P * 256;
+  const int s_end = p.s_begin + p.s_count;
+  constexpr int NL = TPW;
+  const bool prof = (p.dbg & 32) && cw == 0 && chain == p.chain_begin && lane == 0;
+  long long pt[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+
+  float nx_dy = 0.f, nx_c = 0.f, nx_cp = 0.f;
+  float4 nx_g = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_slabs = [&](int ss) {
+    nx_dy = 0.f; nx_c = 0.f; nx_cp = 0.f; nx_g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!cvalid || ss >= s_end) return;
+    const int tt = dir == 0 ? p.T - 1 - ss : ss;
+    const int tcc = dir == 0 ? tt - 1 : tt + 1;
+    const size_t row = (size_t)tt * p.n_pad + cn;
+    nx_dy = p.dy[row * H2 + dir * H + cu];
+    nx_c = p.cell[(row * 2 + dir) * H + cu];
+    if (ss + 1 < p.T) nx_cp = p.cell[(((size_t)tcc * p.n_pad + cn) * 2 + dir) * H + cu];
+    nx_g = *reinterpret_cast<const float4*>(p.gates + (row * 2 + dir) * H4 + 4 * cu);
+  };
+  load_slabs(p.s_begin);
+
+  for (int s = p.s_begin; s < s_end; ++s) {
+    if (prof) tk0 = wall_clock64();
+    const int t = dir == 0 ? p.T - 1 - s : s;
+    const float dyv = nx_dy, cv = nx_c, cpv = nx_cp;
+    const float4 gt = nx_g;
+    float dh_rec = 0.f;
+    if (s > 0) {
+      const unsigned tag = (unsigned)((s - 1 - p.s_begin) >> 1) & 1u;
+      __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          xch + (size_t)((s - 1) & 1) * slot_words + (size_t)cw * P * 256, 0, P * 256 * 4,
+          0x00020000);
+      unsigned off[NL];
+      bool use[NL];
+      u32x4 v[NL];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int grp = tid + i * kThreads;
+        use[i] = grp < P * 64;
+        off[i] = (unsigned)grp * 16u;
+      }
+      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64);
+      if (prof) tk1 = wall_clock64();
+      load_slabs(s + 1);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if (use[i]) {
+          *reinterpret_cast<float4*>(part + 4 * (tid + i * kThreads)) =
+              make_float4(__uint_as_float(v[i][0] & ~1u), __uint_as_float(v[i][1] & ~1u),
+                          __uint_as_float(v[i][2] & ~1u), __uint_as_float(v[i][3] & ~1u));
+        }
+      }
+      __syncthreads();
+      if (prof) tk2 = wall_clock64();
+      for (int pr = 0; pr < P; ++pr) dh_rec += part[pr * 256 + tid];
+    } else {
+      load_slabs(s + 1);
+    }
+    {
+      float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cvalid) {
+        const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
+        const float dh = dyv + cmask * dh_rec;
+        const float tch = fast_tanh(cv);
+        const float d_o = dh * tch;
+        const float dcc = dc + dh * go * (1.f - tch * tch);
+        const float d_i = dcc * gg, d_g = dcc * gi, d_f = dcc * cpv;
+        dc = dcc * gf;
+        z4.x = d_i * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
+        z4.y = d_f * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
+        z4.z = d_g * (1.f - gg * gg);
+        z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
+        *reinterpret_cast<float4*>(p.dz + (((size_t)t * p.n_pad + cn) * 2 + dir) * H4 + 4 * cu) = z4;
+      }
+      // power-of-two scale of this batch column: max over its 16 threads (one DPP row)
+      float m = fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w)));
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+      int ex = 0;
+      if (m > 0.f) (void)frexpf(m, &ex); else ex = 9;
+      ex = ex < -100 ? -100 : ex;                 // keep 2^(9-ex) finite for denormal maxima
+      const float sc = ldexpf(1.f, 9 - ex);
+      if ((tid & 15) == 0) sinv[tid >> 4] = ldexpf(1.f, ex - 9);
+      h4 hi4, lo4;
+      {
+        _Float16 a, b;
+        split_f16(z4.x * sc, a, b); hi4[0] = a; lo4[0] = b;
+        split_f16(z4.y * sc, a, b); hi4[1] = a; lo4[1] = b;
+        split_f16(z4.z * sc, a, b); hi4[2] = a; lo4[2] = b;
+        split_f16(z4.w * sc, a, b); hi4[3] = a; lo4[3] = b;
+      }
+      *reinterpret_cast<h4*>(dzh + (tid >> 4) * DZH + 4 * (tid & 15)) = hi4;
+      *reinterpret_cast<h4*>(dzl + (tid >> 4) * DZH + 4 * (tid & 15)) = lo4;
+    }
+    __syncthreads();
+    if (prof) tk3 = wall_clock64();
+    if (s + 1 < p.T) {
+      h8 bh[2], bl[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bh[kk] = *reinterpret_cast<const h8*>(dzh + nl * DZH + 32 * kk + 8 * g);
+        bl[kk] = *reinterpret_cast<const h8*>(dzl + nl * DZH + 32 * kk + 8 * g);
+      }
+      const float us = sinv[nl];
+      const unsigned wtag = (unsigned)((s - p.s_begin) >> 1) & 1u;
+      __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+          xch + (size_t)(s & 1) * slot_words, 0, (unsigned)(slot_words * 4), 0x00020000);
+      u32x4 o[TPW];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int mt = w + 4 * i;
+        f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac0 = am, ac1 = am;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[i][kk], bh[kk], am, 0, 0, 0);
+          ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[i][kk], bl[kk], ac0, 0, 0, 0);
+          ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[i][kk], bh[kk], ac1, 0, 0, 0);
+        }
+        const f32x4 a = (am + (ac0 + ac1) * (1.f / kLoScale)) * us;
+        o[i][0] = tag_word(a[0], wtag); o[i][1] = tag_word(a[1], wtag);
+        o[i][2] = tag_word(a[2], wtag); o[i][3] = tag_word(a[3], wtag);
+        const unsigned off = mt < P
+            ? (unsigned)((((size_t)mt * P + cw) * 256 + nl * 16 + 4 * g) * 4)
+            : 0xFFFFFFF0u;
+        xstore<FAST>(o[i], wr, off);
+      }
+    }
+    if (prof && s > 0) {
+      const long long tk4 = wall_clock64();
+      pt[0] += tk1 - tk0; pt[1] += tk2 - tk1; pt[2] += tk3 - tk2; pt[3] += tk4 - tk3;
+    }
+  }
+  if (prof) {
+    long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
+    for (int i = 0; i < 4; ++i) out[i] = pt[i];
+  }
+  if (cvalid && p.dc_state) p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu] = dc;
+}
+
+template <int TPW>
+__global__ void __launch_bounds__(kThreads)
+lstm_bwd_kernel_h(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int chain_local, cw;
+  if (!map_block(p, chain_local, cw)) return;
+  const int chain = p.chain_begin + chain_local;
+  const bool fast = chain_on_one_xcd(p, chain, cw, reinterpret_cast<int*>(lds));
+  if (fast) bwd_body_h<TPW, true>(p, chain, cw, lds);
+  else bwd_body_h<TPW, false>(p, chain, cw, lds);
+}
+
 // ---------------------------------------------------------------------------
 struct Plan {
-  int R, P, TPW, MAXR;
+  int R, P, TPW, MAXR, NKK, prec;
   size_t shm;
   size_t xchain_words;
   int chains_per_launch;
@@ -550,6 +934,21 @@ kern_t pick_fwd(int maxr) {
     case 32: return lstm_fwd_kernel<32>;
     case 64: return lstm_fwd_kernel<64>;
     default: return lstm_fwd_kernel<128>;
+  }
+}
+kern_t pick_fwd_h(int nkk) {
+  switch (nkk) {
+    case 4: return lstm_fwd_kernel_h<4>;
+    case 8: return lstm_fwd_kernel_h<8>;
+    default: return lstm_fwd_kernel_h<16>;
+  }
+}
+kern_t pick_bwd_h(int tpw) {
+  switch (tpw) {
+    case 1: return lstm_bwd_kernel_h<1>;
+    case 2: return lstm_bwd_kernel_h<2>;
+    case 4: return lstm_bwd_kernel_h<4>;
+    default: return lstm_bwd_kernel_h<8>;
   }
 }
 kern_t pick_bwd(int tpw) {
@@ -577,6 +976,10 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   Plan pl;
   kern_t k;
   pl.P = (H + 15) / 16;
+  // recurrent-product arithmetic: 1 = split-fp16 MFMA (22-bit mantissa, default),
+  // 0 = exact fp32 MFMA
+  pl.prec = env_int("ASR_LSTM_PREC", 1) ? 1 : 0;
+  pl.NKK = 0;
   if (!bwd) {
     pl.R = up4((H + 3) / 4);
     if (pl.R > 128) {
@@ -588,6 +991,12 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     pl.shm = (size_t)2 * 16 * (4 * pl.R + 4) * 4;
     pl.xchain_words = (size_t)2 * 16 * H;
     k = pick_fwd(pl.MAXR);
+    if (pl.prec == 1) {
+      const int nkk = (H + 31) / 32;
+      pl.NKK = nkk <= 4 ? 4 : nkk <= 8 ? 8 : 16;
+      pl.shm = (size_t)4 * 16 * (32 * pl.NKK + 8) * 2;
+      k = pick_fwd_h(pl.NKK);
+    }
   } else {
     pl.R = 16; pl.MAXR = 0;
     const int tpw = (pl.P + 3) / 4;
@@ -599,6 +1008,10 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     pl.shm = (size_t)(16 * 68 + pl.P * 256) * 4;
     pl.xchain_words = (size_t)2 * pl.P * pl.P * 256;
     k = pick_bwd(pl.TPW);
+    if (pl.prec == 1) {
+      pl.shm = (size_t)(pl.P * 256 + 16) * 4 + (size_t)2 * 16 * 72 * 2;
+      k = pick_bwd_h(pl.TPW);
+    }
   }
   if (pl.shm < (size_t)pl.P * 4 + 16) pl.shm = (size_t)pl.P * 4 + 16;
   if (pl.shm > 64 * 1024) {
