@@ -63,6 +63,11 @@ class Model(object):
         self.stop_training = False
         self._bufs = {}
         self._step = 0
+        # weight-gradient GEMMs run on a side stream, concurrently with the next
+        # layer's persistent BPTT kernel (which occupies only H/16 x chains CUs)
+        import os as _os
+        self.overlap = _os.environ.get('ASR_OVERLAP', '1') != '0'
+        self._side = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         self._rng = torch.Generator(device=self.device)
         self._rng.manual_seed(int(seed) + 12345)
         self._layout(seed)
@@ -309,6 +314,22 @@ class Model(object):
         rows = T * n_pad
         da = dlogits
         split = 'auto'
+        pending = []
+        if not hasattr(self, '_dz_free'):
+            self._dz_free = [None, None]
+
+        def flush_side():
+            # enqueue deferred weight-gradient work on the side stream (called right
+            # AFTER the next layer's BPTT kernel has been launched on the main stream)
+            while pending:
+                fn, ready, par = pending.pop(0)
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ready)
+                    fn('gemm_side')
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    self._dz_free[par] = ev
+
         for si in range(len(self.stages) - 1, -1, -1):
             s = self.stages[si]
             rec = self._acts[si]
@@ -332,36 +353,53 @@ class Model(object):
             elif s.kind == 'bilstm':
                 Hp = s.Hp
                 BW, BU = rec['BW'], rec['BU']
-                dz = self._buf('dz', (T, n_pad, 2, 4 * Hp))
+                # two dz buffers alternate so that the side stream may still read layer
+                # l's dz while layer l-1's BPTT writes the other one
+                par = self._dz_parity = 1 - getattr(self, '_dz_parity', 0)
+                dz = self._buf('dz%d' % par, (T, n_pad, 2, 4 * Hp))
+                main = torch.cuda.current_stream(self.device)
+                if self.overlap and self._dz_free[par] is not None:
+                    main.wait_event(self._dz_free[par])
                 U = self._view(s.oU, 2 * Hp * 4 * Hp)
                 rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp,
                                                mask_u=BU, mode=self.lstm_mode)
+                flush_side()        # previous layer's dW/dU/db now overlap this BPTT
                 y = rec['y']
-                # dU[d] = (h_prev (.) B_U)^T dz[d]: h_prev is y shifted by one step in the
-                # direction's processing order (zero at its first step)
-                kk = (T - 1) * n_pad
-                for d in range(2):
-                    a_off = d * Hp + (0 if d == 0 else n_pad * 2 * Hp)
-                    b_off = d * 4 * Hp + (n_pad * 8 * Hp if d == 0 else 0)
-                    if kk > 0:
-                        ops.gemm(y, dz, self.grads, Hp, 4 * Hp, kk, trans_a=True, lda=2 * Hp,
-                                 ldb=8 * Hp, ldc=4 * Hp, a_off=a_off, b_off=b_off,
-                                 c_off=s.oU + d * Hp * 4 * Hp, split_k=split,
-                                 a_scale=None if BU is None else BU[d],
-                                 a_scale_period=n_pad)
-                    else:
-                        self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
-                # dW = (x (.) B_W)^T dz, db = colsum(dz)
-                if BW is None:
-                    ops.gemm(a_in, dz, self.grads, s.f_in_pad, 8 * Hp, rows, trans_a=True,
-                             c_off=s.oW, split_k=split)
-                else:
+
+                def weight_grads(wsn, s=s, dz=dz, y=y, a_in=a_in, BW=BW, BU=BU, Hp=Hp):
+                    # dU[d] = (h_prev (.) B_U)^T dz[d]: h_prev is y shifted by one step in
+                    # the direction's processing order (zero at its first step)
+                    kk = (T - 1) * n_pad
                     for d in range(2):
-                        ops.gemm(a_in, dz, self.grads, s.f_in_pad, 4 * Hp, rows, trans_a=True,
-                                 ldb=8 * Hp, ldc=8 * Hp, b_off=d * 4 * Hp,
-                                 c_off=s.oW + d * 4 * Hp, split_k=split, a_scale=BW[d],
-                                 a_scale_period=n_pad)
-                ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp))
+                        a_off = d * Hp + (0 if d == 0 else n_pad * 2 * Hp)
+                        b_off = d * 4 * Hp + (n_pad * 8 * Hp if d == 0 else 0)
+                        if kk > 0:
+                            ops.gemm(y, dz, self.grads, Hp, 4 * Hp, kk, trans_a=True, lda=2 * Hp,
+                                     ldb=8 * Hp, ldc=4 * Hp, a_off=a_off, b_off=b_off,
+                                     c_off=s.oU + d * Hp * 4 * Hp, split_k=split,
+                                     a_scale=None if BU is None else BU[d],
+                                     a_scale_period=n_pad, ws_name=wsn)
+                        else:
+                            self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
+                    # dW = (x (.) B_W)^T dz, db = colsum(dz)
+                    if BW is None:
+                        ops.gemm(a_in, dz, self.grads, s.f_in_pad, 8 * Hp, rows, trans_a=True,
+                                 c_off=s.oW, split_k=split, ws_name=wsn)
+                    else:
+                        for d in range(2):
+                            ops.gemm(a_in, dz, self.grads, s.f_in_pad, 4 * Hp, rows, trans_a=True,
+                                     ldb=8 * Hp, ldc=8 * Hp, b_off=d * 4 * Hp,
+                                     c_off=s.oW + d * 4 * Hp, split_k=split, a_scale=BW[d],
+                                     a_scale_period=n_pad, ws_name=wsn)
+                    ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp),
+                               ws_name=wsn + '_cs')
+
+                if self.overlap:
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    pending.append((weight_grads, ready, par))
+                else:
+                    weight_grads('gemm')
                 if not first:
                     dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
                     if BW is None:
@@ -374,6 +412,9 @@ class Model(object):
                                      b_off=s.oW + d * 4 * Hp, beta=0.0 if d == 0 else 1.0,
                                      c_scale=BW[d], c_scale_period=n_pad)
                     da = dx
+        flush_side()
+        if self.overlap and self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
         return da
 
     # ------------------------------------------------------------------ batches

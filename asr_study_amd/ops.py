@@ -52,7 +52,7 @@ def pad16(n):
 # --------------------------------------------------------------------------- GEMM
 def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None,
          alpha=1.0, beta=0.0, bias=None, a_scale=None, a_scale_period=0, c_scale=None,
-         c_scale_period=0, split_k=0, a_off=0, b_off=0, c_off=0):
+         c_scale_period=0, split_k=0, a_off=0, b_off=0, c_off=0, ws_name='gemm'):
     """C[M,N] = alpha * opA(A) @ opB(B) + beta*C (+bias), see include/asr_hip.h.
 
     A/B/Cm are float32 CUDA tensors used as raw storage; *_off are element
@@ -81,14 +81,14 @@ def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ld
         split_k = max(1, min(64, (1024 + tiles - 1) // tiles, int(K) // 256))
     a.split_k = int(split_k)
     nbytes = lib.asr_gemm_workspace_bytes(C.byref(a))
-    ws = WS.get('gemm', nbytes, Cm.device) if nbytes else None
+    ws = WS.get(ws_name, nbytes, Cm.device) if nbytes else None
     L.check(lib.asr_gemm(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_gemm')
 
 
-def colsum(X, M, N, ldx, out, beta=0.0, x_off=0):
+def colsum(X, M, N, ldx, out, beta=0.0, x_off=0, ws_name='colsum'):
     lib = L.load()
     nbytes = lib.asr_colsum_workspace_bytes(int(M), int(N))
-    ws = WS.get('colsum', nbytes, out.device)
+    ws = WS.get(ws_name, nbytes, out.device)
     L.check(lib.asr_colsum(C.c_void_p(X.data_ptr() + 4 * int(x_off)), int(M), int(N),
                            int(ldx), _ptr(out), float(beta), _ptr(ws), nbytes, _stream()),
             'asr_colsum')
