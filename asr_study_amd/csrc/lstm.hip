@@ -61,6 +61,7 @@ struct LstmParams {
   int poll;                // 1: persistent (poll tags); 0: one step per launch
   int allow_fast;          // may use the same-XCD transport
   int dbg;                 // ablation switches (ASR_LSTM_DBG), 0 in production
+  int xstride;             // fwd: bytes between consecutive unit-group tiles in a slot
   const float* U;
   const float* mask_u;
   const float* zx;
@@ -397,7 +398,7 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
   float c = 0.f;
   bool dead = false;
   unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;    // [2][UG][16][4]
-  const int slot_words = 16 * H;
+  const int slot_words = UG * (p.xstride / 4);
   const int s_end = p.s_begin + p.s_count;
   if (ug_ok && p.s_begin > 0) {
     const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
@@ -433,7 +434,7 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
       for (int i = 0; i < NL; ++i) {
         const int grp = tid + i * kThreads;
         use[i] = grp < UG * 16;
-        off[i] = (unsigned)grp * 16u;
+        off[i] = (unsigned)((grp >> 4) * p.xstride + (grp & 15) * 16);
       }
       gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64);
       if (prof) tk1 = wall_clock64();
@@ -500,7 +501,7 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
         if (lane < 16) {
           __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
               xch + (size_t)(s & 1) * slot_words, 0, slot_words * 4, 0x00020000);
-          xstore<FAST>(o, wr, (unsigned)(ug * 16 + nl) * 16u);
+          xstore<FAST>(o, wr, (unsigned)(ug * p.xstride + nl * 16));
         }
       }
       const size_t row = (size_t)t * p.n_pad + n;
@@ -965,6 +966,12 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
+int fwd_xstride() {
+  int v = env_int("ASR_LSTM_XSTRIDE", 256);
+  if (v < 256 || (v & 255)) v = 256;
+  return v;
+}
+
 int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   const int H = a->H;
   const int chains = 2 * (a->n_pad / 16);
@@ -992,6 +999,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     pl.xchain_words = (size_t)2 * 16 * H;
     k = pick_fwd(pl.MAXR);
     if (pl.prec == 1) {
+      pl.xchain_words = (size_t)2 * (H / 4) * (size_t)(fwd_xstride() / 4);
       const int nkk = (H + 31) / 32;
       pl.NKK = nkk <= 4 ? 4 : nkk <= 8 ? 8 : 16;
       pl.shm = (size_t)4 * 16 * (32 * pl.NKK + 8) * 2;
@@ -1050,7 +1058,8 @@ constexpr size_t kStatusBytes = 256;
 size_t xbuf_bytes(const asr_lstm_args* a, bool bwd) {
   const size_t chains = (size_t)2 * (a->n_pad / 16);
   const size_t P = (a->H + 15) / 16;
-  const size_t words = bwd ? (size_t)2 * P * P * 256 : (size_t)2 * 16 * a->H;
+  const size_t words = bwd ? (size_t)2 * P * P * 256
+                           : (size_t)2 * (a->H / 4) * (size_t)(fwd_xstride() / 4);
   return asr_align_up(chains * words * 4, 256);
 }
 size_t xcc_bytes(const asr_lstm_args* a) {
@@ -1096,6 +1105,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.poll = stepwise ? 0 : 1;
   p.allow_fast = env_int("ASR_LSTM_FAST", 1);
   p.dbg = env_int("ASR_LSTM_DBG", 0);
+  p.xstride = fwd_xstride();
   const int steps_per_launch = stepwise ? 1 : a->T;
   for (int s0 = 0; s0 < a->T; s0 += steps_per_launch) {
     for (int cb = 0; cb < chains; cb += pl.chains_per_launch) {

@@ -179,6 +179,47 @@ def main():
     ctc = out[0].cpu().numpy()
     assert np.all(np.isfinite(ctc)), 'non-finite CTC loss in the benchmark step'
 
+    extra = {}
+    if rank == 0:
+        # ---- secondary roofline figures (outside the timed region): the gate GEMM of
+        # a middle layer and the CTC loss+gradient, each timed with HIP events
+        T0 = 999
+        n_pad0 = ops.pad16(N)
+        rows = T0 * n_pad0
+
+        def ev_time(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        xg = torch.randn(rows, 2 * H, device=dev)
+        wg = torch.randn(2 * H, 8 * H, device=dev) * 0.05
+        zg = torch.empty(rows, 8 * H, device=dev)
+        tg = ev_time(lambda: ops.gemm(xg, wg, zg, rows, 8 * H, 2 * H))
+        gf = 2.0 * rows * 8 * H * 2 * H
+        extra['roofline_gate_gemm'] = {
+            'kernel': 'gemm_f32_mfma_kernel %dx%dx%d (x@W, one BiLSTM layer)' % (rows, 8 * H, 2 * H),
+            'bound': 'mfma', 'achieved': round(gf / tg / 1e9, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(gf / tg / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+            'avg_launch_ms': round(tg, 4)}
+        lg = torch.randn(T0, n_pad0, C, device=dev)
+        gg = torch.empty_like(lg)
+        sl0 = torch.full((N,), T0, dtype=torch.int32, device=dev)
+        tc = ev_time(lambda: ops.ctc_loss_grad(lg, lab_d, lab_len_d, sl0, N, grad=gg,
+                                               grad_scale=1.0 / N))
+        cb = 2.0 * T0 * N * C * 4
+        extra['roofline_ctc'] = {
+            'kernel': 'ctc_logsoftmax + ctc_alpha_beta + ctc_grad (T=%d, N=%d, C=%d)' % (T0, N, C),
+            'bound': 'hbm', 'achieved': round(cb / tc / 1e6, 2), 'peak': PEAK_HBM_GBS,
+            'unit': 'GB/s', 'frac': round(cb / tc / 1e6 / PEAK_HBM_GBS, 5),
+            'avg_ms': round(tc, 4),
+            'note': 'latency-bound: a 999-step dependent recursion per utterance (DESIGN.md 6)'}
+        del xg, wg, zg, lg, gg
     if rank == 0:
         T = 999
         n_pad = ops.pad16(N)
@@ -207,6 +248,7 @@ def main():
                          'avg_launch_ms': round(lstm_ms, 4) if lstm_ms else None,
                          'flops_per_launch': flops},
         }
+        line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(line))
