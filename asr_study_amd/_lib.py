@@ -34,14 +34,15 @@ class GemmArgs(C.Structure):
                 ('bias', void_p),
                 ('a_scale', void_p), ('a_scale_period', C.c_int), ('a_scale_ld', C.c_int),
                 ('c_scale', void_p), ('c_scale_period', C.c_int), ('c_scale_ld', C.c_int),
-                ('split_k', C.c_int)]
+                ('split_k', C.c_int), ('precision', C.c_int),
+                ('a_absmax', void_p), ('b_absmax', void_p)]
 
 
 class LstmArgs(C.Structure):
     _fields_ = [('T', C.c_int), ('n_pad', C.c_int), ('H', C.c_int), ('mode', C.c_int),
                 ('U', void_p), ('mask_u', void_p),
                 ('zx', void_p), ('y', void_p), ('cell', void_p), ('gates', void_p),
-                ('dy', void_p), ('dz', void_p)]
+                ('dy', void_p), ('dz', void_p), ('dz_absmax', void_p)]
 
 
 class Segment(C.Structure):
@@ -63,6 +64,7 @@ SIGNATURES = {
                                         void_p]),
     'asr_gemm_workspace_bytes': (C.c_size_t, [C.POINTER(GemmArgs)]),
     'asr_gemm': (C.c_int, [C.POINTER(GemmArgs), void_p, C.c_size_t, void_p]),
+    'asr_absmax': (C.c_int, [void_p, C.c_int64, void_p, void_p]),
     'asr_colsum_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'asr_colsum': (C.c_int, [void_p, C.c_int, C.c_int, C.c_int, void_p, C.c_float, void_p,
                              C.c_size_t, void_p]),

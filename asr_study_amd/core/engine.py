@@ -342,13 +342,14 @@ class Model(object):
                     da = da * rec['mask']
                 continue
             if s.kind == 'dense':
+                gmx = ops.absmax(da, self._buf('damax%d' % si, (1,)))
                 ops.gemm(a_in, da, self.grads, s.f_in_pad, s.n_out, rows, trans_a=True,
-                         c_off=s.oW, split_k=split)
+                         c_off=s.oW, split_k=split, b_absmax=gmx)
                 ops.colsum(da, rows, s.n_out, s.n_out, self._gview(s.ob, s.n_out))
                 if not first:
                     dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
                     ops.gemm(da, self.params, dx, rows, s.f_in_pad, s.n_out, trans_b=True,
-                             b_off=s.oW)
+                             b_off=s.oW, a_absmax=gmx)
                     da = dx
             elif s.kind == 'bilstm':
                 Hp = s.Hp
@@ -361,12 +362,13 @@ class Model(object):
                 if self.overlap and self._dz_free[par] is not None:
                     main.wait_event(self._dz_free[par])
                 U = self._view(s.oU, 2 * Hp * 4 * Hp)
+                zmx = self._buf('dzmax%d' % par, (1,))
                 rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp,
-                                               mask_u=BU, mode=self.lstm_mode)
+                                               mask_u=BU, mode=self.lstm_mode, dz_absmax=zmx)
                 flush_side()        # previous layer's dW/dU/db now overlap this BPTT
                 y = rec['y']
 
-                def weight_grads(wsn, s=s, dz=dz, y=y, a_in=a_in, BW=BW, BU=BU, Hp=Hp):
+                def weight_grads(wsn, s=s, dz=dz, y=y, a_in=a_in, BW=BW, BU=BU, Hp=Hp, zmx=zmx):
                     # dU[d] = (h_prev (.) B_U)^T dz[d]: h_prev is y shifted by one step in
                     # the direction's processing order (zero at its first step)
                     kk = (T - 1) * n_pad
@@ -378,19 +380,19 @@ class Model(object):
                                      ldb=8 * Hp, ldc=4 * Hp, a_off=a_off, b_off=b_off,
                                      c_off=s.oU + d * Hp * 4 * Hp, split_k=split,
                                      a_scale=None if BU is None else BU[d],
-                                     a_scale_period=n_pad, ws_name=wsn)
+                                     a_scale_period=n_pad, ws_name=wsn, b_absmax=zmx)
                         else:
                             self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
                     # dW = (x (.) B_W)^T dz, db = colsum(dz)
                     if BW is None:
                         ops.gemm(a_in, dz, self.grads, s.f_in_pad, 8 * Hp, rows, trans_a=True,
-                                 c_off=s.oW, split_k=split, ws_name=wsn)
+                                 c_off=s.oW, split_k=split, ws_name=wsn, b_absmax=zmx)
                     else:
                         for d in range(2):
                             ops.gemm(a_in, dz, self.grads, s.f_in_pad, 4 * Hp, rows, trans_a=True,
                                      ldb=8 * Hp, ldc=8 * Hp, b_off=d * 4 * Hp,
                                      c_off=s.oW + d * 4 * Hp, split_k=split, a_scale=BW[d],
-                                     a_scale_period=n_pad, ws_name=wsn)
+                                     a_scale_period=n_pad, ws_name=wsn, b_absmax=zmx)
                     ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp),
                                ws_name=wsn + '_cs')
 
@@ -404,13 +406,13 @@ class Model(object):
                     dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
                     if BW is None:
                         ops.gemm(dz, self.params, dx, rows, s.f_in_pad, 8 * Hp, trans_b=True,
-                                 b_off=s.oW)
+                                 b_off=s.oW, a_absmax=zmx)
                     else:   # dx = sum_d B_W[d] (.) (dz_d @ W_d^T)
                         for d in range(2):
                             ops.gemm(dz, self.params, dx, rows, s.f_in_pad, 4 * Hp, trans_b=True,
                                      lda=8 * Hp, ldb=8 * Hp, a_off=d * 4 * Hp,
                                      b_off=s.oW + d * 4 * Hp, beta=0.0 if d == 0 else 1.0,
-                                     c_scale=BW[d], c_scale_period=n_pad)
+                                     c_scale=BW[d], c_scale_period=n_pad, a_absmax=zmx)
                     da = dx
         flush_side()
         if self.overlap and self._side is not None:

@@ -221,6 +221,243 @@ gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, 
   }
 }
 
+
+// ===========================================================================
+// Split-fp16 GEMM: every fp32 operand element x is staged in LDS as
+// hi = fp16(x*s), lo = fp16(x*s - hi) (s = per-tensor power of two that maps max|x|
+// into [2^8, 2^9): 22 mantissa bits for elements within 2^-10 of the maximum, an
+// absolute resolution of 2^-32 of the maximum below that -- fp16 subnormals are
+// kept) and the product is accumulated in fp32 as hi*hi + hi*lo + lo*hi with three
+// v_mfma_f32_32x32x16_f16 per K=16 slab instead of eight v_mfma_f32_32x32x2_f32:
+// 16x the MFMA rate for 3x the MFMAs.  The dropped lo*lo term is 2^-22 relative.
+// Tile 128x128x32, 4 waves (2x2, 64x64 each), both operands K-contiguous in LDS
+// ([mn][32 + 8 pad] halfs -> conflict-free ds_read_b128), register prefetch of the
+// next tile + double-buffered LDS, one barrier per K=32 step.
+using hx8 = __attribute__((ext_vector_type(8))) _Float16;
+using hx4 = __attribute__((ext_vector_type(4))) _Float16;
+constexpr int HBK = 32;
+constexpr int HLD = HBK + 8;                 // halfs per LDS row (80 bytes)
+
+__device__ __forceinline__ float pow2_scale(const float* absmax) {
+  // 2^(9 - e) with max = f * 2^e, f in [0.5, 1): max*scale in [2^8, 2^9)
+  if (absmax == nullptr) return 1.f;
+  const unsigned b = __float_as_uint(*absmax);
+  int e = (int)((b >> 23) & 0xff) - 126;
+  if ((b & 0x7fffffffu) == 0u) return 1.f;
+  int k = 9 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  return __uint_as_float((unsigned)(127 + k) << 23);
+}
+
+// 16 fp32 values of one thread's share of a tile -> (hi, lo) halfs, [4 rows][4 k]
+struct Frag16 { float v[4][4]; };   // v[r][c]: r = mn offset (0..3), c = k offset (0..3)
+
+__device__ __forceinline__ void h_tile_load(const TileSrc& s, int k0, int mn0, int k_end,
+                                            Frag16 (&f)[1]) {
+  // mn-contiguous source: thread owns k rows 4kq..4kq+3 x mn 4mq..4mq+3
+  // k-contiguous source:  thread owns mn rows r0 + {0,32,64,96}... see below
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) f[0].v[r][c] = 0.f;
+  if (s.mn_contig) {
+    const int kq = tid >> 5, mq = tid & 31;
+    const int mn = mn0 + 4 * mq;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = k0 + 4 * kq + c;
+      if (k < k_end) {
+        const float* src = s.p + (size_t)k * s.ld + mn;
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s.vec_ok && mn + 3 < s.mn_total) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (mn + e < s.mn_total) t[e] = src[e];
+        }
+        if (s.scale) {
+          const float* sc = s.scale + (size_t)(k % s.period) * s.scale_ld + mn;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (mn + e < s.mn_total) t[e] *= sc[e];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[0].v[r][c] = t[r];
+      }
+    }
+  } else {
+    // 128 rows x 8 k-quads = 1024 float4; thread takes rows (tid>>3) + 32*r, quad tid&7
+    const int kq = tid & 7;
+    const int k = k0 + 4 * kq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mn = mn0 + (tid >> 3) + 32 * r;
+      if (mn < s.mn_total) {
+        const float* src = s.p + (size_t)mn * s.ld + k;
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s.vec_ok && k + 3 < k_end) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e < k_end) t[e] = src[e];
+        }
+        if (s.scale) {
+          const float* sc = s.scale + (size_t)(mn % s.period) * s.scale_ld + k;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e < k_end) t[e] *= sc[e];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) f[0].v[r][c] = t[c];
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void h_tile_store(int mn_contig, const Frag16 (&f)[1], float scale,
+                                             _Float16 (*Shi)[HLD], _Float16 (*Slo)[HLD]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    hx4 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x = f[0].v[r][c] * scale;
+      const _Float16 h = (_Float16)x;
+      hi[c] = h;
+      lo[c] = (_Float16)(x - (float)h);
+    }
+    int row, col;
+    if (mn_contig) { row = 4 * (tid & 31) + r; col = 4 * (tid >> 5); }
+    else { row = (tid >> 3) + 32 * r; col = 4 * (tid & 7); }
+    *reinterpret_cast<hx4*>(&Shi[row][col]) = hi;
+    *reinterpret_cast<hx4*>(&Slo[row][col]) = lo;
+  }
+}
+
+struct HScales { const float* a_absmax; const float* b_absmax; };
+
+__global__ void __launch_bounds__(256)
+gemm_f16x2_kernel(TileSrc A, TileSrc B, int M, int N, int K, int k_per_split, Epilogue ep,
+                  HScales hs) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
+  // [buf 2][A_hi, A_lo, B_hi, B_lo][128][HLD]
+  auto tile = [&](int buf, int which) {
+    return reinterpret_cast<_Float16 (*)[HLD]>(hsm + ((size_t)(buf * 4 + which) * 128) * HLD);
+  };
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int k_begin = blockIdx.z * k_per_split;
+  int k_end = k_begin + k_per_split;
+  if (k_end > K) k_end = K;
+  const float sa = pow2_scale(hs.a_absmax), sb = pow2_scale(hs.b_absmax);
+
+  f32x16 am[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) am[i][j][e] = 0.f;
+
+  Frag16 fa[1], fb[1];
+  const int nk = (k_end - k_begin + HBK - 1) / HBK;
+  if (nk > 0) {
+    h_tile_load(A, k_begin, m0, k_end, fa);
+    h_tile_load(B, k_begin, n0, k_end, fb);
+    h_tile_store(A.mn_contig, fa, sa, tile(0, 0), tile(0, 1));
+    h_tile_store(B.mn_contig, fb, sb, tile(0, 2), tile(0, 3));
+  }
+  __syncthreads();
+  const int lrow = lane & 31, lk = 8 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      h_tile_load(A, k_begin + (kt + 1) * HBK, m0, k_end, fa);
+      h_tile_load(B, k_begin + (kt + 1) * HBK, n0, k_end, fb);
+    }
+    _Float16 (*Ah)[HLD] = tile(cur, 0);
+    _Float16 (*Al)[HLD] = tile(cur, 1);
+    _Float16 (*Bh)[HLD] = tile(cur, 2);
+    _Float16 (*Bl)[HLD] = tile(cur, 3);
+#pragma unroll
+    for (int ks = 0; ks < HBK / 16; ++ks) {
+      hx8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const hx8*>(&Ah[wm * 64 + i * 32 + lrow][16 * ks + lk]);
+        al[i] = *reinterpret_cast<const hx8*>(&Al[wm * 64 + i * 32 + lrow][16 * ks + lk]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = *reinterpret_cast<const hx8*>(&Bh[wn * 64 + j * 32 + lrow][16 * ks + lk]);
+        bl[j] = *reinterpret_cast<const hx8*>(&Bl[wn * 64 + j * 32 + lrow][16 * ks + lk]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], am[i][j], 0, 0, 0);
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], am[i][j], 0, 0, 0);
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], am[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) {
+      h_tile_store(A.mn_contig, fa, sa, tile(cur ^ 1, 0), tile(cur ^ 1, 1));
+      h_tile_store(B.mn_contig, fb, sb, tile(cur ^ 1, 2), tile(cur ^ 1, 3));
+    }
+    __syncthreads();
+  }
+  const float unscale = 1.f / (sa * sb);
+  const int lcol = lane & 31, lhalf = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + lcol;
+      if (col >= N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+        if (row >= M) continue;
+        float v = am[i][j][e] * unscale;
+        if (ep.partial) {
+          ep.partial[((size_t)blockIdx.z * M + row) * N + col] = v;
+        } else {
+          v *= ep.alpha;
+          float* dst = ep.C + (size_t)row * ep.ldc + col;
+          if (ep.bias) v += ep.bias[col];
+          if (ep.c_scale) v *= ep.c_scale[(size_t)(row % ep.c_period) * ep.c_ld + col];
+          if (ep.beta != 0.f) v += ep.beta * *dst;
+          *dst = v;
+        }
+      }
+    }
+}
+
+// max |x| of a flat tensor -> out[0] (float).  Two launches: per-block maxima via
+// atomicMax on the float bits (all non-negative, so integer order == float order).
+__global__ void __launch_bounds__(256)
+absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  const size_t n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float4 q = x4[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w))));
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+  m = asr_wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
 // Column sums (bias gradients): out[n] = beta*out[n] + sum_m X[m][n].  HBM-bound:
 // X is read exactly once with 256-byte coalesced rows.  Stage 1: grid (N/64, RS);
 // each 256-thread block owns 64 columns x one slice of rows (4 row phases, float64
@@ -315,7 +552,27 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
     ep.partial = reinterpret_cast<float*>(workspace);
   }
   dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, splits);
-  if (BK == 16)
+  static const int prec_env = [] { const char* v = getenv("ASR_GEMM_PREC"); return v ? atoi(v) : 1; }();
+  const int prec = a->precision == 0 ? 0 : (a->precision == 1 ? 1 : prec_env);
+  if (prec == 1 && a->K >= 32) {
+    // split-fp16 path: K slabs of 32
+    int kps = (a->K + splits - 1) / splits;
+    kps = (kps + HBK - 1) / HBK * HBK;
+    int sp = splits;
+    while (sp > 1 && (size_t)(sp - 1) * kps >= (size_t)a->K) --sp;
+    grid.z = sp;
+    const size_t shm = (size_t)2 * 4 * 128 * HLD * sizeof(_Float16);
+    static bool attr_done = false;
+    if (!attr_done) {
+      ASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_f16x2_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      attr_done = true;
+    }
+    HScales hs{a->a_absmax, a->b_absmax};
+    hipLaunchKernelGGL(gemm_f16x2_kernel, grid, dim3(256), shm, stream, A, B, a->M, a->N, a->K,
+                       kps, ep, hs);
+    splits = sp;
+  } else if (BK == 16)
     hipLaunchKernelGGL(gemm_f32_mfma_kernel<16>, grid, dim3(256), 0, stream, A, B, a->M, a->N,
                        a->K, k_per_split, ep);
   else
@@ -332,6 +589,20 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
                        reinterpret_cast<const float*>(workspace), splits, a->M, a->N, ep2);
     ASR_CHECK_LAUNCH();
   }
+  return ASR_OK;
+}
+
+extern "C" int asr_absmax(const float* x, int64_t n, float* out, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(x && out && n > 0, "absmax: bad arguments");
+  ASR_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0, "absmax: x must be 16-byte aligned");
+  ASR_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), stream));
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, (size_t)n,
+                     reinterpret_cast<unsigned*>(out));
+  ASR_CHECK_LAUNCH();
   return ASR_OK;
 }
 

@@ -71,6 +71,7 @@ struct LstmParams {
   const float* dy;
   float* dz;
   float* dc_state;
+  unsigned* dz_absmax;     // optional: max |dz| as float bits (atomicMax)
   unsigned* xbuf;          // exchange buffer (words)
   long long xchain_words;  // words per chain (2 slots)
   int* xcc;                // [chains][P] XCC id + 1 of every workgroup
@@ -568,6 +569,7 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
   float cmask = 1.f;
   if (cvalid && p.mask_u) cmask = p.mask_u[((size_t)dir * p.n_pad + cn) * H + cu];
   float dc = 0.f;
+  float zmax = 0.f;
   if (cvalid && p.s_begin > 0) dc = p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu];
   bool dead = false;
   unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;   // [2][P cons][P prod][256]
@@ -651,6 +653,7 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
         z4.z = d_g * (1.f - gg * gg);
         z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
         *reinterpret_cast<float4*>(p.dz + (((size_t)t * p.n_pad + cn) * 2 + dir) * H4 + 4 * cu) = z4;
+        zmax = fmaxf(zmax, fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w))));
       }
       *reinterpret_cast<float4*>(dzl + (tid >> 4) * DZS + 4 * (tid & 15)) = z4;
     }
@@ -706,6 +709,10 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
     for (int i = 0; i < 4; ++i) out[i] = pt[i];
   }
   if (cvalid && p.dc_state) p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu] = dc;
+  if (p.dz_absmax) {
+    zmax = asr_wave_max(zmax);
+    if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
+  }
 }
 
 template <int TPW>
@@ -764,6 +771,7 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
   float cmask = 1.f;
   if (cvalid && p.mask_u) cmask = p.mask_u[((size_t)dir * p.n_pad + cn) * H + cu];
   float dc = 0.f;
+  float zmax = 0.f;
   if (cvalid && p.s_begin > 0) dc = p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu];
   bool dead = false;
   unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;
@@ -843,6 +851,7 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
       }
       // power-of-two scale of this batch column: max over its 16 threads (one DPP row)
       float m = fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w)));
+      zmax = fmaxf(zmax, m);
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
       int ex = 0;
@@ -904,6 +913,10 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
     for (int i = 0; i < 4; ++i) out[i] = pt[i];
   }
   if (cvalid && p.dc_state) p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu] = dc;
+  if (p.dz_absmax) {
+    zmax = asr_wave_max(zmax);
+    if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
+  }
 }
 
 template <int TPW>
@@ -1093,6 +1106,8 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.R = pl.R; p.P = pl.P;
   p.U = a->U; p.mask_u = a->mask_u; p.zx = a->zx; p.y = a->y; p.cell = a->cell;
   p.gates = a->gates; p.dy = a->dy; p.dz = a->dz;
+  p.dz_absmax = bwd ? reinterpret_cast<unsigned*>(a->dz_absmax) : nullptr;
+  if (p.dz_absmax) ASR_CHECK_HIP(hipMemsetAsync(p.dz_absmax, 0, sizeof(unsigned), stream));
   p.status = reinterpret_cast<int*>(ws);
   p.xcc = reinterpret_cast<int*>(ws + kStatusBytes);
   p.xbuf = reinterpret_cast<unsigned*>(ws + kStatusBytes + cb_);

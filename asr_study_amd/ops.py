@@ -52,7 +52,8 @@ def pad16(n):
 # --------------------------------------------------------------------------- GEMM
 def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None,
          alpha=1.0, beta=0.0, bias=None, a_scale=None, a_scale_period=0, c_scale=None,
-         c_scale_period=0, split_k=0, a_off=0, b_off=0, c_off=0, ws_name='gemm'):
+         c_scale_period=0, split_k=0, a_off=0, b_off=0, c_off=0, ws_name='gemm',
+         precision=-1, a_absmax=None, b_absmax=None):
     """C[M,N] = alpha * opA(A) @ opB(B) + beta*C (+bias), see include/asr_hip.h.
 
     A/B/Cm are float32 CUDA tensors used as raw storage; *_off are element
@@ -80,9 +81,20 @@ def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ld
         tiles = ((int(M) + 127) // 128) * ((int(N) + 127) // 128)
         split_k = max(1, min(64, (1024 + tiles - 1) // tiles, int(K) // 256))
     a.split_k = int(split_k)
+    a.precision = int(precision)
+    a.a_absmax = a_absmax.data_ptr() if a_absmax is not None else None
+    a.b_absmax = b_absmax.data_ptr() if b_absmax is not None else None
     nbytes = lib.asr_gemm_workspace_bytes(C.byref(a))
     ws = WS.get(ws_name, nbytes, Cm.device) if nbytes else None
     L.check(lib.asr_gemm(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_gemm')
+
+
+def absmax(x, out=None):
+    """max |x| of a contiguous float32 CUDA tensor -> 1-element float32 tensor."""
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    L.check(L.load().asr_absmax(_ptr(x), x.numel(), _ptr(out), _stream()), 'asr_absmax')
+    return out
 
 
 def colsum(X, M, N, ldx, out, beta=0.0, x_off=0, ws_name='colsum'):
@@ -96,12 +108,12 @@ def colsum(X, M, N, ldx, out, beta=0.0, x_off=0, ws_name='colsum'):
 
 # --------------------------------------------------------------------------- LSTM
 def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=None,
-               dy=None, dz=None, mode=0):
+               dy=None, dz=None, mode=0, dz_absmax=None):
     a = L.LstmArgs()
     a.T, a.n_pad, a.H, a.mode = int(T), int(n_pad), int(H), int(mode)
     a.U = U.data_ptr()
     for name, t in (('mask_u', mask_u), ('zx', zx), ('y', y), ('cell', cell),
-                    ('gates', gates), ('dy', dy), ('dz', dz)):
+                    ('gates', gates), ('dy', dy), ('dz', dz), ('dz_absmax', dz_absmax)):
         setattr(a, name, t.data_ptr() if t is not None else None)
     return a
 
@@ -118,10 +130,12 @@ def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=
     return ws
 
 
-def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check=False):
+def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check=False,
+                 dz_absmax=None):
     lib = L.load()
     _check_f32(dy, U, cell, gates, dz, mask_u)
-    a = _lstm_args(T, n_pad, H, U, mask_u, cell=cell, gates=gates, dy=dy, dz=dz, mode=mode)
+    a = _lstm_args(T, n_pad, H, U, mask_u, cell=cell, gates=gates, dy=dy, dz=dz, mode=mode,
+                   dz_absmax=dz_absmax)
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 1)
     ws = WS.get('lstm_bwd', nbytes, dy.device)
     L.check(lib.asr_lstm_seq_bwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_bwd')

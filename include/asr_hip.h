@@ -124,10 +124,19 @@ typedef struct asr_gemm_args {
   int c_scale_period;
   int c_scale_ld;
   int split_k;             /* 0/1 = none                                     */
+  /* arithmetic: 0 = exact fp32 MFMA; 1 = split-fp16 MFMA (hi + lo/2048, 22-bit   */
+  /* mantissa, fp32 accumulate); -1 = library default (env ASR_GEMM_PREC, 1).    */
+  int precision;
+  /* split-fp16 only: device floats holding max|A| / max|B| (asr_absmax) used to */
+  /* pick a power-of-two pre-scale so tiny gradients stay in fp16 range; NULL=1. */
+  const float* a_absmax;
+  const float* b_absmax;
 } asr_gemm_args;
 size_t asr_gemm_workspace_bytes(const asr_gemm_args* a);
 int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes,
              asr_stream_t stream);
+/* out[0] = max |x[i]| over a 16-byte aligned flat tensor (HBM-bound).         */
+int asr_absmax(const float* x, int64_t n, float* out, asr_stream_t stream);
 /* out[n] = beta*out[n] + sum_m X[m, n]  (bias gradients; X read once,       */
 /* float64 accumulation, fixed-order two-stage reduce).                      */
 size_t asr_colsum_workspace_bytes(int M, int N);
@@ -156,6 +165,9 @@ typedef struct asr_lstm_args {
   /* backward: dy (T, n_pad, 2H) in; dz (T, n_pad, 2, 4H) out.               */
   const float* dy;
   float* dz;
+  /* backward, optional: receives max |dz| (one device float; used as the     */
+  /* split-fp16 GEMM pre-scale of the gradient operand), or NULL.             */
+  float* dz_absmax;
 } asr_lstm_args;
 size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
 int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,

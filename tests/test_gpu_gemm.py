@@ -44,9 +44,12 @@ def test_gemm_asymmetric_identity():
     M = N = K = 96
     B = np.arange(K * N, dtype=np.float32).reshape(K, N) / 100.0
     Cd = torch.zeros((M, N), dtype=torch.float32, device='cuda:0')
-    ops.gemm(to_dev(np.eye(M, dtype=np.float32)), to_dev(B), Cd, M, N, K)
+    ops.gemm(to_dev(np.eye(M, dtype=np.float32)), to_dev(B), Cd, M, N, K, precision=0)
     torch.cuda.synchronize()
-    assert np.array_equal(Cd.cpu().numpy(), B)
+    assert np.array_equal(Cd.cpu().numpy(), B)          # exact-fp32 MFMA path: bit exact
+    ops.gemm(to_dev(np.eye(M, dtype=np.float32)), to_dev(B), Cd, M, N, K, precision=1)
+    torch.cuda.synchronize()
+    assert np.abs(Cd.cpu().numpy() - B).max() < 2e-6 * B.max()   # split-fp16: 22-bit operands
 
 
 def test_gemm_masks_and_strided_views():
@@ -83,3 +86,33 @@ def test_gemm_masks_and_strided_views():
     ops.colsum(to_dev(dz), T * NB, 8 * H, 8 * H, cs)
     torch.cuda.synchronize()
     assert report('colsum', cs.cpu().numpy(), dz.astype(np.float64).sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb,sk', CASES)
+def test_gemm_split_fp16_variants(M, N, K, ta, tb, sk):
+    """precision=1: split-fp16 MFMA path; tolerance 2e-6 relative to sum|a||b| terms
+    (22-bit operands, fp32 accumulation)."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(M * 3 + N + K)
+    A = rs.randn(K, M) if ta else rs.randn(M, K)
+    B = rs.randn(N, K) if tb else rs.randn(K, N)
+    A *= 1e-5                                   # gradient-like magnitudes need the pre-scale
+    A[0, 0] = 3e-3                              # one outlier sets the scale
+    C0 = rs.randn(M, N) * 1e-5
+    bias = rs.randn(N) * 1e-5
+    want = 0.75 * ((A.T if ta else A) @ (B.T if tb else B)) + 0.5 * C0 + bias
+    Ad = to_dev(A.astype(np.float32))
+    Cd = to_dev(C0.astype(np.float32))
+    ops.gemm(Ad, to_dev(B.astype(np.float32)), Cd, M, N, K, trans_a=ta, trans_b=tb, alpha=0.75,
+             beta=0.5, bias=to_dev(bias.astype(np.float32)), split_k=sk, precision=1,
+             a_absmax=ops.absmax(Ad))
+    torch.cuda.synchronize()
+    err = report('gemm16 %dx%dx%d ta=%d tb=%d sk=%d' % (M, N, K, ta, tb, sk), Cd.cpu().numpy(), want)
+    assert err < 2e-6 * np.abs(want).max()
+
+
+def test_absmax():
+    from asr_study_amd import ops
+    x = torch.randn(1000003, device='cuda:0') * 1e-4
+    x[77777] = -0.5
+    assert abs(float(ops.absmax(x[:1000000].contiguous())) - 0.5) < 1e-7
