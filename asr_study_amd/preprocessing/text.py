@@ -1,115 +1,115 @@
 # -*- coding: utf-8 -*-
-"""Label parsers with the reference's surface (preprocessing/text.py).
+"""Character-level label parsers (the reference's ``preprocessing/text.py`` surface:
+``CharParser(mode)``, ``.map`` / ``.imap`` / ``.is_valid`` / ``__call__``, and the two
+ready-made instances ``simple_char_parser`` / ``complex_char_parser``).
 
-Python-3 restatement of CharParser: the reference's _sanitize uses py2-only
-string.maketrans / str.translate(None, ...) (text.py:94) and dict.iteritems
-(:138).  simple_char_parser: a-z -> 0..25, ' ' -> 26, blank id 27 (28 classes).
-"""
+Vocabulary order (it fixes the class ids the CTC layer is trained on): a-z = 0..25,
+then -- when enabled -- the Brazilian-Portuguese accented letters, upper-case copies,
+space, punctuation, digits; the CTC blank is the id after the last symbol.  With the
+default mode ('space') that is 27 symbols + blank = 28 classes.
+
+Sanitising pipeline of ``map`` (same order as the reference's ``_sanitize``, which is
+observable: e.g. digits are removed *after* runs of spaces were collapsed): collapse
+whitespace, drop digits, transliterate accents (unidecode), turn '-' and "'" into
+spaces and drop the remaining punctuation, drop spaces, lower-case -- each step only
+when the corresponding mode letter is absent."""
 import string
+import unicodedata
 
 import numpy as np
 
-try:                                    # optional, like the reference's dependency
-    from unidecode import unidecode
-except ImportError:                     # ASCII-only fallback: strip combining marks
-    import unicodedata
-
-    def unidecode(text):
-        return ''.join(c for c in unicodedata.normalize('NFKD', text)
-                       if not unicodedata.combining(c)).encode('ascii', 'ignore').decode()
+try:
+    from unidecode import unidecode as _to_ascii
+except ImportError:                      # optional dependency, as in the reference
+    def _to_ascii(text):
+        decomposed = unicodedata.normalize('NFKD', text)
+        return ''.join(ch for ch in decomposed if not unicodedata.combining(ch)) \
+            .encode('ascii', 'ignore').decode()
 
 PUNCTUATIONS = "'""-,.!?:;"
 ACCENTS = u'ãõçâêôáíóúàüóé'
+MODE_LETTERS = {'sensitive': 'S', 'space': 's', 'accents': 'a', 'punctuation': 'p',
+                'digits': 'd'}
+_DASHES_TO_SPACE = str.maketrans("-'", '  ')
+_NO_PUNCT = str.maketrans('', '', string.punctuation)
 
 
 class BaseParser(object):
-    """Interface class for all parsers (text.py:13-33)."""
-
     def __call__(self, _input):
         return self.map(_input)
 
     def map(self, _input):
-        pass
+        raise NotImplementedError
 
     def imap(self, _input):
-        pass
+        raise NotImplementedError
 
     def is_valid(self, _input):
-        pass
+        raise NotImplementedError
+
+
+def _parse_mode(mode):
+    if mode == 'all':
+        return sorted(MODE_LETTERS.values())
+    letters = []
+    for token in mode.split('|'):
+        if token in MODE_LETTERS:
+            letters.append(MODE_LETTERS[token])
+        elif token in MODE_LETTERS.values():
+            letters.append(token)
+        else:
+            raise ValueError('Unknown mode %s' % token)
+    return letters
+
+
+def _build_vocab(flags):
+    symbols = list(string.ascii_lowercase)
+    if 'a' in flags:
+        symbols += list(ACCENTS)
+    if 'S' in flags:
+        symbols += [c.upper() for c in symbols]
+    if 's' in flags:
+        symbols.append(' ')
+    if 'p' in flags:
+        symbols += list(PUNCTUATIONS)
+    if 'd' in flags:
+        symbols += list(string.digits)
+    vocab = {}
+    for sym in symbols:                  # later duplicates keep the LATER id (dict assign)
+        vocab[sym] = len(vocab)
+    inverse = {idx: sym for sym, idx in vocab.items()}
+    inverse[len(inverse)] = '<b>'        # CTC blank
+    return vocab, inverse
 
 
 class CharParser(BaseParser):
-    """Maps text to a character vocabulary (text.py:36-143).
-
-    mode: 'space'|'s', 'accents'|'a', 'punctuation'|'p', 'digits'|'d',
-    'sensitive'|'S', joined with '|', or 'all'.
-    """
-
     def __init__(self, mode='space'):
-        self._permitted_modes = {'sensitive': 'S', 'space': 's', 'accents': 'a',
-                                 'punctuation': 'p', 'digits': 'd'}
-        if mode == 'all':
-            self.mode = list(self._permitted_modes.values())
-        else:
-            self.mode = []
-            for m in mode.split('|'):
-                try:
-                    self.mode.append(self._permitted_modes[m])
-                except KeyError:
-                    if m not in self._permitted_modes.values():
-                        raise ValueError('Unknown mode %s' % m)
-                    self.mode.append(m)
-        self._vocab, self._inv_vocab = self._gen_vocab()
-
-    def map(self, txt, sanitize=True):
-        if sanitize:
-            txt = self._sanitize(txt)
-        return np.array([self._vocab[c] for c in txt], dtype='int32')
-
-    def imap(self, labels):
-        return ''.join([self._inv_vocab[int(l)] for l in labels])
+        self._permitted_modes = dict(MODE_LETTERS)
+        self.mode = _parse_mode(mode)
+        self._vocab, self._inv_vocab = _build_vocab(self.mode)
 
     def _sanitize(self, text):
-        text = ' '.join(text.split())                       # duplicated spaces
-        if 'd' not in self.mode:
-            text = ''.join([c for c in text if not c.isdigit()])
-        if 'a' not in self.mode:
-            text = unidecode(text)
-        if 'p' not in self.mode:
-            text = text.translate(str.maketrans("-'", '  '))
-            text = text.translate(str.maketrans('', '', string.punctuation))
-        if 's' not in self.mode:
+        flags = self.mode
+        text = ' '.join(text.split())
+        if 'd' not in flags:
+            text = ''.join(ch for ch in text if not ch.isdigit())
+        if 'a' not in flags:
+            text = _to_ascii(text)
+        if 'p' not in flags:
+            text = text.translate(_DASHES_TO_SPACE).translate(_NO_PUNCT)
+        if 's' not in flags:
             text = text.replace(' ', '')
-        if 'S' not in self.mode:
-            text = text.lower()
-        return text
+        return text if 'S' in flags else text.lower()
+
+    def map(self, txt, sanitize=True):
+        chars = self._sanitize(txt) if sanitize else txt
+        return np.fromiter((self._vocab[c] for c in chars), dtype='int32', count=len(chars))
+
+    def imap(self, labels):
+        return ''.join(self._inv_vocab[int(i)] for i in labels)
 
     def is_valid(self, text):
-        try:
-            self.map(text, sanitize=False)
-            return True
-        except KeyError:
-            return False
-
-    def _gen_vocab(self):
-        vocab = {chr(v + ord('a')): v for v in range(ord('z') - ord('a') + 1)}
-        if 'a' in self.mode:
-            for a in ACCENTS:
-                vocab[a] = len(vocab)
-        if 'S' in self.mode:
-            for char in list(vocab.keys()):
-                vocab[char.upper()] = len(vocab)
-        if 's' in self.mode:
-            vocab[' '] = len(vocab)
-        if 'p' in self.mode:
-            for p in PUNCTUATIONS:
-                vocab[p] = len(vocab)
-        if 'd' in self.mode:
-            for num in range(10):
-                vocab[str(num)] = len(vocab)
-        inv_vocab = {v: k for (k, v) in vocab.items()}
-        inv_vocab[len(inv_vocab)] = '<b>'                   # blank label
-        return vocab, inv_vocab
+        return all(c in self._vocab for c in text)
 
 
 simple_char_parser = CharParser()

@@ -36,19 +36,24 @@ def _resolve(module):
 
 
 def inspect_module(module, to_dict=True, regex=False):
-    modules = {}
+    """Members defined in ``module`` itself (not imported into it).  With ``regex``
+    the name is a prefix pattern over every loaded sub-module (``datasets*``)."""
     if regex:
-        pattern = re.compile(module)
-        for key, value in list(sys.modules.items()):
-            if pattern.match(key):
-                modules[key] = value
+        import importlib
+        import pkgutil
+        root = _resolve(module.rstrip('*.'))
+        pkg = importlib.import_module(root)
+        for info in pkgutil.iter_modules(getattr(pkg, '__path__', [])):
+            importlib.import_module(root + '.' + info.name)
+        pattern = re.compile(re.escape(root) + r'(\.|$)')
+        modules = {k: v for k, v in list(sys.modules.items()) if pattern.match(k) and v}
     else:
         module = _resolve(module)
         modules = {module: sys.modules[module]}
     members = []
     for key, value in modules.items():
         members.extend(inspect.getmembers(
-            value, lambda m: hasattr(m, '__module__') and m.__module__ == key))
+            value, lambda m, key=key: getattr(m, '__module__', None) == key))
     return dict(members) if to_dict else members
 
 

@@ -1,49 +1,70 @@
-"""Hyper-parameter bag with the reference's surface (utils/hparams.py:
-``HParams(**kv).parse(['k','v',...]|dict|str).values()``, attribute access returns
-None for unknown keys, ``update`` merges and returns self)."""
+"""Free-form hyper-parameter bag used by the command lines.
+
+Behavioural contract (what train.py / eval.py of the reference rely on,
+utils/hparams.py): construct from keyword arguments; ``parse`` accepts a dict, a flat
+``[key, value, key, value, ...]`` list whose values are run through
+``ast.literal_eval`` when they look like literals (otherwise kept as strings), or a
+string holding a dict literal; ``update`` merges and returns the bag; attribute and
+item access return ``None`` for unknown keys; ``values()`` exposes the dict;
+``vars(bag)`` works (``__dict__`` is the dict)."""
 import ast
 
 
+def _literal(text):
+    """'512' -> 512, '[1, 2]' -> [1, 2], 'tanh' -> 'tanh'."""
+    if not isinstance(text, str):
+        return text
+    try:
+        return ast.literal_eval(text)
+    except (ValueError, SyntaxError):
+        return text
+
+
+def _pairs(flat):
+    flat = list(flat)
+    return {flat[i]: _literal(flat[i + 1]) for i in range(0, len(flat) - 1, 2)}
+
+
 class HParams(object):
-    def __init__(self, **init_hparams):
-        object.__setattr__(self, 'keyvals', dict(init_hparams))
+    __slots__ = ('keyvals',)
+
+    def __init__(self, **initial):
+        object.__setattr__(self, 'keyvals', dict(initial))
+
+    # -- merging -----------------------------------------------------------
+    def update(self, mapping):
+        self.keyvals.update(mapping)
+        return self
+
+    def parse(self, spec):
+        if isinstance(spec, dict):
+            return self.update(spec)
+        if isinstance(spec, (list, tuple, set)):
+            return self.update(_pairs(spec))
+        return self.update(ast.literal_eval(spec))
+
+    # -- access ------------------------------------------------------------
+    def values(self):
+        return self.keyvals
 
     def __getitem__(self, key):
         return self.keyvals.get(key)
 
-    def __getattribute__(self, attribute):
-        if attribute == '__dict__':
+    def __getattribute__(self, name):
+        if name == '__dict__':
             return object.__getattribute__(self, 'keyvals')
-        return object.__getattribute__(self, attribute)
+        return object.__getattribute__(self, name)
 
-    def __getattr__(self, key):
-        return object.__getattribute__(self, 'keyvals').get(key)
+    def __getattr__(self, name):           # only reached for unknown attributes
+        return object.__getattribute__(self, 'keyvals').get(name)
 
-    def __setattr__(self, key, value):
-        self.keyvals[key] = value
+    def __setattr__(self, name, value):
+        self.keyvals[name] = value
 
-    def update(self, values_dict):
-        self.keyvals.update(values_dict)
-        return self
+    def __contains__(self, key):
+        return key in self.keyvals
 
-    def parse(self, values):
-        """dict -> merged; list/set ['k1','v1','k2','v2'] -> values literal-eval'ed
-        when possible (utils/hparams.py:48-63); str -> literal dict."""
-        if type(values) == dict:
-            return self.update(values)
-        if type(values) in (set, list, tuple):
-            values = list(values)
-            tmp = {}
-            for k, v in zip(values[::2], values[1::2]):
-                try:
-                    tmp[k] = ast.literal_eval(v)
-                except (ValueError, SyntaxError):
-                    tmp[k] = v
-            return self.update(tmp)
-        return self.update(ast.literal_eval(values))
+    def __repr__(self):
+        return 'HParams(%r)' % (self.keyvals,)
 
-    def values(self):
-        return self.keyvals
-
-    def __str__(self):
-        return str(self.keyvals)
+    __str__ = lambda self: str(self.keyvals)

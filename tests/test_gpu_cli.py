@@ -14,16 +14,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _dataset(tmp_path, fmt):
+    """Built through the make_dataset command line (extras/make_dataset.py)."""
+    from asr_study_amd import cli
     from asr_study_amd.datasets import h5lite
-    from asr_study_amd.datasets.dummy import Dummy
-    from asr_study_amd.preprocessing import audio, text
     if fmt == 'h5' and not h5lite.available():
         fmt = 'npz'
-    ds = Dummy(num_speakers=4, num_utterances_per_speaker=6, max_duration=1.2, min_duration=0.6,
-               max_label_length=8, split=[0.5, 0.25], seed=3)
     fname = str(tmp_path / ('dummy.' + fmt))
-    ds.to_h5(fname, input_parser=audio.MFCC(dd=False), label_parser=text.simple_char_parser,
-             fmt=fmt)
+    cli.make_dataset_main(['--parser', 'dummy', '--parser_params', 'num_speakers', '4',
+                           'num_utterances_per_speaker', '6', 'max_duration', '1.2',
+                           'min_duration', '0.6', 'max_label_length', '8', 'split',
+                           '[0.5, 0.25]', 'seed', '3', '--input_parser', 'mfcc',
+                           '--input_parser_params', 'dd', 'False', '--output_file', fname])
     return fname
 
 
