@@ -17,6 +17,7 @@ reference's Keras layout: per Bidirectional layer [W (in,4H), U (H,4H), b (4H)] 
 the forward then the backward copy, gate blocks i,f,c,o; Dense [W, b].
 """
 import math
+import os
 import time
 
 import numpy as np
@@ -495,7 +496,10 @@ class Model(object):
 
     def _allreduce(self):
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (
+                dist.get_world_size() > 1 or os.environ.get('ASR_FORCE_ALLREDUCE') == '1'):
+            # RCCL orders itself after the kernels already enqueued on the current stream
+            # and the current stream after the collective (synchronous-op semantics)
             dist.all_reduce(self.grads)
             return dist.get_world_size()
         return 1

@@ -99,7 +99,8 @@ def main():
         raise SystemExit('bench.py needs a GPU (the hot path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    force_dist = os.environ.get('ASR_FORCE_ALLREDUCE') == '1'   # exercise RCCL at world 1 (tests)
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -133,25 +134,33 @@ def main():
     lab_d = torch.from_numpy(lab).to(dev)
     lab_len_d = torch.from_numpy(lab_len.astype(np.int32)).to(dev)
 
-    lstm_ev = []
+    lstm_ev = {'lstm_seq_fwd': [], 'lstm_seq_bwd': []}
+
+    def _timed(name):
+        orig = getattr(ops, name)
+
+        def timed(*a, **k):
+            # HIP events on the stream the kernel is launched on (torch's current stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            lstm_ev[name].append((e0, e1))
+            return r
+        return orig, timed
 
     def step(record=False):
         slab, frames = feat.batch_device(audio_d, offs, lens, host_lens)
         if record:
-            orig = ops.lstm_seq_fwd
-
-            def timed(*a, **k):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                r = orig(*a, **k)
-                e1.record()
-                lstm_ev.append((e0, e1))
-                return r
-            ops.lstm_seq_fwd = timed
+            saved = {}
+            for name in lstm_ev:
+                saved[name], wrapped = _timed(name)
+                setattr(ops, name, wrapped)
             try:
                 return model.train_step_device(slab, lab_d, lab_len_d, frames, N, world)
             finally:
-                ops.lstm_seq_fwd = orig
+                for name, fn in saved.items():
+                    setattr(ops, name, fn)
         return model.train_step_device(slab, lab_d, lab_len_d, frames, N, world)
 
     for _ in range(args.warmup):
@@ -203,7 +212,9 @@ def main():
         tg = ev_time(lambda: ops.gemm(xg, wg, zg, rows, 8 * H, 2 * H))
         gf = 2.0 * rows * 8 * H * 2 * H
         extra['roofline_gate_gemm'] = {
-            'kernel': 'gemm_f32_mfma_kernel %dx%dx%d (x@W, one BiLSTM layer)' % (rows, 8 * H, 2 * H),
+            'kernel': 'gemm_f16x2_kernel %dx%dx%d (x@W, one BiLSTM layer; split-fp16: 3 fp16 '
+                      'MFMAs per fp32 product, priced as fp32 flops against the fp32-MFMA peak)'
+                      % (rows, 8 * H, 2 * H),
             'bound': 'mfma', 'achieved': round(gf / tg / 1e9, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(gf / tg / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
             'avg_launch_ms': round(tg, 4)}
@@ -225,11 +236,33 @@ def main():
         n_pad = ops.pad16(N)
         ms = dt / args.steps * 1e3
         value = world * N * 10.0 / (dt / args.steps)
-        lstm_ms = float(np.mean([a.elapsed_time(b) for a, b in lstm_ev])) if lstm_ev else None
-        # dominant kernel: the persistent recurrent forward kernel (one launch per
-        # layer): algorithmic flops = 2 * T * n_pad * 2 dirs * H * 4H
+        def avg_ms(name):
+            ev = lstm_ev[name]
+            return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+        fwd_ms, bwd_ms = avg_ms('lstm_seq_fwd'), avg_ms('lstm_seq_bwd')
+        # dominant kernels: the persistent recurrent kernels (one launch per layer and
+        # pass, both directions).  Algorithmic flops per launch = 2*T*n_pad*2 dirs*H*4H
+        # (h@U forward, dz@U^T in BPTT); algorithmic HBM bytes per launch:
+        # fwd reads zx, writes y+cell+gates; bwd reads dy+gates+cell, writes dz.
         flops = 2.0 * T * n_pad * 2 * H * 4 * H
-        ach = flops / (lstm_ms * 1e-3) / 1e12 if lstm_ms else None
+        slab_b = 4.0 * T * n_pad * 2 * H
+        alg_bytes = {'fwd': 4 * slab_b + slab_b + slab_b + 4 * slab_b,
+                     'bwd': slab_b + 4 * slab_b + slab_b + 4 * slab_b}
+        # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE),
+        # profiles/r1c_bench_cfg2_hbm_traffic.md; measured at cfg2 only
+        pmc = {'cfg2': {'fwd': 643.94e6, 'bwd': 647.85e6}}.get(args.config, {})
+
+        def roof(kind, ms, kernel):
+            ach = flops / (ms * 1e-3) / 1e12 if ms else None
+            return {'kernel': kernel, 'bound': 'mfma', 'achieved': round(ach, 3) if ach else None,
+                    'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
+                    'traffic': pmc.get(kind), 'algorithmic_bytes': alg_bytes[kind],
+                    'avg_launch_ms': round(ms, 4) if ms else None,
+                    'us_per_timestep': round(ms * 1e3 / T, 3) if ms else None,
+                    'flops_per_launch': flops,
+                    'note': 'latency-bound recurrence (T dependent steps, cross-workgroup '
+                            'hand-off per step): see DESIGN.md 5 for the per-step anatomy'}
         line = {
             'metric': 'audio-seconds/sec trained (MFCC+BiLSTM+CTC)',
             'value': round(value, 1), 'unit': 'audio-seconds/s', 'n_gpus': world,
@@ -240,19 +273,16 @@ def main():
                        'global_batch': world * N, 'utterance_seconds': 10.0, 'frames': T,
                        'dropout': args.dropout, 'optimizer': 'adam(clipnorm=400)',
                        'parallelism': 'dp%d' % world, 'params': model.count_params()},
-            'roofline': {'kernel': 'lstm_fwd_kernel (persistent recurrent BiLSTM layer)',
-                         'bound': 'mfma', 'achieved': round(ach, 3) if ach else None,
-                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
-                         'traffic': None,
-                         'avg_launch_ms': round(lstm_ms, 4) if lstm_ms else None,
-                         'flops_per_launch': flops},
+            'roofline': roof('bwd', bwd_ms, 'lstm_bwd_kernel_h (persistent BPTT of one BiLSTM '
+                                            'layer, both directions)'),
+            'roofline_lstm_fwd': roof('fwd', fwd_ms, 'lstm_fwd_kernel_h (persistent forward '
+                                                     'recurrence of one BiLSTM layer)'),
         }
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 
