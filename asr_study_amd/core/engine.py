@@ -253,6 +253,7 @@ class Model(object):
         rows = T * n_pad
         a = x
         self._acts = []
+        drawn = None
         for si, s in enumerate(self.stages):
             rec = {'in': a}
             if s.kind == 'noise':
@@ -276,7 +277,9 @@ class Model(object):
                 if masks is not None and si in masks:
                     BW, BU = masks[si]
                 elif training and (s.dropout_W > 0 or s.dropout_U > 0):
-                    BW, BU = self._draw_masks(s, n_pad)
+                    if drawn is None:
+                        drawn = self._draw_all_masks(n_pad)
+                    BW, BU = drawn[si]
                 rec['BW'], rec['BU'] = BW, BU
                 zx = self._buf('zx', (T, n_pad, 2, 4 * Hp))
                 bias = self._view(s.ob, 8 * Hp)
@@ -300,13 +303,38 @@ class Model(object):
             self._acts.append(rec)
         return a
 
-    def _draw_masks(self, s, n_pad):
-        def draw(shape, p):
-            if p <= 0:
-                return torch.ones(shape, dtype=torch.float32, device=self.device)
-            keep = torch.rand(shape, generator=self._rng, device=self.device) >= p
-            return keep.to(torch.float32) / (1.0 - p)
-        return (draw((2, n_pad, s.f_in_pad), s.dropout_W), draw((2, n_pad, s.Hp), s.dropout_U))
+    def _draw_all_masks(self, n_pad):
+        """Variational-dropout masks of every BiLSTM stage for one batch, drawn with ONE
+        uniform fill + one select over a flat buffer (per-element drop probabilities and
+        1/(1-p) scales are cached): {stage: (B_W (2, n_pad, in), B_U (2, n_pad, H))}."""
+        plan = self._mask_plan.get(n_pad) if hasattr(self, '_mask_plan') else None
+        if plan is None:
+            if not hasattr(self, '_mask_plan'):
+                self._mask_plan = {}
+            segs, pvals, off = [], [], 0
+            for si, s in enumerate(self.stages):
+                if s.kind != 'bilstm' or not (s.dropout_W > 0 or s.dropout_U > 0):
+                    continue
+                nw, nu = 2 * n_pad * s.f_in_pad, 2 * n_pad * s.Hp
+                segs.append((si, off, nw, nu, s.f_in_pad, s.Hp))
+                pvals += [(nw, s.dropout_W), (nu, s.dropout_U)]
+                off += nw + nu
+            if off == 0:
+                plan = (segs, None, None, 0)
+            else:
+                p = torch.cat([torch.full((n,), float(v)) for n, v in pvals]).to(self.device)
+                plan = (segs, p, 1.0 / (1.0 - p), off)
+            self._mask_plan[n_pad] = plan
+        segs, p, scale, total = plan
+        if total == 0:
+            return {}
+        u = torch.rand(total, generator=self._rng, device=self.device)
+        flat = torch.where(u >= p, scale, torch.zeros((), device=self.device))
+        out = {}
+        for si, off, nw, nu, fin, Hp in segs:
+            out[si] = (flat[off:off + nw].view(2, n_pad, fin),
+                       flat[off + nw:off + nw + nu].view(2, n_pad, Hp))
+        return out
 
     # ------------------------------------------------------------------ backward
     def backward(self, dlogits):
@@ -369,7 +397,7 @@ class Model(object):
                 flush_side()        # previous layer's dW/dU/db now overlap this BPTT
                 y = rec['y']
 
-                def weight_grads(wsn, s=s, dz=dz, y=y, a_in=a_in, BW=BW, BU=BU, Hp=Hp, zmx=zmx):
+                def grads_U(wsn, s=s, dz=dz, y=y, BU=BU, Hp=Hp, zmx=zmx):
                     # dU[d] = (h_prev (.) B_U)^T dz[d]: h_prev is y shifted by one step in
                     # the direction's processing order (zero at its first step)
                     kk = (T - 1) * n_pad
@@ -384,6 +412,8 @@ class Model(object):
                                      a_scale_period=n_pad, ws_name=wsn, b_absmax=zmx)
                         else:
                             self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
+
+                def grads_W(wsn, s=s, dz=dz, a_in=a_in, BW=BW, Hp=Hp, zmx=zmx):
                     # dW = (x (.) B_W)^T dz, db = colsum(dz)
                     if BW is None:
                         ops.gemm(a_in, dz, self.grads, s.f_in_pad, 8 * Hp, rows, trans_a=True,
@@ -397,12 +427,10 @@ class Model(object):
                     ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp),
                                ws_name=wsn + '_cs')
 
-                if self.overlap:
-                    ready = torch.cuda.Event()
-                    ready.record(main)
-                    pending.append((weight_grads, ready, par))
-                else:
-                    weight_grads('gemm')
+                def weight_grads(wsn, gu=grads_U, gw=grads_W):
+                    gu(wsn)
+                    gw(wsn)
+
                 if not first:
                     dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
                     if BW is None:
@@ -414,6 +442,22 @@ class Model(object):
                                      lda=8 * Hp, ldb=8 * Hp, a_off=d * 4 * Hp,
                                      b_off=s.oW + d * 4 * Hp, beta=0.0 if d == 0 else 1.0,
                                      c_scale=BW[d], c_scale_period=n_pad, a_absmax=zmx)
+                    da = dx
+                if not self.overlap:
+                    weight_grads('gemm')
+                elif first:
+                    # nothing left to hide behind: share the tail between both streams
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    pending.append((grads_U, ready, par))
+                    flush_side()
+                    grads_W('gemm')
+                else:
+                    # the side stream starts once the dX GEMMs (critical path) are done,
+                    # i.e. together with the next layer's BPTT kernel
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    pending.append((weight_grads, ready, par))
                     da = dx
         flush_side()
         if self.overlap and self._side is not None:

@@ -33,7 +33,13 @@ struct TileSrc {
   const float* scale;  // optional mask over storage (row % period, col)
   int period, scale_ld;
   int vec_ok;          // 16-byte aligned rows
+  int scale_vec;       // mask rows 16-byte aligned as well
 };
+
+// row % period; the period is n_pad (a multiple of 16, in practice a power of two)
+__device__ __forceinline__ int mod_period(int row, int period) {
+  return (period & (period - 1)) == 0 ? (row & (period - 1)) : row % period;
+}
 
 // Loads the (BK x 128) tile starting at (k0, mn0) into BK/8 float4 registers.
 template <int BK>
@@ -57,9 +63,14 @@ __device__ __forceinline__ void tile_load(const TileSrc& s, int k0, int mn0, int
           for (int e = 0; e < 4; ++e) if (mn + e < s.mn_total) v[e] = src[e];
         }
         if (s.scale) {
-          const float* sc = s.scale + (size_t)(k % s.period) * s.scale_ld + mn;
+          const float* sc = s.scale + (size_t)mod_period(k, s.period) * s.scale_ld + mn;
+          if (s.scale_vec && mn + 3 < s.mn_total) {
+            const float4 q = *reinterpret_cast<const float4*>(sc);
+            v[0] *= q.x; v[1] *= q.y; v[2] *= q.z; v[3] *= q.w;
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (mn + e < s.mn_total) v[e] *= sc[e];
+            for (int e = 0; e < 4; ++e) if (mn + e < s.mn_total) v[e] *= sc[e];
+          }
         }
       }
     } else {
@@ -78,9 +89,14 @@ __device__ __forceinline__ void tile_load(const TileSrc& s, int k0, int mn0, int
           for (int e = 0; e < 4; ++e) if (k + e < k_end) v[e] = src[e];
         }
         if (s.scale) {
-          const float* sc = s.scale + (size_t)(mn % s.period) * s.scale_ld + k;
+          const float* sc = s.scale + (size_t)mod_period(mn, s.period) * s.scale_ld + k;
+          if (s.scale_vec && k + 3 < k_end) {
+            const float4 q = *reinterpret_cast<const float4*>(sc);
+            v[0] *= q.x; v[1] *= q.y; v[2] *= q.z; v[3] *= q.w;
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (k + e < k_end) v[e] *= sc[e];
+            for (int e = 0; e < 4; ++e) if (k + e < k_end) v[e] *= sc[e];
+          }
         }
       }
     }
@@ -195,7 +211,7 @@ gemm_f32_mfma_kernel(TileSrc A, TileSrc B, int M, int N, int K, int k_per_split,
           v *= ep.alpha;
           float* dst = ep.C + (size_t)row * ep.ldc + col;
           if (ep.bias) v += ep.bias[col];
-          if (ep.c_scale) v *= ep.c_scale[(size_t)(row % ep.c_period) * ep.c_ld + col];
+          if (ep.c_scale) v *= ep.c_scale[(size_t)mod_period(row, ep.c_period) * ep.c_ld + col];
           if (ep.beta != 0.f) v += ep.beta * *dst;
           *dst = v;
         }
@@ -215,7 +231,7 @@ gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, 
     v *= ep.alpha;
     float* dst = ep.C + (size_t)row * ep.ldc + col;
     if (ep.bias) v += ep.bias[col];
-    if (ep.c_scale) v *= ep.c_scale[(size_t)(row % ep.c_period) * ep.c_ld + col];
+    if (ep.c_scale) v *= ep.c_scale[(size_t)mod_period(row, ep.c_period) * ep.c_ld + col];
     if (ep.beta != 0.f) v += ep.beta * *dst;
     *dst = v;
   }
@@ -278,9 +294,14 @@ __device__ __forceinline__ void h_tile_load(const TileSrc& s, int k0, int mn0, i
           for (int e = 0; e < 4; ++e) if (mn + e < s.mn_total) t[e] = src[e];
         }
         if (s.scale) {
-          const float* sc = s.scale + (size_t)(k % s.period) * s.scale_ld + mn;
+          const float* sc = s.scale + (size_t)mod_period(k, s.period) * s.scale_ld + mn;
+          if (s.scale_vec && mn + 3 < s.mn_total) {
+            const float4 q = *reinterpret_cast<const float4*>(sc);
+            t[0] *= q.x; t[1] *= q.y; t[2] *= q.z; t[3] *= q.w;
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (mn + e < s.mn_total) t[e] *= sc[e];
+            for (int e = 0; e < 4; ++e) if (mn + e < s.mn_total) t[e] *= sc[e];
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) f[0].v[r][c] = t[r];
@@ -304,9 +325,14 @@ __device__ __forceinline__ void h_tile_load(const TileSrc& s, int k0, int mn0, i
           for (int e = 0; e < 4; ++e) if (k + e < k_end) t[e] = src[e];
         }
         if (s.scale) {
-          const float* sc = s.scale + (size_t)(mn % s.period) * s.scale_ld + k;
+          const float* sc = s.scale + (size_t)mod_period(mn, s.period) * s.scale_ld + k;
+          if (s.scale_vec && k + 3 < k_end) {
+            const float4 q = *reinterpret_cast<const float4*>(sc);
+            t[0] *= q.x; t[1] *= q.y; t[2] *= q.z; t[3] *= q.w;
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (k + e < k_end) t[e] *= sc[e];
+            for (int e = 0; e < 4; ++e) if (k + e < k_end) t[e] *= sc[e];
+          }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) f[0].v[r][c] = t[c];
@@ -431,7 +457,7 @@ gemm_f16x2_kernel(TileSrc A, TileSrc B, int M, int N, int K, int k_per_split, Ep
           v *= ep.alpha;
           float* dst = ep.C + (size_t)row * ep.ldc + col;
           if (ep.bias) v += ep.bias[col];
-          if (ep.c_scale) v *= ep.c_scale[(size_t)(row % ep.c_period) * ep.c_ld + col];
+          if (ep.c_scale) v *= ep.c_scale[(size_t)mod_period(row, ep.c_period) * ep.c_ld + col];
           if (ep.beta != 0.f) v += ep.beta * *dst;
           *dst = v;
         }
@@ -523,10 +549,11 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
   A.mn_total = a->M; A.k_total = a->K;
   A.scale = a->a_scale; A.period = a->a_scale_period > 0 ? a->a_scale_period : 1;
   A.scale_ld = a->a_scale_ld;
+  A.scale_vec = a->a_scale && (a->a_scale_ld % 4 == 0) && aligned16(a->a_scale);
   A.vec_ok = (a->lda % 4 == 0) && aligned16(a->A);
   B.p = a->B; B.ld = a->ldb; B.mn_contig = a->trans_b ? 0 : 1;
   B.mn_total = a->N; B.k_total = a->K;
-  B.scale = nullptr; B.period = 1; B.scale_ld = 0;
+  B.scale = nullptr; B.period = 1; B.scale_ld = 0; B.scale_vec = 0;
   B.vec_ok = (a->ldb % 4 == 0) && aligned16(a->B);
   ASR_CHECK_ARG(a->lda >= (a->trans_a ? a->M : a->K), "gemm: lda too small");
   ASR_CHECK_ARG(a->ldb >= (a->trans_b ? a->K : a->N), "gemm: ldb too small");

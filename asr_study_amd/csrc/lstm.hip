@@ -445,15 +445,17 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
         if (use[i]) {
           const int grp = tid + i * kThreads;
           const int gu = grp >> 4, gn = grp & 15;
-          h4 hi4, lo4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            _Float16 a, b;
-            split_f16(__uint_as_float(v[i][e] & ~1u), a, b);
-            hi4[e] = a; lo4[e] = b;
-          }
-          *reinterpret_cast<h4*>(th + gn * HS + 4 * gu) = hi4;
-          *reinterpret_cast<h4*>(tl + gn * HS + 4 * gu) = lo4;
+          // exchanged word = fp16 hi << 16 | fp16 lo (split once, by the producer);
+          // the tag sits in lo's LSB and is cleared so that zeros stay exact zeros
+          const unsigned a0 = v[i][0] & ~1u, a1 = v[i][1] & ~1u;
+          const unsigned a2 = v[i][2] & ~1u, a3 = v[i][3] & ~1u;
+          uint2 hi2, lo2;
+          hi2.x = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+          hi2.y = __builtin_amdgcn_perm(a3, a2, 0x07060302u);
+          lo2.x = __builtin_amdgcn_perm(a1, a0, 0x05040100u);
+          lo2.y = __builtin_amdgcn_perm(a3, a2, 0x05040100u);
+          *reinterpret_cast<uint2*>(th + gn * HS + 4 * gu) = hi2;
+          *reinterpret_cast<uint2*>(tl + gn * HS + 4 * gu) = lo2;
         }
       }
       __syncthreads();
@@ -493,7 +495,10 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
       const float h = go * fast_tanh(c);
       if (s + 1 < p.T) {
         const unsigned wtag = (unsigned)((s - p.s_begin) >> 1) & 1u;
-        const unsigned w0 = tag_word(h * mask, wtag);
+        _Float16 ph, pl;
+        split_f16(h * mask, ph, pl);
+        const unsigned w0 = ((((unsigned)__builtin_bit_cast(unsigned short, ph) << 16) |
+                              (unsigned)__builtin_bit_cast(unsigned short, pl)) & ~1u) | wtag;
         u32x4 o;
         o[0] = w0;
         o[1] = (unsigned)__shfl_down((int)w0, 16, 64);
@@ -742,8 +747,8 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
   const int P = p.P;
   const int dir = chain / p.NB, bt = chain % p.NB;
   constexpr int DZH = 72;                         // LDS row stride of the dz tiles (halfs)
-  float* part = lds;                              // [P][256] gathered partial dh
-  float* sinv = lds + (size_t)P * 256;            // [16] 1/scale per batch column
+  float* part = lds;                              // [4 waves][256] partial dh sums
+  float* sinv = lds + 4 * 256;                    // [16] 1/scale per batch column
   _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZH] hi
   _Float16* dzl = dzh + 16 * DZH;                           // [16][DZH] lo
 
@@ -819,17 +824,20 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
       gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64);
       if (prof) tk1 = wall_clock64();
       load_slabs(s + 1);
+      // wave w holds producers w, w+4, ...: add them in registers, then 4 partial
+      // tiles (one per wave) meet in LDS instead of P
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         if (use[i]) {
-          *reinterpret_cast<float4*>(part + 4 * (tid + i * kThreads)) =
-              make_float4(__uint_as_float(v[i][0] & ~1u), __uint_as_float(v[i][1] & ~1u),
-                          __uint_as_float(v[i][2] & ~1u), __uint_as_float(v[i][3] & ~1u));
+          acc.x += __uint_as_float(v[i][0] & ~1u); acc.y += __uint_as_float(v[i][1] & ~1u);
+          acc.z += __uint_as_float(v[i][2] & ~1u); acc.w += __uint_as_float(v[i][3] & ~1u);
         }
       }
+      *reinterpret_cast<float4*>(part + 4 * tid) = acc;
       __syncthreads();
       if (prof) tk2 = wall_clock64();
-      for (int pr = 0; pr < P; ++pr) dh_rec += part[pr * 256 + tid];
+      dh_rec = (part[tid] + part[256 + tid]) + (part[512 + tid] + part[768 + tid]);
     } else {
       load_slabs(s + 1);
     }
@@ -1030,7 +1038,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     pl.xchain_words = (size_t)2 * pl.P * pl.P * 256;
     k = pick_bwd(pl.TPW);
     if (pl.prec == 1) {
-      pl.shm = (size_t)(pl.P * 256 + 16) * 4 + (size_t)2 * 16 * 72 * 2;
+      pl.shm = (size_t)(4 * 256 + 16) * 4 + (size_t)2 * 16 * 72 * 2;
       k = pick_bwd_h(pl.TPW);
     }
   }
