@@ -42,7 +42,8 @@ class LstmArgs(C.Structure):
     _fields_ = [('T', C.c_int), ('n_pad', C.c_int), ('H', C.c_int), ('mode', C.c_int),
                 ('U', void_p), ('mask_u', void_p),
                 ('zx', void_p), ('y', void_p), ('cell', void_p), ('gates', void_p),
-                ('dy', void_p), ('dz', void_p), ('dz_absmax', void_p)]
+                ('dy', void_p), ('dz', void_p), ('dz_absmax', void_p),
+                ('step_begin', C.c_int), ('step_count', C.c_int)]
 
 
 class Segment(C.Structure):

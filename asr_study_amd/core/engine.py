@@ -69,6 +69,10 @@ class Model(object):
         import os as _os
         self.overlap = _os.environ.get('ASR_OVERLAP', '1') != '0'
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        # the GEMMs either side of a recurrence are pipelined against its last quarter
+        # (frames whose both directions are already final), on a third stream
+        self.pipeline = self.overlap and _os.environ.get('ASR_PIPELINE', '0') == '1'
+        self._pipe = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         self._rng = torch.Generator(device=self.device)
         self._rng.manual_seed(int(seed) + 12345)
         self._layout(seed)
@@ -253,7 +257,21 @@ class Model(object):
         rows = T * n_pad
         a = x
         self._acts = []
-        drawn = None
+        drawn = [None]
+        nb = 0
+        pipe = self.pipeline and self._pipe is not None and self.lstm_mode == 0 and T >= 16
+        S = (3 * T) // 4
+        pre = {}
+
+        def stage_masks(i):
+            st = self.stages[i]
+            if masks is not None and i in masks:
+                return masks[i]
+            if training and (st.dropout_W > 0 or st.dropout_U > 0):
+                if drawn[0] is None:
+                    drawn[0] = self._draw_all_masks(n_pad)
+                return drawn[0][i]
+            return None, None
         for si, s in enumerate(self.stages):
             rec = {'in': a}
             if s.kind == 'noise':
@@ -273,35 +291,80 @@ class Model(object):
                 a = out
             elif s.kind == 'bilstm':
                 Hp = s.Hp
-                BW = BU = None
-                if masks is not None and si in masks:
-                    BW, BU = masks[si]
-                elif training and (s.dropout_W > 0 or s.dropout_U > 0):
-                    if drawn is None:
-                        drawn = self._draw_all_masks(n_pad)
-                    BW, BU = drawn[si]
+                BW, BU = stage_masks(si)
                 rec['BW'], rec['BU'] = BW, BU
-                zx = self._buf('zx', (T, n_pad, 2, 4 * Hp))
-                bias = self._view(s.ob, 8 * Hp)
-                if BW is None:
-                    ops.gemm(a, self.params, zx, rows, 8 * Hp, s.f_in_pad, b_off=s.oW, bias=bias)
-                else:       # each direction has its own input mask (two Keras layers)
-                    for d in range(2):
-                        ops.gemm(a, self.params, zx, rows, 4 * Hp, s.f_in_pad,
-                                 ldb=8 * Hp, ldc=8 * Hp, b_off=s.oW + d * 4 * Hp,
-                                 c_off=d * 4 * Hp, bias=bias[d * 4 * Hp:(d + 1) * 4 * Hp],
-                                 a_scale=BW[d], a_scale_period=n_pad)
+                zx = self._buf('zx%d_%d' % (nb % 2, Hp), (T, n_pad, 2, 4 * Hp))
+                nb += 1
+                main = torch.cuda.current_stream(self.device)
+                inner_done = pre.pop(si, None)
+                if inner_done is None:
+                    self._gate_gemm(a, s, zx, BW, 0, rows, n_pad)
+                else:       # frames [T-S, S) were projected while the previous layer ran
+                    self._gate_gemm(a, s, zx, BW, 0, (T - S) * n_pad, n_pad)
+                    self._gate_gemm(a, s, zx, BW, S * n_pad, rows, n_pad)
+                    main.wait_event(inner_done)
                 y = self._buf('y%d' % si, (T, n_pad, 2 * Hp))
                 cell = self._buf('cell%d' % si, (T, n_pad, 2, Hp))
                 gates = self._buf('gates%d' % si, (T, n_pad, 2, 4 * Hp))
                 U = self._view(s.oU, 2 * Hp * 4 * Hp)
-                rec['ws'] = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
-                                             mode=self.lstm_mode)
+                nxt = self.stages[si + 1] if si + 1 < len(self.stages) else None
+                if pipe and nxt is not None and nxt.kind == 'bilstm':
+                    # after S = 3T/4 steps the frames [T-S, S) of y are final in BOTH
+                    # directions: the next layer's input projection of those frames runs
+                    # on the pipe stream while this recurrence finishes its last quarter
+                    ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
+                                     mode=self.lstm_mode, steps=(0, S))
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    zx_n = self._buf('zx%d_%d' % (nb % 2, nxt.Hp), (T, n_pad, 2, 4 * nxt.Hp))
+                    with torch.cuda.stream(self._pipe):
+                        self._pipe.wait_event(ev)
+                        self._gate_gemm(y, nxt, zx_n, stage_masks(si + 1)[0], (T - S) * n_pad,
+                                        S * n_pad, n_pad)
+                        done = torch.cuda.Event()
+                        done.record(self._pipe)
+                    pre[si + 1] = done
+                    rec['ws'] = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
+                                                 mode=self.lstm_mode, steps=(S, T - S))
+                else:
+                    rec['ws'] = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
+                                                 mode=self.lstm_mode)
                 rec.update(y=y, cell=cell, gates=gates)
                 a = y
             rec['out'] = a
             self._acts.append(rec)
         return a
+
+    def _gate_gemm(self, a, s, zx, BW, r0, r1, n_pad):
+        """zx[r0:r1] = (a[r0:r1] (.) B_W) @ W + b over slab rows [r0, r1) (whole frames)."""
+        m, Hp = r1 - r0, s.Hp
+        if m <= 0:
+            return
+        bias = self._view(s.ob, 8 * Hp)
+        if BW is None:
+            ops.gemm(a, self.params, zx, m, 8 * Hp, s.f_in_pad, a_off=r0 * s.f_in_pad,
+                     b_off=s.oW, c_off=r0 * 8 * Hp, bias=bias)
+            return
+        for d in range(2):      # each direction has its own input mask (two Keras layers)
+            ops.gemm(a, self.params, zx, m, 4 * Hp, s.f_in_pad, ldb=8 * Hp, ldc=8 * Hp,
+                     a_off=r0 * s.f_in_pad, b_off=s.oW + d * 4 * Hp,
+                     c_off=r0 * 8 * Hp + d * 4 * Hp, bias=bias[d * 4 * Hp:(d + 1) * 4 * Hp],
+                     a_scale=BW[d], a_scale_period=n_pad)
+
+    def _dx_gemm(self, dz, s, dx, BW, r0, r1, n_pad, zmx):
+        """dx[r0:r1] = sum_d B_W[d] (.) (dz_d[r0:r1] @ W_d^T) over slab rows [r0, r1)."""
+        m, Hp = r1 - r0, s.Hp
+        if m <= 0:
+            return
+        if BW is None:
+            ops.gemm(dz, self.params, dx, m, s.f_in_pad, 8 * Hp, trans_b=True,
+                     a_off=r0 * 8 * Hp, b_off=s.oW, c_off=r0 * s.f_in_pad, a_absmax=zmx)
+            return
+        for d in range(2):
+            ops.gemm(dz, self.params, dx, m, s.f_in_pad, 4 * Hp, trans_b=True, lda=8 * Hp,
+                     ldb=8 * Hp, a_off=r0 * 8 * Hp + d * 4 * Hp, b_off=s.oW + d * 4 * Hp,
+                     c_off=r0 * s.f_in_pad, beta=0.0 if d == 0 else 1.0, c_scale=BW[d],
+                     c_scale_period=n_pad, a_absmax=zmx)
 
     def _draw_all_masks(self, n_pad):
         """Variational-dropout masks of every BiLSTM stage for one batch, drawn with ONE
@@ -392,9 +455,32 @@ class Model(object):
                     main.wait_event(self._dz_free[par])
                 U = self._view(s.oU, 2 * Hp * 4 * Hp)
                 zmx = self._buf('dzmax%d' % par, (1,))
-                rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp,
-                                               mask_u=BU, mode=self.lstm_mode, dz_absmax=zmx)
-                flush_side()        # previous layer's dW/dU/db now overlap this BPTT
+                pipe_b = (self.pipeline and self._pipe is not None and not first
+                          and self.lstm_mode == 0 and T >= 16)
+                S = (3 * T) // 4
+                dx = None
+                if pipe_b:
+                    # after S BPTT steps the gate gradients of frames [T-S, S) are final
+                    # in both directions: their dX GEMMs overlap the last quarter
+                    dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
+                    ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp,
+                                     mask_u=BU, mode=self.lstm_mode, dz_absmax=zmx, steps=(0, S))
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    flush_side()    # previous layer's dW/dU/db now overlap this BPTT
+                    with torch.cuda.stream(self._pipe):
+                        self._pipe.wait_event(ev)
+                        self._dx_gemm(dz, s, dx, BW, (T - S) * n_pad, S * n_pad, n_pad, zmx)
+                        dx_inner = torch.cuda.Event()
+                        dx_inner.record(self._pipe)
+                    rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad,
+                                                   Hp, mask_u=BU, mode=self.lstm_mode,
+                                                   dz_absmax=zmx, steps=(S, T - S))
+                else:
+                    rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad,
+                                                   Hp, mask_u=BU, mode=self.lstm_mode,
+                                                   dz_absmax=zmx)
+                    flush_side()    # previous layer's dW/dU/db now overlap this BPTT
                 y = rec['y']
 
                 def grads_U(wsn, s=s, dz=dz, y=y, BU=BU, Hp=Hp, zmx=zmx):
@@ -431,17 +517,14 @@ class Model(object):
                     gu(wsn)
                     gw(wsn)
 
-                if not first:
+                if pipe_b:
+                    self._dx_gemm(dz, s, dx, BW, 0, (T - S) * n_pad, n_pad, zmx)
+                    self._dx_gemm(dz, s, dx, BW, S * n_pad, rows, n_pad, zmx)
+                    main.wait_event(dx_inner)
+                    da = dx
+                elif not first:
                     dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
-                    if BW is None:
-                        ops.gemm(dz, self.params, dx, rows, s.f_in_pad, 8 * Hp, trans_b=True,
-                                 b_off=s.oW, a_absmax=zmx)
-                    else:   # dx = sum_d B_W[d] (.) (dz_d @ W_d^T)
-                        for d in range(2):
-                            ops.gemm(dz, self.params, dx, rows, s.f_in_pad, 4 * Hp, trans_b=True,
-                                     lda=8 * Hp, ldb=8 * Hp, a_off=d * 4 * Hp,
-                                     b_off=s.oW + d * 4 * Hp, beta=0.0 if d == 0 else 1.0,
-                                     c_scale=BW[d], c_scale_period=n_pad, a_absmax=zmx)
+                    self._dx_gemm(dz, s, dx, BW, 0, rows, n_pad, zmx)
                     da = dx
                 if not self.overlap:
                     weight_grads('gemm')

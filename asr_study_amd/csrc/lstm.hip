@@ -30,8 +30,9 @@
 //    16-byte group is its own flag -- no fences, no flags, placement independent
 //    (MI355X guide, Guideline 16 / R2 "the data IS the flag").  Two slots (step
 //    parity) suffice: a producer is at most one step ahead of its slowest
-//    consumer, so a slot holds step s or s-2, which differ in bit (s>>1)&1.  The
-//    buffer is memset to 0xFF (tag 1) before each launch.  Transport: agent-scope
+//    consumer, so a slot holds step s or s-2, which differ in bit (s>>1)&1 (absolute
+//    step number, so a sequence may be continued by a later launch).  The buffer is
+//    memset to 0xFF (tag 1) before step 0.  Transport: agent-scope
 //    (sc1, write-through) stores + sc1 loads.  If -- and only if -- every
 //    workgroup of a chain reports the same XCC id at kernel start, the chain
 //    switches to plain stores + L1-bypassing (nt) loads served by that XCD's L2;
@@ -252,7 +253,7 @@ __device__ __forceinline__ void fwd_body(const LstmParams& p, int chain, int wg,
     if (s > 0) {
       // ---- gather h_{s-1} (already masked by its producer) into LDS, once per WG
       float* hbuf = hbuf0 + (s & 1) * hb_words;
-      const unsigned tag = (unsigned)((s - 1 - p.s_begin) >> 1) & 1u;
+      const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
       __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)((s - 1) & 1) * slot_words, 0, slot_words * 4, 0x00020000);
       unsigned off[NL];
@@ -317,7 +318,7 @@ __device__ __forceinline__ void fwd_body(const LstmParams& p, int chain, int wg,
       if (s + 1 < p.T) {
         // lanes nl, nl+16, nl+32, nl+48 hold units 4ug..4ug+3 of sample nl: collect
         // them in lane nl so the wave publishes ONE contiguous 256-byte tile
-        const unsigned wtag = (unsigned)((s - p.s_begin) >> 1) & 1u;
+        const unsigned wtag = (unsigned)(s >> 1) & 1u;
         const unsigned w0 = tag_word(h * mask, wtag);
         u32x4 o;
         o[0] = w0;
@@ -425,7 +426,7 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
     if (s > 0) {
       _Float16* th = hb + (size_t)(s & 1) * 2 * tile_halfs;      // hi tile, lo tile follows
       _Float16* tl = th + tile_halfs;
-      const unsigned tag = (unsigned)((s - 1 - p.s_begin) >> 1) & 1u;
+      const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
       __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)((s - 1) & 1) * slot_words, 0, slot_words * 4, 0x00020000);
       unsigned off[NL];
@@ -494,7 +495,7 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
       c = gf * c + gi * gg;
       const float h = go * fast_tanh(c);
       if (s + 1 < p.T) {
-        const unsigned wtag = (unsigned)((s - p.s_begin) >> 1) & 1u;
+        const unsigned wtag = (unsigned)(s >> 1) & 1u;
         _Float16 ph, pl;
         split_f16(h * mask, ph, pl);
         const unsigned w0 = ((((unsigned)__builtin_bit_cast(unsigned short, ph) << 16) |
@@ -611,7 +612,7 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
     float dh_rec = 0.f;
     if (s > 0) {
       // ---- gather the partial dh tiles addressed to this WG: [P prod][16 n][16 u]
-      const unsigned tag = (unsigned)((s - 1 - p.s_begin) >> 1) & 1u;
+      const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
       __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)((s - 1) & 1) * slot_words + (size_t)cw * P * 256, 0, P * 256 * 4,
           0x00020000);
@@ -675,7 +676,7 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
           bv[4 * q] = d4.x; bv[4 * q + 1] = d4.y; bv[4 * q + 2] = d4.z; bv[4 * q + 3] = d4.w;
         }
       }
-      const unsigned wtag = (unsigned)((s - p.s_begin) >> 1) & 1u;
+      const unsigned wtag = (unsigned)(s >> 1) & 1u;
       __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)(s & 1) * slot_words, 0, (unsigned)(slot_words * 4), 0x00020000);
       // straight-line: tile i's publish is issued as soon as its 16 MFMAs retire and
@@ -808,7 +809,7 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
     const float4 gt = nx_g;
     float dh_rec = 0.f;
     if (s > 0) {
-      const unsigned tag = (unsigned)((s - 1 - p.s_begin) >> 1) & 1u;
+      const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
       __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)((s - 1) & 1) * slot_words + (size_t)cw * P * 256, 0, P * 256 * 4,
           0x00020000);
@@ -888,7 +889,7 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
         bl[kk] = *reinterpret_cast<const h8*>(dzl + nl * DZH + 32 * kk + 8 * g);
       }
       const float us = sinv[nl];
-      const unsigned wtag = (unsigned)((s - p.s_begin) >> 1) & 1u;
+      const unsigned wtag = (unsigned)(s >> 1) & 1u;
       __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)(s & 1) * slot_words, 0, (unsigned)(slot_words * 4), 0x00020000);
       u32x4 o[TPW];
@@ -1043,6 +1044,11 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     }
   }
   if (pl.shm < (size_t)pl.P * 4 + 16) pl.shm = (size_t)pl.P * 4 + 16;
+  // Own the CU: a latency-bound workgroup must not share its SIMDs / LDS pipe with the
+  // GEMM workgroups (80 KB LDS each) that the host overlaps on a second stream, so it
+  // reserves enough LDS that none of those fits beside it (ASR_LSTM_EXCL=0 disables).
+  static const int excl = env_int("ASR_LSTM_EXCL", 1);
+  if (excl && pl.shm < (size_t)96 * 1024) pl.shm = (size_t)96 * 1024;
   if (pl.shm > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)pl.shm) != hipSuccess) {
@@ -1115,28 +1121,41 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.U = a->U; p.mask_u = a->mask_u; p.zx = a->zx; p.y = a->y; p.cell = a->cell;
   p.gates = a->gates; p.dy = a->dy; p.dz = a->dz;
   p.dz_absmax = bwd ? reinterpret_cast<unsigned*>(a->dz_absmax) : nullptr;
-  if (p.dz_absmax) ASR_CHECK_HIP(hipMemsetAsync(p.dz_absmax, 0, sizeof(unsigned), stream));
   p.status = reinterpret_cast<int*>(ws);
   p.xcc = reinterpret_cast<int*>(ws + kStatusBytes);
   p.xbuf = reinterpret_cast<unsigned*>(ws + kStatusBytes + cb_);
   p.xchain_words = (long long)pl.xchain_words;
   p.dc_state = reinterpret_cast<float*>(ws + kStatusBytes + cb_ + xb);
-  ASR_CHECK_HIP(hipMemsetAsync(ws, 0, kStatusBytes + cb_, stream));
-  ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes + cb_, 0xFF, xb, stream));
+  // step range of this call: the whole sequence, or a slice that continues a previous
+  // call on the same workspace (state: exchange slots, cell slab / dc_state)
+  int r_begin = 0, r_end = a->T;
+  if (a->step_count > 0) {
+    ASR_CHECK_ARG(a->step_begin >= 0 && a->step_begin + a->step_count <= a->T,
+                  "lstm: step range [%d, +%d) outside T=%d", a->step_begin, a->step_count, a->T);
+    r_begin = a->step_begin;
+    r_end = a->step_begin + a->step_count;
+  }
+  if (r_begin == 0) {
+    if (p.dz_absmax) ASR_CHECK_HIP(hipMemsetAsync(p.dz_absmax, 0, sizeof(unsigned), stream));
+    ASR_CHECK_HIP(hipMemsetAsync(ws, 0, kStatusBytes, stream));
+    ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes + cb_, 0xFF, xb, stream));
+  }
   const int chains = 2 * p.NB;
   const bool stepwise = a->mode == 1;
   p.poll = stepwise ? 0 : 1;
   p.allow_fast = env_int("ASR_LSTM_FAST", 1);
   p.dbg = env_int("ASR_LSTM_DBG", 0);
   p.xstride = fwd_xstride();
-  const int steps_per_launch = stepwise ? 1 : a->T;
-  for (int s0 = 0; s0 < a->T; s0 += steps_per_launch) {
+  const int steps_per_launch = stepwise ? 1 : (r_end - r_begin);
+  for (int s0 = r_begin; s0 < r_end; s0 += steps_per_launch) {
+    // the XCC table is rebuilt by every persistent launch (placement may differ)
+    if (!stepwise) ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes, 0, cb_, stream));
     for (int cb = 0; cb < chains; cb += pl.chains_per_launch) {
       const int nch = (chains - cb) < pl.chains_per_launch ? (chains - cb) : pl.chains_per_launch;
       p.chain_begin = cb;
       p.nch = nch;
       p.s_begin = s0;
-      p.s_count = (a->T - s0) < steps_per_launch ? (a->T - s0) : steps_per_launch;
+      p.s_count = (r_end - s0) < steps_per_launch ? (r_end - s0) : steps_per_launch;
       const int groups = (nch + 7) / 8;
       hipLaunchKernelGGL(k, dim3(groups * 8 * pl.P), dim3(kThreads), pl.shm, stream, p);
       ASR_CHECK_LAUNCH();

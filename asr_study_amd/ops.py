@@ -108,9 +108,10 @@ def colsum(X, M, N, ldx, out, beta=0.0, x_off=0, ws_name='colsum'):
 
 # --------------------------------------------------------------------------- LSTM
 def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=None,
-               dy=None, dz=None, mode=0, dz_absmax=None):
+               dy=None, dz=None, mode=0, dz_absmax=None, steps=None):
     a = L.LstmArgs()
     a.T, a.n_pad, a.H, a.mode = int(T), int(n_pad), int(H), int(mode)
+    a.step_begin, a.step_count = (0, 0) if steps is None else (int(steps[0]), int(steps[1]))
     a.U = U.data_ptr()
     for name, t in (('mask_u', mask_u), ('zx', zx), ('y', y), ('cell', cell),
                     ('gates', gates), ('dy', dy), ('dz', dz), ('dz_absmax', dz_absmax)):
@@ -118,10 +119,14 @@ def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=No
     return a
 
 
-def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=False):
+def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=False,
+                 steps=None):
+    """steps=(begin, count): only that slice of the recurrence (consecutive slices from 0
+    on the same stream continue one sequence); None = all T steps."""
     lib = L.load()
     _check_f32(zx, U, y, cell, gates, mask_u)
-    a = _lstm_args(T, n_pad, H, U, mask_u, zx=zx, y=y, cell=cell, gates=gates, mode=mode)
+    a = _lstm_args(T, n_pad, H, U, mask_u, zx=zx, y=y, cell=cell, gates=gates, mode=mode,
+                   steps=steps)
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 0)
     ws = WS.get('lstm_fwd', nbytes, zx.device)
     L.check(lib.asr_lstm_seq_fwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_fwd')
@@ -131,11 +136,11 @@ def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=
 
 
 def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check=False,
-                 dz_absmax=None):
+                 dz_absmax=None, steps=None):
     lib = L.load()
     _check_f32(dy, U, cell, gates, dz, mask_u)
     a = _lstm_args(T, n_pad, H, U, mask_u, cell=cell, gates=gates, dy=dy, dz=dz, mode=mode,
-                   dz_absmax=dz_absmax)
+                   dz_absmax=dz_absmax, steps=steps)
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 1)
     ws = WS.get('lstm_bwd', nbytes, dy.device)
     L.check(lib.asr_lstm_seq_bwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_bwd')

@@ -168,6 +168,14 @@ typedef struct asr_lstm_args {
   /* backward, optional: receives max |dz| (one device float; used as the     */
   /* split-fp16 GEMM pre-scale of the gradient operand), or NULL.             */
   float* dz_absmax;
+  /* Optional step range: process recurrence steps [step_begin, step_begin +  */
+  /* step_count) only (step s is frame s of the forward direction and frame   */
+  /* T-1-s of the backward one; BPTT walks them in the opposite order).  A    */
+  /* sequence is processed by calls with consecutive ranges starting at 0 on  */
+  /* the SAME workspace and stream order; step_count = 0 means all T steps.   */
+  /* Lets the caller overlap the GEMMs that feed / consume the outer frames   */
+  /* with the recurrence over the inner ones.                                 */
+  int step_begin, step_count;
 } asr_lstm_args;
 size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
 int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,

@@ -94,3 +94,39 @@ def test_forward_and_backward(T, N, F, H, mode, use_mask):
         assert report('lstm dz %s %s' % (d, tag), dzh[:, :N, di], w) < 1e-4 * scale
     # padding rows received zero upstream gradient -> exactly zero gate gradients
     assert np.all(dzh[:, N:] == 0)
+
+
+@pytest.mark.parametrize('T,N,H,cuts', [
+    (64, 16, 64, (48,)),             # the 3T/4 split the engine uses
+    (41, 32, 256, (1, 2, 17, 40)),   # odd boundaries incl. single-step slices
+])
+def test_step_ranges_continue_one_sequence(T, N, H, cuts):
+    """asr_lstm_args.step_begin/step_count: consecutive slices == one call, bit for bit
+    (the slices only move kernel boundaries; the arithmetic is unchanged)."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(T * H)
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.1).astype(np.float32)).to(dev)
+    bounds = [0] + list(cuts) + [T]
+
+    def run(sliced):
+        y = torch.zeros(T, n_pad, 2 * H, device=dev)
+        cell = torch.zeros(T, n_pad, 2, H, device=dev)
+        gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+        dz = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+        amax = torch.zeros(1, device=dev)
+        ranges = [(a, b - a) for a, b in zip(bounds[:-1], bounds[1:])] if sliced else [None]
+        for r in ranges:
+            ws = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, steps=r)
+        ops.lstm_status(ws)
+        for r in ranges:
+            ws = ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, dz_absmax=amax, steps=r)
+        ops.lstm_status(ws)
+        return [t.cpu().numpy() for t in (y, cell, gates, dz, amax)]
+    whole, parts = run(False), run(True)
+    for name, a, b in zip(('y', 'cell', 'gates', 'dz', 'absmax'), whole, parts):
+        assert np.array_equal(a, b), name
+    assert np.abs(whole[3]).max() == whole[4][0]
