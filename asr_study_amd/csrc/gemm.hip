@@ -465,6 +465,216 @@ gemm_f16x2_kernel(TileSrc A, TileSrc B, int M, int N, int K, int k_per_split, Ep
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fast path of the split-fp16 GEMM: the same tile / MFMA / LDS scheme with a
+// BRANCH-FREE K loop.  All global reads are 16-byte buffer loads through a
+// descriptor whose extent is the operand's; rows or K positions outside the problem
+// get an out-of-range offset and come back as zeros, so the loop body is straight
+// line code the compiler can software-pipeline (the generic kernel's per-element
+// bound checks cost ~370 branches and ~110 waits per K slab).  Workgroups are mapped
+// XCD-aware (see tile_of_block).  Preconditions (checked by the host, which otherwise
+// falls back to the generic kernel): 16-byte aligned rows, K % 4 == 0, an
+// mn-contiguous operand has mn % 4 == 0, extents < 4 GiB, mask period a power of two.
+using u32x4g = __attribute__((ext_vector_type(4))) unsigned;
+constexpr unsigned kOob = 0xFFFFFFF0u;
+
+// blockIdx.x -> (row tile, column tile, K split).  The dispatcher deals consecutive
+// workgroup ids round-robin over the 8 XCDs (id % 8), each with its own 4 MB L2, so
+// every XCD gets a CONTIGUOUS range of an ordering in which the ~64 workgroups it runs
+// at a time form a compact (8 row tiles x 8 column tiles) block of one K split: their
+// A / B panels are fetched into that L2 once and shared.
+struct TileId { int tm, tn, z; };
+__device__ __forceinline__ TileId tile_of_block(int TM, int TN, int splits) {
+  constexpr int kXcd = 8, GM = 8;
+  const int total = TM * TN * splits;
+  const int q = total / kXcd, r = total % kXcd;       // bijective for any total
+  const int xcd = blockIdx.x % kXcd, idx = blockIdx.x / kXcd;
+  const int g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int tiles = TM * TN;
+  TileId t;
+  t.z = g / tiles;
+  const int rem = g - t.z * tiles;
+  const int band = rem / (GM * TN);                   // band of GM row tiles
+  const int in_band = rem - band * (GM * TN);
+  const int rows_here = (TM - band * GM) < GM ? (TM - band * GM) : GM;
+  t.tm = band * GM + in_band % rows_here;
+  t.tn = in_band / rows_here;
+  return t;
+}
+
+struct FastSrc {
+  const float* p; int ld, mn_total;
+  unsigned extent;                 // bytes addressable from p
+  const float* scale; int pmask, scale_ld; unsigned scale_extent;
+};
+
+template <bool MN, bool MASK>
+struct FastLoader {
+  __amdgpu_buffer_rsrc_t rsrc, mrsrc;
+  unsigned off[4], moff[4];        // byte offsets of this thread's four loads at k_begin
+  unsigned step;                   // bytes per K slab
+  int k0, k_end;                   // this thread's first K index, slab range end
+  int pmask, scale_ld, mn;
+
+  __device__ __forceinline__ void init(const FastSrc& s, int mn0, int k_begin, int kend) {
+    const int tid = threadIdx.x;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.p), 0, s.extent, 0x00020000);
+    if (MASK)
+      mrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s.scale), 0, s.scale_extent,
+                                                0x00020000);
+    k_end = kend;
+    pmask = s.pmask; scale_ld = s.scale_ld;
+    if (MN) {        // storage (K, MN): thread = k rows 4*(tid>>5)+c, columns 4*(tid&31)..+3
+      k0 = k_begin + 4 * (tid >> 5);
+      mn = mn0 + 4 * (tid & 31);
+      const bool ok = mn + 3 < s.mn_total;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        off[c] = ok ? (unsigned)(((size_t)(k0 + c) * s.ld + mn) * 4) : kOob;
+      step = (unsigned)(HBK * s.ld * 4);
+    } else {         // storage (MN, K): thread = rows (tid>>3)+32r, k quad tid&7
+      k0 = k_begin + 4 * (tid & 7);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mn0 + (tid >> 3) + 32 * r;
+        off[r] = row < s.mn_total ? (unsigned)(((size_t)row * s.ld + k0) * 4) : kOob;
+        if (MASK) moff[r] = (unsigned)(((size_t)(row & s.pmask) * s.scale_ld + k0) * 4);
+      }
+      step = (unsigned)(HBK * 4);
+    }
+  }
+
+  __device__ __forceinline__ void load(int kt, Frag16 (&f)[1]) const {
+    float4 q[4], m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + kt * HBK + (MN ? i : 0);
+      const bool ok = k < k_end && off[i] != kOob;
+      const unsigned o = ok ? off[i] + (unsigned)kt * step : kOob;
+      q[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0));
+      if (MASK) {
+        const unsigned mo = !ok ? kOob
+            : MN ? (unsigned)(((size_t)(k & pmask) * scale_ld + mn) * 4)
+                 : moff[i] + (unsigned)kt * step;
+        m[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, mo, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (MASK) { q[i].x *= m[i].x; q[i].y *= m[i].y; q[i].z *= m[i].z; q[i].w *= m[i].w; }
+      if (MN) {      // load i = k row c: element e belongs to tile row e
+        f[0].v[0][i] = q[i].x; f[0].v[1][i] = q[i].y; f[0].v[2][i] = q[i].z; f[0].v[3][i] = q[i].w;
+      } else {       // load i = tile row r: elements are 4 consecutive k
+        f[0].v[i][0] = q[i].x; f[0].v[i][1] = q[i].y; f[0].v[i][2] = q[i].z; f[0].v[i][3] = q[i].w;
+      }
+    }
+  }
+};
+
+template <bool AMN, bool BMN, bool MASK>
+__global__ void __launch_bounds__(256)
+gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_split, int splits,
+                       Epilogue ep, HScales hs) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
+  // [buf 2][A_hi, A_lo, B_hi, B_lo][128][HLD]
+  auto tile = [&](int buf, int which) {
+    return reinterpret_cast<_Float16 (*)[HLD]>(hsm + ((size_t)(buf * 4 + which) * 128) * HLD);
+  };
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const TileId tb = tile_of_block((M + BM - 1) / BM, (N + BN - 1) / BN, splits);
+  const int m0 = tb.tm * BM, n0 = tb.tn * BN;
+  const int k_begin = tb.z * k_per_split;
+  int k_end = k_begin + k_per_split;
+  if (k_end > K) k_end = K;
+  const float sa = pow2_scale(hs.a_absmax), sb = pow2_scale(hs.b_absmax);
+
+  f32x16 am[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) am[i][j][e] = 0.f;
+
+  FastLoader<AMN, MASK> la;
+  FastLoader<BMN, false> lb;
+  la.init(A, m0, k_begin, k_end);
+  lb.init(B, n0, k_begin, k_end);
+  Frag16 fa[1], fb[1];
+  const int nk = (k_end - k_begin + HBK - 1) / HBK;
+  if (nk > 0) {
+    la.load(0, fa);
+    lb.load(0, fb);
+    h_tile_store(AMN, fa, sa, tile(0, 0), tile(0, 1));
+    h_tile_store(BMN, fb, sb, tile(0, 2), tile(0, 3));
+  }
+  __syncthreads();
+  const int lrow = lane & 31, lk = 8 * (lane >> 5);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    // past the last slab every offset is out of range: the loads return zeros unused
+    la.load(kt + 1, fa);
+    lb.load(kt + 1, fb);
+    _Float16 (*Ah)[HLD] = tile(cur, 0);
+    _Float16 (*Al)[HLD] = tile(cur, 1);
+    _Float16 (*Bh)[HLD] = tile(cur, 2);
+    _Float16 (*Bl)[HLD] = tile(cur, 3);
+#pragma unroll
+    for (int ks = 0; ks < HBK / 16; ++ks) {
+      hx8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const hx8*>(&Ah[wm * 64 + i * 32 + lrow][16 * ks + lk]);
+        al[i] = *reinterpret_cast<const hx8*>(&Al[wm * 64 + i * 32 + lrow][16 * ks + lk]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = *reinterpret_cast<const hx8*>(&Bh[wn * 64 + j * 32 + lrow][16 * ks + lk]);
+        bl[j] = *reinterpret_cast<const hx8*>(&Bl[wn * 64 + j * 32 + lrow][16 * ks + lk]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], am[i][j], 0, 0, 0);
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], am[i][j], 0, 0, 0);
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], am[i][j], 0, 0, 0);
+        }
+    }
+    h_tile_store(AMN, fa, sa, tile(cur ^ 1, 0), tile(cur ^ 1, 1));
+    h_tile_store(BMN, fb, sb, tile(cur ^ 1, 2), tile(cur ^ 1, 3));
+    __syncthreads();
+  }
+  const float unscale = 1.f / (sa * sb);
+  const int lcol = lane & 31, lhalf = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + lcol;
+      if (col >= N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+        if (row >= M) continue;
+        float v = am[i][j][e] * unscale;
+        if (ep.partial) {
+          ep.partial[((size_t)tb.z * M + row) * N + col] = v;
+        } else {
+          v *= ep.alpha;
+          float* dst = ep.C + (size_t)row * ep.ldc + col;
+          if (ep.bias) v += ep.bias[col];
+          if (ep.c_scale) v *= ep.c_scale[(size_t)mod_period(row, ep.c_period) * ep.c_ld + col];
+          if (ep.beta != 0.f) v += ep.beta * *dst;
+          *dst = v;
+        }
+      }
+    }
+}
+
 // max |x| of a flat tensor -> out[0] (float).  Two launches: per-block maxima via
 // atomicMax on the float bits (all non-negative, so integer order == float order).
 __global__ void __launch_bounds__(256)
@@ -579,6 +789,7 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
     ep.partial = reinterpret_cast<float*>(workspace);
   }
   dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, splits);
+  const int tiles_mn = (int)(grid.x * grid.y);
   static const int prec_env = [] { const char* v = getenv("ASR_GEMM_PREC"); return v ? atoi(v) : 1; }();
   const int prec = a->precision == 0 ? 0 : (a->precision == 1 ? 1 : prec_env);
   if (prec == 1 && a->K >= 32) {
@@ -596,8 +807,56 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
       attr_done = true;
     }
     HScales hs{a->a_absmax, a->b_absmax};
-    hipLaunchKernelGGL(gemm_f16x2_kernel, grid, dim3(256), shm, stream, A, B, a->M, a->N, a->K,
-                       kps, ep, hs);
+    // fast (branch-free) kernel when the geometry allows 16-byte buffer loads throughout
+    auto extent = [](const TileSrc& t) {
+      return t.mn_contig ? ((size_t)(t.k_total - 1) * t.ld + t.mn_total) * 4
+                         : ((size_t)(t.mn_total - 1) * t.ld + t.k_total) * 4;
+    };
+    const size_t lim = ((size_t)1 << 32) - ((size_t)1 << 20);
+    const bool pow2 = (A.period & (A.period - 1)) == 0;
+    const size_t mask_ext = A.scale ? ((size_t)(A.period - 1) * A.scale_ld +
+                                       (A.mn_contig ? A.mn_total : A.k_total)) * 4 : 0;
+    static const int fast_env = [] { const char* v = getenv("ASR_GEMM_FAST"); return v ? atoi(v) : 1; }();
+    const bool fast = fast_env && A.vec_ok && B.vec_ok && a->K % 4 == 0 &&
+                      (!A.mn_contig || a->M % 4 == 0) && (!B.mn_contig || a->N % 4 == 0) &&
+                      extent(A) < lim && extent(B) < lim &&
+                      (!A.scale || (A.scale_vec && pow2 && mask_ext < lim));
+    if (fast) {
+      FastSrc fa_, fb_;
+      fa_.p = A.p; fa_.ld = A.ld; fa_.mn_total = A.mn_total; fa_.extent = (unsigned)extent(A);
+      fa_.scale = A.scale; fa_.pmask = A.period - 1; fa_.scale_ld = A.scale_ld;
+      fa_.scale_extent = (unsigned)mask_ext;
+      fb_.p = B.p; fb_.ld = B.ld; fb_.mn_total = B.mn_total; fb_.extent = (unsigned)extent(B);
+      fb_.scale = nullptr; fb_.pmask = 0; fb_.scale_ld = 0; fb_.scale_extent = 0;
+      const int total = tiles_mn * sp;
+      const int key = (A.mn_contig ? 4 : 0) | (B.mn_contig ? 2 : 0) | (A.scale ? 1 : 0);
+#define ASR_FAST_CASE(KEY, AMN, BMN, MASK)                                                    \
+      case KEY: {                                                                              \
+        static bool done = false;                                                              \
+        if (!done) {                                                                           \
+          ASR_CHECK_HIP(hipFuncSetAttribute(                                                   \
+              (const void*)gemm_f16x2_fast_kernel<AMN, BMN, MASK>,                             \
+              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                          \
+          done = true;                                                                         \
+        }                                                                                      \
+        hipLaunchKernelGGL((gemm_f16x2_fast_kernel<AMN, BMN, MASK>), dim3(total), dim3(256),   \
+                           shm, stream, fa_, fb_, a->M, a->N, a->K, kps, sp, ep, hs);          \
+      } break;
+      switch (key) {
+        ASR_FAST_CASE(0, false, false, false)
+        ASR_FAST_CASE(1, false, false, true)
+        ASR_FAST_CASE(2, false, true, false)
+        ASR_FAST_CASE(3, false, true, true)
+        ASR_FAST_CASE(4, true, false, false)
+        ASR_FAST_CASE(5, true, false, true)
+        ASR_FAST_CASE(6, true, true, false)
+        ASR_FAST_CASE(7, true, true, true)
+      }
+#undef ASR_FAST_CASE
+    } else {
+      hipLaunchKernelGGL(gemm_f16x2_kernel, grid, dim3(256), shm, stream, A, B, a->M, a->N, a->K,
+                         kps, ep, hs);
+    }
     splits = sp;
   } else if (BK == 16)
     hipLaunchKernelGGL(gemm_f32_mfma_kernel<16>, grid, dim3(256), 0, stream, A, B, a->M, a->N,
