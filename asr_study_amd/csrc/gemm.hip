@@ -341,9 +341,19 @@ __device__ __forceinline__ void h_tile_load(const TileSrc& s, int k0, int mn0, i
   }
 }
 
+// tile row (0..31) of a thread for a k-contiguous operand: the two rows that share a
+// 16-lane ds_write_b64 group are 4 apart (80-byte rows -> banks 16 apart: no overlap)
+__device__ __forceinline__ int kc_row() {
+  const int rr = threadIdx.x >> 3;
+  return (rr & ~7) | ((rr & 1) << 2) | ((rr >> 1) & 3);
+}
+
 __device__ __forceinline__ void h_tile_store(int mn_contig, const Frag16 (&f)[1], float scale,
-                                             _Float16 (*Shi)[HLD], _Float16 (*Slo)[HLD]) {
+                                             _Float16 (*Shi)[HLD], _Float16 (*Slo)[HLD],
+                                             int kq = -1) {
   const int tid = threadIdx.x;
+  const int krow = kq < 0 ? (tid >> 3) : kc_row();   // fast path passes kq >= 0
+  if (kq < 0) kq = tid >> 5;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     hx4 hi, lo;
@@ -355,8 +365,8 @@ __device__ __forceinline__ void h_tile_store(int mn_contig, const Frag16 (&f)[1]
       lo[c] = (_Float16)(x - (float)h);
     }
     int row, col;
-    if (mn_contig) { row = 4 * (tid & 31) + r; col = 4 * (tid >> 5); }
-    else { row = (tid >> 3) + 32 * r; col = 4 * (tid & 7); }
+    if (mn_contig) { row = 4 * (tid & 31) + r; col = 4 * kq; }
+    else { row = krow + 32 * r; col = 4 * (tid & 7); }
     *reinterpret_cast<hx4*>(&Shi[row][col]) = hi;
     *reinterpret_cast<hx4*>(&Slo[row][col]) = lo;
   }
@@ -508,6 +518,16 @@ struct FastSrc {
   const float* scale; int pmask, scale_ld; unsigned scale_extent;
 };
 
+// k quad (0..7) of a thread for an mn-contiguous operand.  Rotating it with the column
+// quad makes the 16 lanes that share a ds_write_b64 cycle hit 16 different bank pairs
+// when they store their transposed 4x4 blocks ([mn][k] rows are 80 bytes apart, so
+// unrotated lanes 4 rows apart collide 8-way); global reads stay 32-byte contiguous
+// per lane pair and whole lines per workgroup.
+__device__ __forceinline__ int mn_kquad() {
+  const int tid = threadIdx.x;
+  return ((tid >> 5) + ((tid & 31) >> 1)) & 7;
+}
+
 template <bool MN, bool MASK>
 struct FastLoader {
   __amdgpu_buffer_rsrc_t rsrc, mrsrc;
@@ -524,19 +544,19 @@ struct FastLoader {
                                                 0x00020000);
     k_end = kend;
     pmask = s.pmask; scale_ld = s.scale_ld;
-    if (MN) {        // storage (K, MN): thread = k rows 4*(tid>>5)+c, columns 4*(tid&31)..+3
-      k0 = k_begin + 4 * (tid >> 5);
+    if (MN) {        // storage (K, MN): thread = k rows 4*kq+c, columns 4*(tid&31)..+3
+      k0 = k_begin + 4 * mn_kquad();
       mn = mn0 + 4 * (tid & 31);
       const bool ok = mn + 3 < s.mn_total;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         off[c] = ok ? (unsigned)(((size_t)(k0 + c) * s.ld + mn) * 4) : kOob;
       step = (unsigned)(HBK * s.ld * 4);
-    } else {         // storage (MN, K): thread = rows (tid>>3)+32r, k quad tid&7
+    } else {         // storage (MN, K): thread = rows kc_row()+32r, k quad tid&7
       k0 = k_begin + 4 * (tid & 7);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = mn0 + (tid >> 3) + 32 * r;
+        const int row = mn0 + kc_row() + 32 * r;
         off[r] = row < s.mn_total ? (unsigned)(((size_t)row * s.ld + k0) * 4) : kOob;
         if (MASK) moff[r] = (unsigned)(((size_t)(row & s.pmask) * s.scale_ld + k0) * 4);
       }
@@ -544,7 +564,9 @@ struct FastLoader {
     }
   }
 
-  __device__ __forceinline__ void load(int kt, Frag16 (&f)[1]) const {
+  // Issues the loads only; the mask (if any) lands in fm and is applied by apply_mask()
+  // right before the values are needed, so nothing here waits on memory.
+  __device__ __forceinline__ void load(int kt, Frag16 (&f)[1], Frag16 (&fm)[1]) const {
     float4 q[4], m[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -553,21 +575,35 @@ struct FastLoader {
       const unsigned o = ok ? off[i] + (unsigned)kt * step : kOob;
       q[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0));
       if (MASK) {
-        const unsigned mo = !ok ? kOob
-            : MN ? (unsigned)(((size_t)(k & pmask) * scale_ld + mn) * 4)
-                 : moff[i] + (unsigned)kt * step;
+        const unsigned mraw = MN ? (unsigned)(((size_t)(k & pmask) * scale_ld + mn) * 4)
+                                 : moff[i] + (unsigned)kt * step;
+        const unsigned mo = ok ? mraw : kOob;
         m[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, mo, 0, 0));
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (MASK) { q[i].x *= m[i].x; q[i].y *= m[i].y; q[i].z *= m[i].z; q[i].w *= m[i].w; }
       if (MN) {      // load i = k row c: element e belongs to tile row e
         f[0].v[0][i] = q[i].x; f[0].v[1][i] = q[i].y; f[0].v[2][i] = q[i].z; f[0].v[3][i] = q[i].w;
+        if (MASK) {
+          fm[0].v[0][i] = m[i].x; fm[0].v[1][i] = m[i].y; fm[0].v[2][i] = m[i].z;
+          fm[0].v[3][i] = m[i].w;
+        }
       } else {       // load i = tile row r: elements are 4 consecutive k
         f[0].v[i][0] = q[i].x; f[0].v[i][1] = q[i].y; f[0].v[i][2] = q[i].z; f[0].v[i][3] = q[i].w;
+        if (MASK) {
+          fm[0].v[i][0] = m[i].x; fm[0].v[i][1] = m[i].y; fm[0].v[i][2] = m[i].z;
+          fm[0].v[i][3] = m[i].w;
+        }
       }
     }
+  }
+  __device__ __forceinline__ static void apply_mask(Frag16 (&f)[1], const Frag16 (&fm)[1]) {
+    if (!MASK) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) f[0].v[r][c] *= fm[0].v[r][c];
   }
 };
 
@@ -599,25 +635,31 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
 #pragma unroll
       for (int e = 0; e < 16; ++e) am[i][j][e] = 0.f;
 
+  const int kq_rot = mn_kquad();
   FastLoader<AMN, MASK> la;
   FastLoader<BMN, false> lb;
   la.init(A, m0, k_begin, k_end);
   lb.init(B, n0, k_begin, k_end);
-  Frag16 fa[1], fb[1];
+  // Two register sets: while slab kt is multiplied out of LDS, slab kt+1 (loaded one
+  // iteration ago) is converted into the other LDS buffer and the loads of slab kt+2
+  // are already in flight -- a full iteration of latency cover.
+  Frag16 fa0[1], fb0[1], fa1[1], fb1[1], fm0[1], fm1[1], fmb[1];
   const int nk = (k_end - k_begin + HBK - 1) / HBK;
-  if (nk > 0) {
-    la.load(0, fa);
-    lb.load(0, fb);
-    h_tile_store(AMN, fa, sa, tile(0, 0), tile(0, 1));
-    h_tile_store(BMN, fb, sb, tile(0, 2), tile(0, 3));
-  }
+  la.load(0, fa0, fm0);
+  lb.load(0, fb0, fmb);
+  la.load(1, fa1, fm1);
+  lb.load(1, fb1, fmb);
+  la.apply_mask(fa0, fm0);
+  h_tile_store(AMN, fa0, sa, tile(0, 0), tile(0, 1), kq_rot);
+  h_tile_store(BMN, fb0, sb, tile(0, 2), tile(0, 3), kq_rot);
   __syncthreads();
   const int lrow = lane & 31, lk = 8 * (lane >> 5);
-  for (int kt = 0; kt < nk; ++kt) {
+  auto slab = [&](int kt, Frag16 (&fl_a)[1], Frag16 (&fl_m)[1], Frag16 (&fl_b)[1],
+                  Frag16 (&fs_a)[1], Frag16 (&fs_m)[1], Frag16 (&fs_b)[1]) {
     const int cur = kt & 1;
-    // past the last slab every offset is out of range: the loads return zeros unused
-    la.load(kt + 1, fa);
-    lb.load(kt + 1, fb);
+    // past the last slab every offset is out of range: those loads return zeros, unused
+    la.load(kt + 2, fl_a, fl_m);
+    lb.load(kt + 2, fl_b, fmb);
     _Float16 (*Ah)[HLD] = tile(cur, 0);
     _Float16 (*Al)[HLD] = tile(cur, 1);
     _Float16 (*Bh)[HLD] = tile(cur, 2);
@@ -644,9 +686,14 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], am[i][j], 0, 0, 0);
         }
     }
-    h_tile_store(AMN, fa, sa, tile(cur ^ 1, 0), tile(cur ^ 1, 1));
-    h_tile_store(BMN, fb, sb, tile(cur ^ 1, 2), tile(cur ^ 1, 3));
+    la.apply_mask(fs_a, fs_m);
+    h_tile_store(AMN, fs_a, sa, tile(cur ^ 1, 0), tile(cur ^ 1, 1), kq_rot);
+    h_tile_store(BMN, fs_b, sb, tile(cur ^ 1, 2), tile(cur ^ 1, 3), kq_rot);
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    slab(kt, fa0, fm0, fb0, fa1, fm1, fb1);     // loads slab kt+2 -> set 0, stores set 1
+    if (kt + 1 < nk) slab(kt + 1, fa1, fm1, fb1, fa0, fm0, fb0);
   }
   const float unscale = 1.f / (sa * sb);
   const int lcol = lane & 31, lhalf = lane >> 5;
