@@ -697,6 +697,43 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
   }
   const float unscale = 1.f / (sa * sb);
   const int lcol = lane & 31, lhalf = lane >> 5;
+  if (m0 + BM <= M && n0 + BN <= N) {
+    // interior tile: no per-element bound checks, so the 16 loads of a fragment (mask,
+    // old C) are issued back to back before the first is needed
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + lcol;
+        const int row0 = m0 + wm * 64 + i * 32 + 4 * lhalf;
+        if (ep.partial) {
+          float* dst = ep.partial + ((size_t)tb.z * M + row0) * N + col;
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            dst[(size_t)((e & 3) + 8 * (e >> 2)) * N] = am[i][j][e] * unscale;
+          continue;
+        }
+        float* dst = ep.C + (size_t)row0 * ep.ldc + col;
+        const float bias = ep.bias ? ep.bias[col] : 0.f;
+        float old[16], msk[16];
+        const bool use_old = ep.beta != 0.f;
+        const bool use_msk = ep.c_scale != nullptr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int dr = (e & 3) + 8 * (e >> 2);
+          old[e] = use_old ? dst[(size_t)dr * ep.ldc] : 0.f;
+          msk[e] = use_msk ? ep.c_scale[(size_t)mod_period(row0 + dr, ep.c_period) * ep.c_ld + col]
+                           : 1.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int dr = (e & 3) + 8 * (e >> 2);
+          const float v = (am[i][j][e] * unscale * ep.alpha + bias) * msk[e];
+          dst[(size_t)dr * ep.ldc] = use_old ? v + ep.beta * old[e] : v;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
