@@ -807,14 +807,31 @@ colsum_partial_kernel(const float* __restrict__ X, int M, int N, int ldx, int ro
     partial[(size_t)blockIdx.y * N + col] = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
 }
 
+// 64 columns per workgroup; the four waves take every fourth slice (independent loads,
+// four accumulators each) and meet in LDS.
 __global__ void __launch_bounds__(256)
 colsum_final_kernel(const double* __restrict__ partial, int slices, int N,
                     float* __restrict__ out, float beta) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
-  double t = 0.0;
-  for (int s = 0; s < slices; ++s) t += partial[(size_t)s * N + col];
-  out[col] = (beta != 0.f ? beta * out[col] : 0.f) + (float)t;
+  __shared__ double part[4][64];
+  const int cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  if (col < N) {
+    int s = sg;
+    for (; s + 12 < slices; s += 16) {
+      t0 += partial[(size_t)s * N + col];
+      t1 += partial[(size_t)(s + 4) * N + col];
+      t2 += partial[(size_t)(s + 8) * N + col];
+      t3 += partial[(size_t)(s + 12) * N + col];
+    }
+    for (; s < slices; s += 4) t0 += partial[(size_t)s * N + col];
+  }
+  part[sg][cx] = (t0 + t1) + (t2 + t3);
+  __syncthreads();
+  if (sg == 0 && col < N) {
+    const double t = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+    out[col] = (beta != 0.f ? beta * out[col] : 0.f) + (float)t;
+  }
 }
 
 int colsum_slices(int M) {
@@ -994,7 +1011,7 @@ extern "C" int asr_colsum(const float* X, int M, int N, int ldx, float* out, flo
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, stream, X, M, N,
                      ldx, rows_per_slice, partial);
   ASR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, partial,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, partial,
                      rs, N, out, beta);
   ASR_CHECK_LAUNCH();
   return ASR_OK;
