@@ -50,6 +50,18 @@ EVAL_FLAGS = [
     ('--save_transcriptions', dict(default=None, type=str)),
     ('--beam_width', dict(default=400, type=int)),      # utils/core_utils.py:70-71
 ]
+PREDICT_FLAGS = [
+    ('--model', dict(required=True, type=str)),
+    ('--dataset', dict(default=None, type=str)),
+    ('--file', dict(default=None, type=str)),
+    ('--subset', dict(type=str, default='test')),
+] + _PLUGIN_FLAGS + [
+    ('--no_decoder', dict(action='store_true', default=False)),
+] + _DEVICE_FLAGS + [
+    ('--save', dict(default=None, type=str)),
+    ('--override', dict(default=False, action='store_true')),
+    ('--beam_width', dict(default=400, type=int)),
+]
 MAKE_DATASET_FLAGS = [
     ('--parser', dict(type=str, default='dummy')),
     ('--parser_params', dict(nargs='+', default=[])),
@@ -182,6 +194,62 @@ def eval_main(argv=None):
     for name, v in zip(model.metrics_names, values):
         print('%s: %4f' % (name, v))
     return values
+
+
+# ------------------------------------------------------------------ predict
+def predict_main(argv=None):
+    """predict.py: transcribe one audio file or a dataset split, one utterance per
+    forward pass (batch_size=1, the reference's latency path); ``--no_decoder`` saves the
+    per-frame network outputs instead (HDF5: predictions vlen-f32 + num_labels, labels)."""
+    import numpy as np
+    parser = make_parser('Predicting with an ASR system.', PREDICT_FLAGS)
+    args = parser.parse_args(argv)
+    if args.dataset is None and args.file is None:
+        raise ValueError('dataset or file args must be set.')
+    if args.dataset and args.file:
+        print('Both dataset and file args was set. Ignoring file args.')
+    explicit = utils.parse_nondefault_args(args, parser.parse_args(['--model', args.model]), argv)
+    from .datasets.dataset_generator import DatasetGenerator, DatasetIterator
+    from .utils.core_utils import setup_gpu, load_model
+    setup_gpu(args.gpu, args.allow_growth)
+    model, meta = load_model(args.model, return_meta=True, mode='predict',
+                             decoder=(not args.no_decoder), beam_width=args.beam_width)
+    # only the feature / label plugins are inherited from the training run (the reference
+    # overlays every stored argument, predict.py:60, which would also import its --save)
+    stored = {k: v for k, v in meta['training_args'].items()
+              if k in ('input_parser', 'input_parser_params', 'label_parser',
+                       'label_parser_params')}
+    args = merged_args(args, stored, explicit)
+    feature, labels = resolve_plugins(args)
+    if args.dataset is not None:
+        flow = DatasetGenerator(feature, labels, batch_size=1, seed=0, mode='predict',
+                                shuffle=False).flow_from_fname(args.dataset, datasets=args.subset)
+    else:
+        flow = DatasetIterator(np.array([args.file]), None, input_parser=feature,
+                               label_parser=labels, mode='predict', shuffle=False, batch_size=1)
+        flow.labels = np.array([u''])
+    truth = list(flow.labels) if flow.labels is not None else [u''] * flow.len
+    results = []
+    for index in range(flow.len):
+        out = model.predict(flow.next())
+        best = out[0] if args.no_decoder else labels.imap(out[0])
+        results.append({'label': truth[index], 'best': best})
+        print('Ground Truth: %s' % labels._sanitize(truth[index]))
+        print('   Predicted: %s\n\n' % (best if not args.no_decoder else 'array%s' % (best.shape,)))
+    if args.save is not None:
+        if os.path.exists(args.save):
+            if not args.override:
+                raise IOError('Unable to create file')
+            os.remove(args.save)
+        if not args.no_decoder:
+            raise ValueError('save param must be set if no_decoder is True')
+        from .datasets import h5lite
+        with h5lite.File(args.save, 'w') as f:
+            f.write_vlen_float('predictions', [r['best'].reshape(-1).astype('float32')
+                                               for r in results],
+                               attrs={'num_labels': int(results[0]['best'].shape[-1])})
+            f.write_strings('labels', [str(r['label']) for r in results])
+    return results
 
 
 # ------------------------------------------------------------------ make_dataset

@@ -686,11 +686,20 @@ class Model(object):
         return self._metrics(ctc, dec, dlen, labels, hyps)
 
     def predict(self, x, inputs_length=None):
-        """Decoded label sequences for a batch (greedy or beam, per self.decoder)."""
+        """Decoded label sequences for a batch (greedy or beam, per self.decoder), or the
+        (N, T, C) logits when the model was loaded without a decoder (predict.py's
+        --no_decoder).  ``x`` may also be the ``[inputs, inputs_length]`` list a
+        predict-mode DatasetIterator yields (predict.py:88)."""
+        if isinstance(x, list) and len(x) == 2 and inputs_length is None:
+            x, inputs_length = x
+        if isinstance(x, tuple) and x[0] == 'slab':
+            x = x[1]
         slab = x if (torch.is_tensor(x) and x.dim() == 3 and x.shape[1] % 16 == 0) else self.to_slab(x)
         N = len(inputs_length) if inputs_length is not None else slab.shape[1]
         lens = np.asarray(inputs_length if inputs_length is not None else [slab.shape[0]] * N).reshape(-1)
         logits = self.forward(slab, training=False)
+        if self.decoder is None:
+            return logits[:, :N].permute(1, 0, 2).contiguous().cpu().numpy()
         sl = torch.as_tensor(lens.astype(np.int32)).to(self.device)
         if self.decoder.get('is_greedy', True):
             dec, dlen = ops.ctc_greedy(logits, sl, N)

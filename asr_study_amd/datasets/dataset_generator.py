@@ -181,7 +181,7 @@ class DatasetIterator(Iterator):
 
     def _make_in(self, inputs, batch_size=None):
         if self.input_parser is not None and hasattr(self.input_parser, 'batch') and \
-                str(self.input_parser) != 'raw':
+                str(self.input_parser) != 'raw' and not any(isinstance(i, str) for i in inputs):
             # GPU feature extraction for the whole batch: returns the time-major
             # slab directly (('slab', tensor)), which Model accepts as `inputs`
             slab, frames = self.input_parser.batch([np.asarray(i) for i in inputs])

@@ -65,6 +65,8 @@ def load_model(model_fname, return_meta=False, mode='train', **kwargs):
             model.decoder = dict(is_greedy=kwargs.get('is_greedy', False),
                                  beam_width=kwargs.get('beam_width', 400),
                                  merge_repeated=True)
+        else:                       # predict.py --no_decoder: the network output itself
+            model.decoder = None
         model.metrics_names = ['loss', 'ctc_loss', 'beam_search_loss', 'beam_search_ler']
     if return_meta:
         return model, load_meta(model_fname)

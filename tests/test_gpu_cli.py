@@ -51,6 +51,21 @@ def test_train_eval_cli_roundtrip(tmp_path, capsys):
                 '--save', out, '--batch_size', '4'])
     from asr_study_amd.utils.core_utils import load_meta
     assert len(load_meta(os.path.join(out, 'model.h5'))['epochs']) == 3
+    # predict.py: one utterance per forward pass over the test split, then the raw
+    # network outputs (--no_decoder --save)
+    import predict as predict_cli
+    from asr_study_amd.datasets import h5lite
+    res = predict_cli.main(['--model', os.path.join(out, 'best.h5'), '--dataset', fname,
+                            '--beam_width', '10'])
+    assert len(res) > 0 and all(isinstance(r['best'], str) for r in res)
+    assert 'Ground Truth:' in capsys.readouterr().out
+    pred = str(tmp_path / 'pred.h5')
+    res = predict_cli.main(['--model', os.path.join(out, 'best.h5'), '--dataset', fname,
+                            '--no_decoder', '--save', pred])
+    assert res[0]['best'].ndim == 2 and res[0]['best'].shape[1] == 28
+    with h5lite.File(pred, 'r') as f:
+        assert len(f['predictions'][:]) == len(res)
+        assert int(f['predictions'].attrs['num_labels']) == 28
 
 
 def test_cfg5_beam_search_ler_matches_oracle(tmp_path):
