@@ -62,6 +62,8 @@ struct LstmParams {
   int poll;                // 1: persistent (poll tags); 0: one step per launch
   int allow_fast;          // may use the same-XCD transport
   int dbg;                 // ablation switches (ASR_LSTM_DBG), 0 in production
+  int prepoll;             // 64-clock naps before a step's first poll (see gather_groups)
+  int repoll;              // 64-clock naps between poll rounds
   int xstride;             // fwd: bytes between consecutive unit-group tiles in a slot
   const float* U;
   const float* mask_u;
@@ -125,7 +127,12 @@ template <bool FAST, int NL>
 __device__ __forceinline__ void gather_groups(__amdgpu_buffer_rsrc_t rsrc,
                                               const unsigned (&off)[NL], const bool (&use)[NL],
                                               unsigned tag, int poll, bool& dead, int* status,
-                                              u32x4 (&v)[NL], int nosleep = 0) {
+                                              u32x4 (&v)[NL], int nosleep = 0, int prepoll = 0,
+                                              int repoll = 1) {
+  // A poll that reaches the L2 before the producers' stores costs a whole extra round
+  // trip, and a step waits for the SLOWEST of its waves: napping a little before the
+  // first poll trades a small fixed delay for far fewer second rounds.
+  if (poll) for (int i = 0; i < prepoll; ++i) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
   for (int i = 0; i < NL; ++i)
     if (use[i]) v[i] = xload<FAST>(rsrc, off[i]);
@@ -144,7 +151,7 @@ __device__ __forceinline__ void gather_groups(__amdgpu_buffer_rsrc_t rsrc,
       atomicExch(status, 1);
       return;
     }
-    if (!nosleep) __builtin_amdgcn_s_sleep(1);
+    if (!nosleep) for (int i = 0; i < repoll; ++i) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
     for (int i = 0; i < NL; ++i)
       if (use[i] && !tags_ok(v[i], tag)) v[i] = xload<FAST>(rsrc, off[i]);
@@ -265,7 +272,8 @@ __device__ __forceinline__ void fwd_body(const LstmParams& p, int chain, int wg,
         use[i] = grp < UG * 16;
         off[i] = (unsigned)grp * 16u;
       }
-      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64);
+      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
+                              p.prepoll, p.repoll);
       if (prof) tk1 = wall_clock64();
       // next step's input projection: issued behind the poll (so the poll's in-order
       // wait never includes its HBM latency), consumed one whole compute phase later
@@ -438,7 +446,8 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
         use[i] = grp < UG * 16;
         off[i] = (unsigned)((grp >> 4) * p.xstride + (grp & 15) * 16);
       }
-      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64);
+      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
+                              p.prepoll, p.repoll);
       if (prof) tk1 = wall_clock64();
       zx_next = load_zx(s + 1);
 #pragma unroll
@@ -625,7 +634,8 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
         use[i] = grp < P * 64;
         off[i] = (unsigned)grp * 16u;
       }
-      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64);
+      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
+                              p.prepoll, p.repoll);
       if (prof) tk1 = wall_clock64();
       load_slabs(s + 1);
 #pragma unroll
@@ -822,7 +832,8 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
         use[i] = grp < P * 64;
         off[i] = (unsigned)grp * 16u;
       }
-      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64);
+      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
+                              p.prepoll, p.repoll);
       if (prof) tk1 = wall_clock64();
       load_slabs(s + 1);
       // wave w holds producers w, w+4, ...: add them in registers, then 4 partial
@@ -1145,6 +1156,11 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.poll = stepwise ? 0 : 1;
   p.allow_fast = env_int("ASR_LSTM_FAST", 1);
   p.dbg = env_int("ASR_LSTM_DBG", 0);
+  // measured optimum on MI355X (tools/scratch/sweep_poll.sh): forward 14-16 naps (~0.4 us),
+  // BPTT 8 for chains of <= 16 workgroups and none for wider ones
+  p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.P <= 16 ? 8 : 0)
+                  : env_int("ASR_LSTM_PREPOLL_F", pl.P <= 16 ? 14 : 16);
+  p.repoll = bwd ? env_int("ASR_LSTM_REPOLL_B", 1) : env_int("ASR_LSTM_REPOLL_F", 1);
   p.xstride = fwd_xstride();
   const int steps_per_launch = stepwise ? 1 : (r_end - r_begin);
   for (int s0 = r_begin; s0 < r_end; s0 += steps_per_launch) {
