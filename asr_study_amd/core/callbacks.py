@@ -5,10 +5,16 @@ end, the model weights plus a ``meta`` group {``training_args`` yaml attribute,
 reference's constructor ignores monitor/save_best_only (:20-23), so ``best.h5`` is
 simply the latest epoch; kept as is.
 
-File layout (HDF5 through h5lite): /model_weights/w%03d (flattened float32, Keras
-weight order, see Model.get_weights), attribute ``model_config`` (yaml: factory name
-+ kwargs + shapes); /optimizer/s%d; /meta/...  Byte compatibility with Keras-1.2.2
-``model.save`` files is a later-round row."""
+File layout (HDF5 through h5lite): ``/model_weights`` follows Keras 1.2.2's
+``save_weights_to_hdf5_group`` (attribute ``layer_names``; one group per weight-bearing
+layer with attribute ``weight_names`` and one N-D float32 dataset per weight, in the
+order and gate layout of ``Model.get_weights()``: ``bidirectional_k`` = forward W, U, b
+then backward W, U, b; ``timedistributed_k`` = W, b), so ``model.load_weights(file)`` of
+the reference's Keras model reads it and utils/core_utils.load_model reads files the
+reference wrote.  Extra attributes ``model_config`` (yaml: factory name + kwargs) let
+this package rebuild the topology without Keras' JSON graph; /optimizer/...; /meta/...
+as core/callbacks.py:47-56.  (Keras' own ``model_config`` JSON and ``optimizer_weights``
+are not emitted: ``keras.models.load_model`` of such a file is not supported.)"""
 import numpy as np
 import yaml
 
@@ -29,12 +35,38 @@ class Callback(object):
         pass
 
 
+def keras_layers(model, weights):
+    """[(layer name, [(weight name, array), ...])] in Keras-1.2.2 naming for the model's
+    weight-bearing stages (get_weights() order)."""
+    it = iter(weights)
+    out, nb, nd = [], 0, 0
+    for s in model.stages:
+        if s.kind == 'bilstm':
+            nb += 1
+            ws = []
+            for d in ('forward', 'backward'):
+                for part in ('W', 'U', 'b'):
+                    ws.append(('%s_lstm_%d_%s:0' % (d, nb, part), next(it)))
+            out.append(('bidirectional_%d' % nb, ws))
+        elif s.kind == 'dense':
+            nd += 1
+            out.append(('timedistributed_%d' % nd, [('dense_%d_W:0' % nd, next(it)),
+                                                    ('dense_%d_b:0' % nd, next(it))]))
+    return out
+
+
 def save_model(model, filepath, meta=None, model_config=None):
     weights = model.get_weights()
     with h5lite.File(filepath, 'w') as f:
+        f.attrs['keras_version'] = '1.2.2'
         g = f.create_group('model_weights')
-        g.write_vlen_float('weights', [w.reshape(-1) for w in weights])
-        g.attrs['shapes'] = yaml.safe_dump([list(w.shape) for w in weights])
+        layers = keras_layers(model, weights)
+        g.attrs.set_strings('layer_names', [name for name, _ in layers])
+        for name, ws in layers:
+            lg = g.create_group(name)
+            lg.attrs.set_strings('weight_names', [w for w, _ in ws])
+            for wname, val in ws:
+                lg.write_array(wname, val)
         g.attrs['model_config'] = yaml.safe_dump(model_config or getattr(model, 'config', {}))
         if model.optimizer is not None:
             o = f.create_group('optimizer')

@@ -83,6 +83,11 @@ def _load():
         'H5Screate': (hid_t, [C.c_int]),
         'H5Sclose': (herr_t, [hid_t]),
         'H5Sget_simple_extent_npoints': (C.c_int64, [hid_t]),
+        'H5Sget_simple_extent_ndims': (C.c_int, [hid_t]),
+        'H5Sget_simple_extent_dims': (C.c_int, [hid_t, C.POINTER(hsize_t), C.POINTER(hsize_t)]),
+        'H5Aget_space': (hid_t, [hid_t]),
+        'H5Tget_size': (C.c_size_t, [hid_t]),
+        'H5Tis_variable_str': (C.c_int, [hid_t]),
         'H5Sselect_elements': (herr_t, [hid_t, C.c_int, C.c_size_t, C.POINTER(hsize_t)]),
         'H5Tvlen_create': (hid_t, [hid_t]),
         'H5Tcopy': (hid_t, [hid_t]),
@@ -212,6 +217,24 @@ class Dataset(object):
             lib.H5Sclose(msp)
             lib.H5Sclose(fsp)
 
+    def dims(self):
+        """Full N-D shape (Keras weight datasets are N-D; the dataset files are 1-D)."""
+        sp = self.lib.H5Dget_space(self.id)
+        nd = self.lib.H5Sget_simple_extent_ndims(sp)
+        d = (hsize_t * max(nd, 1))()
+        if nd > 0:
+            self.lib.H5Sget_simple_extent_dims(sp, d, None)
+        self.lib.H5Sclose(sp)
+        return tuple(int(d[i]) for i in range(nd))
+
+    def read_array(self):
+        """The whole numeric dataset as a float32 ndarray of its N-D shape."""
+        out = np.empty(self.n, np.float32)
+        if self.n:
+            _chk(self.lib.H5Dread(self.id, _g('H5T_NATIVE_FLOAT_g'), H5S_ALL, H5S_ALL, H5P_DEFAULT,
+                                  out.ctypes.data_as(C.c_void_p)), 'read ' + self.name)
+        return out.reshape(self.dims())
+
     def __getitem__(self, key):
         if isinstance(key, (int, np.integer)):
             k = int(key)
@@ -252,13 +275,14 @@ class _Attrs(object):
         t = lib.H5Aget_type(a)
         cls = lib.H5Tget_class(t)
         try:
-            if cls == H5T_STRING:
-                mt = _vlen_str_type()
-                buf = C.c_char_p()
-                _chk(lib.H5Aread(a, mt, C.byref(buf)), 'attr read')
-                val = (buf.value or b'').decode('utf-8')
-                lib.H5Tclose(mt)
-                return val
+            if cls == H5T_STRING:          # read with the file's own string type
+                if lib.H5Tis_variable_str(t) > 0:
+                    buf = C.c_char_p()
+                    _chk(lib.H5Aread(a, t, C.byref(buf)), 'attr read')
+                    return (buf.value or b'').decode('utf-8')
+                raw = C.create_string_buffer(int(lib.H5Tget_size(t)) + 1)
+                _chk(lib.H5Aread(a, t, raw), 'attr read')
+                return raw.raw.split(b'\0')[0].decode('utf-8')
             if cls == H5T_FLOAT:
                 v = C.c_double()
                 _chk(lib.H5Aread(a, _g('H5T_NATIVE_DOUBLE_g'), C.byref(v)), 'attr read')
@@ -269,6 +293,50 @@ class _Attrs(object):
         finally:
             lib.H5Tclose(t)
             lib.H5Aclose(a)
+
+    def get_strings(self, name):
+        """An attribute holding an ARRAY of strings (Keras' layer_names / weight_names,
+        stored by h5py as fixed-length byte strings) -> list of str."""
+        lib = self.lib
+        if name not in self:
+            raise KeyError(name)
+        a = _chk(lib.H5Aopen(self.obj, name.encode(), H5P_DEFAULT), 'attr ' + name)
+        sp = lib.H5Aget_space(a)
+        n = int(lib.H5Sget_simple_extent_npoints(sp))
+        lib.H5Sclose(sp)
+        ft = lib.H5Aget_type(a)
+        try:
+            if lib.H5Tis_variable_str(ft) > 0:
+                buf = (C.c_char_p * max(n, 1))()      # read with the file's own type:
+                _chk(lib.H5Aread(a, ft, buf), 'attr read ' + name)   # no cset conversion
+                return [(buf[i] or b'').decode('utf-8') for i in range(n)]
+            width = int(lib.H5Tget_size(ft))            # fixed-length, NUL padded
+            raw = C.create_string_buffer(max(n * width, 1))
+            _chk(lib.H5Aread(a, ft, raw), 'attr read ' + name)
+            return [raw.raw[i * width:(i + 1) * width].split(b'\0')[0].decode('utf-8')
+                    for i in range(n)]
+        finally:
+            lib.H5Tclose(ft)
+            lib.H5Aclose(a)
+
+    def set_strings(self, name, strings):
+        """Writes a 1-D array-of-strings attribute (fixed-length bytes, as h5py does for a
+        numpy 'S' array)."""
+        lib = self.lib
+        enc = [s.encode('utf-8') for s in strings]
+        width = max([len(e) for e in enc] + [1])
+        t = _chk(lib.H5Tcopy(_g('H5T_C_S1_g')), 'H5Tcopy')
+        lib.H5Tset_size(t, width)
+        dims = (hsize_t * 1)(len(enc))
+        sp = lib.H5Screate_simple(1, dims, None)
+        a = _chk(lib.H5Acreate2(self.obj, name.encode(), t, sp, H5P_DEFAULT, H5P_DEFAULT),
+                 'attr create')
+        raw = b''.join(e.ljust(width, b'\0') for e in enc)
+        buf = C.create_string_buffer(raw, len(raw) or 1)
+        _chk(lib.H5Awrite(a, t, buf), 'attr write')
+        lib.H5Aclose(a)
+        lib.H5Sclose(sp)
+        lib.H5Tclose(t)
 
     def __setitem__(self, name, value):
         lib = self.lib
@@ -377,6 +445,20 @@ class Group(object):
         _chk(lib.H5Dwrite(d, t, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf), 'write ' + name)
         lib.H5Dclose(d)
         lib.H5Tclose(t)
+
+    def write_array(self, name, array):
+        """N-D float32 dataset (Keras weight layout)."""
+        lib = self.lib
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        shape = a.shape if a.ndim else (1,)
+        dims = (hsize_t * len(shape))(*shape)
+        sp = lib.H5Screate_simple(len(shape), dims, None)
+        d = _chk(lib.H5Dcreate2(self.id, name.encode(), _g('H5T_IEEE_F32LE_g'), sp, H5P_DEFAULT,
+                                H5P_DEFAULT, H5P_DEFAULT), 'create dataset ' + name)
+        lib.H5Sclose(sp)
+        _chk(lib.H5Dwrite(d, _g('H5T_NATIVE_FLOAT_g'), H5S_ALL, H5S_ALL, H5P_DEFAULT,
+                          a.ctypes.data_as(C.c_void_p)), 'write ' + name)
+        lib.H5Dclose(d)
 
     def write_float(self, name, values):
         lib = self.lib

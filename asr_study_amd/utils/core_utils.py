@@ -12,6 +12,7 @@ import yaml
 
 from ..datasets import h5lite
 from . import generic_utils as utils
+from .hparams import HParams
 
 
 def setup_gpu(gpu, allow_growth=False, log_device_placement=False):
@@ -38,15 +39,30 @@ def load_model(model_fname, return_meta=False, mode='train', **kwargs):
     from ..core import optimizers
     with h5lite.File(model_fname, 'r') as f:
         g = f['model_weights']
-        cfg = yaml.safe_load(g.attrs['model_config'])
-        shapes = yaml.safe_load(g.attrs['shapes'])
-        flat = g['weights'][:]
-        weights = [np.asarray(a, np.float32).reshape(s) for a, s in zip(flat, shapes)]
+        cfg = yaml.safe_load(g.attrs['model_config']) if 'model_config' in g.attrs else None
+        if 'layer_names' in g.attrs:       # Keras-1.2.2 weight layout (ours or the reference's)
+            weights = []
+            for lname in g.attrs.get_strings('layer_names'):
+                lg = g[lname]
+                names = lg.attrs.get_strings('weight_names') if 'weight_names' in lg.attrs else []
+                weights += [lg[w].read_array() for w in names]
+        else:                              # round-1 development format
+            shapes = yaml.safe_load(g.attrs['shapes'])
+            weights = [np.asarray(a, np.float32).reshape(s)
+                       for a, s in zip(g['weights'][:], shapes)]
         opt_state = None
         if 'optimizer' in f:
             o = f['optimizer']
             opt_state = (yaml.safe_load(o.attrs['config']), o['state'][:],
                          int(o.attrs['iterations']))
+        if cfg is None:
+            # a file written by the reference: the topology is named in meta/training_args
+            # (train.py:127-129), input / output widths are read off the weights
+            targs = yaml.safe_load(f['meta'].attrs['training_args'])
+            kwargs = HParams().parse(list(targs.get('model_params') or [])).values()
+            kwargs.setdefault('num_features', int(weights[0].shape[0]))
+            kwargs.setdefault('num_classes', int(weights[-1].shape[0]))
+            cfg = {'name': targs['model'], 'kwargs': kwargs}
     factory = utils.get_from_module('core.models', cfg['name'])
     model = factory(**cfg.get('kwargs', {}))
     model.config = cfg

@@ -74,3 +74,79 @@ def test_char_parser_vocab():
     # spaces are collapsed BEFORE digits are dropped (text.py:84-88): a double space survives
     assert p("It's 4 o-clock!").tolist() == p.map('it s  o clock', sanitize=False).tolist()
     assert not p.is_valid('ABC') and p.is_valid('abc')
+
+
+def test_keras122_layout_checkpoint_reader():
+    """The Keras-1.2.2 ``model.save`` + MetaCheckpoint layout written by h5py
+    (tests/golden/gen_keras_h5.py) is read back through h5lite: layer / weight name
+    attributes (arrays of byte strings), N-D float32 weights in file order, meta group."""
+    import yaml
+    from asr_study_amd.datasets import h5lite
+    from asr_study_amd.utils.core_utils import load_meta
+    if not h5lite.available():
+        pytest.skip('libhdf5 not present')
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    want = np.load(os.path.join(here, 'keras122_graves_weights.npz'))
+    fname = os.path.join(here, 'keras122_graves.h5')
+    with h5lite.File(fname, 'r') as f:
+        g = f['model_weights']
+        layers = g.attrs.get_strings('layer_names')
+        assert layers[:4] == ['input_1', 'gaussiannoise_1', 'bidirectional_1', 'timedistributed_1']
+        got = {}
+        for lname in layers:
+            for w in g[lname].attrs.get_strings('weight_names'):
+                got[w] = g[lname][w].read_array()
+        assert list(got) == ['forward_lstm_1_W:0', 'forward_lstm_1_U:0', 'forward_lstm_1_b:0',
+                             'backward_lstm_1_W:0', 'backward_lstm_1_U:0', 'backward_lstm_1_b:0',
+                             'dense_1_W:0', 'dense_1_b:0']
+        for k, v in got.items():
+            assert v.dtype == np.float32 and np.array_equal(v, want[k.replace(':', '_')]), k
+        targs = yaml.safe_load(f['meta'].attrs['training_args'])
+        assert targs['model'] == 'graves2006'
+    meta = load_meta(fname)
+    assert meta['epochs'] == [0, 1, 2] and meta['val_loss'] == [28.0, 22.5, 19.75]
+
+
+def test_keras_layout_writer_roundtrip_and_h5py_view(tmp_path):
+    """What save_model writes is the same layout: names, shapes and values survive, and
+    h5py (when the conda interpreter is around) sees ordinary Keras weight groups."""
+    import subprocess
+    from asr_study_amd.core import callbacks
+    from asr_study_amd.datasets import h5lite
+    if not h5lite.available():
+        pytest.skip('libhdf5 not present')
+
+    class Stage(object):
+        def __init__(self, kind):
+            self.kind = kind
+
+    class Fake(object):
+        stages = [Stage('noise'), Stage('bilstm'), Stage('bilstm'), Stage('dense')]
+        optimizer = None
+        config = {'name': 'brsmv1', 'kwargs': {'num_hiddens': 4}}
+
+        def get_weights(self):
+            rs = np.random.RandomState(3)
+            shapes = [(5, 16), (4, 16), (16,)] * 2 + [(8, 16), (4, 16), (16,)] * 2 + [(8, 7), (7,)]
+            return [rs.randn(*s).astype(np.float32) for s in shapes]
+    fname = str(tmp_path / 'ck.h5')
+    callbacks.save_model(Fake(), fname, meta={'training_args': {'model': 'brsmv1'}, 'epochs': [0]})
+    want = Fake().get_weights()
+    with h5lite.File(fname, 'r') as f:
+        g = f['model_weights']
+        assert g.attrs.get_strings('layer_names') == ['bidirectional_1', 'bidirectional_2',
+                                                       'timedistributed_1']
+        got = []
+        for lname in g.attrs.get_strings('layer_names'):
+            got += [g[lname][w].read_array() for w in g[lname].attrs.get_strings('weight_names')]
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    conda = '/opt/conda/bin/python3.9'
+    if os.path.exists(conda):
+        code = ("import h5py,sys;f=h5py.File(sys.argv[1],'r');g=f['model_weights'];"
+                "n=[x.decode() for x in g.attrs['layer_names']];"
+                "w=[x.decode() for x in g[n[0]].attrs['weight_names']];"
+                "print(n, w[0], g[n[0]][w[0]].shape, g[n[0]][w[0]].dtype)")
+        out = subprocess.run([conda, '-c', code, fname], stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=60)
+        if out.returncode == 0:
+            assert "forward_lstm_1_W:0 (5, 16) float32" in out.stdout.decode()

@@ -93,3 +93,39 @@ def test_cfg5_beam_search_ler_matches_oracle(tmp_path):
             assert hyp == want
         m = model.test_on_batch([('slab', slab), truth, lens])
         assert abs(m[3] - OD.ler(hyp, truth)) < 1e-6
+
+
+def test_load_keras122_layout_checkpoint_and_round_trip(tmp_path):
+    """A checkpoint in the reference's on-disk layout (Keras-1.2.2 weight groups + meta,
+    written by h5py: tests/golden/gen_keras_h5.py) loads into the product model with the
+    topology named in meta/training_args; saving it again and reloading preserves every
+    weight bit for bit, and the forward pass equals the oracle's on those weights."""
+    from asr_study_amd.core.callbacks import save_model
+    from asr_study_amd.utils.core_utils import load_model
+    from oracle import lstm as OL
+    here = os.path.join(ROOT, 'tests', 'golden')
+    want = np.load(os.path.join(here, 'keras122_graves_weights.npz'))
+    model, meta = load_model(os.path.join(here, 'keras122_graves.h5'), return_meta=True)
+    order = ['forward_lstm_1_W_0', 'forward_lstm_1_U_0', 'forward_lstm_1_b_0',
+             'backward_lstm_1_W_0', 'backward_lstm_1_U_0', 'backward_lstm_1_b_0',
+             'dense_1_W_0', 'dense_1_b_0']
+    got = model.get_weights()
+    assert len(got) == 8 and all(np.array_equal(g, want[k]) for g, k in zip(got, order))
+    assert meta['training_args']['model'] == 'graves2006' and meta['epochs'] == [0, 1, 2]
+    again = str(tmp_path / 'again.h5')
+    save_model(model, again, meta)
+    m2 = load_model(again)
+    assert all(np.array_equal(a, b) for a, b in zip(m2.get_weights(), got))
+    rs = np.random.RandomState(0)
+    x = rs.randn(3, 20, 26).astype(np.float32)
+    logits = model.forward(model.to_slab(x)).cpu().numpy()[:, :3]
+    p = {'layers': [{d: {'W': want[d + '_lstm_1_W_0'].astype(np.float64),
+                         'U': want[d + '_lstm_1_U_0'].astype(np.float64),
+                         'b': want[d + '_lstm_1_b_0'].astype(np.float64)}
+                     for d in ('forward', 'backward')}],
+         'dense': {'W': want['dense_1_W_0'].astype(np.float64),
+                   'b': want['dense_1_b_0'].astype(np.float64)}}
+    p['layers'][0] = {'fwd': p['layers'][0]['forward'], 'bwd': p['layers'][0]['backward']}
+    ref = OL.model_forward(p, np.transpose(x, (1, 0, 2)).astype(np.float64))
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert np.abs(logits - ref).max() < 1e-4
