@@ -15,20 +15,52 @@ SOURCES = ['capi.cpp', 'ctc.hip', 'frontend.hip', 'gemm.hip', 'lstm.hip',
 ARCH = 'gfx950'
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [
+STAMP = LIB + '.srchash'
+
+
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES] + [
         os.path.join(CSRC, 'common.h'),
         os.path.join(os.path.dirname(HERE), 'include', 'asr_hip.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale():
+    """Content-based (a snapshot copy may not preserve mtimes): the library is current
+    iff the hash of every source it was built from is recorded next to it."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+        return True
+    with open(STAMP) as f:
+        return f.read().strip() != _source_hash()
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libasr_hip.so."""
+    """Compile every HIP source for gfx950 and link libasr_hip.so.  Safe to call from
+    several processes at once (one rank per GPU): an exclusive file lock serialises
+    them, the first one builds, the others find the library current."""
     if not force and not _stale():
         return LIB
+    import fcntl
+    with open(LIB + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or _stale():
+                _compile(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return LIB
+
+
+def _compile(verbose):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []
@@ -45,9 +77,12 @@ def build(force=False, verbose=False):
         out = p.communicate()[0].decode()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (src, out))
-    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs + ['-lpthread']
+    tmp = LIB + '.tmp.%d' % os.getpid()
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs + ['-lpthread']
     subprocess.check_call(cmd)
-    return LIB
+    os.replace(tmp, LIB)                     # atomic: a loader never sees a partial file
+    with open(STAMP, 'w') as f:
+        f.write(_source_hash() + '\n')
 
 
 if __name__ == '__main__':
