@@ -1156,7 +1156,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.poll = stepwise ? 0 : 1;
   p.allow_fast = env_int("ASR_LSTM_FAST", 1);
   p.dbg = env_int("ASR_LSTM_DBG", 0);
-  // measured optimum on MI355X (tools/scratch/sweep_poll.sh): forward 14-16 naps (~0.4 us),
+  // measured optimum on MI355X (tools/sweep_poll.sh): forward 14-16 naps (~0.4 us),
   // BPTT 8 for chains of <= 16 workgroups and none for wider ones
   p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.P <= 16 ? 8 : 0)
                   : env_int("ASR_LSTM_PREPOLL_F", pl.P <= 16 ? 14 : 16);
