@@ -677,14 +677,23 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
         bh[j] = *reinterpret_cast<const hx8*>(&Bh[wn * 64 + j * 32 + lrow][16 * ks + lk]);
         bl[j] = *reinterpret_cast<const hx8*>(&Bl[wn * 64 + j * 32 + lrow][16 * ks + lk]);
       }
+      // term-major order: consecutive MFMAs go to four different accumulators, so none
+      // waits for the previous one's result (the small cross terms first)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 2; ++j)
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], am[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], am[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], am[i][j], 0, 0, 0);
-        }
     }
     la.apply_mask(fs_a, fs_m);
     h_tile_store(AMN, fs_a, sa, tile(cur ^ 1, 0), tile(cur ^ 1, 1), kq_rot);

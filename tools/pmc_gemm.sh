@@ -1,9 +1,22 @@
 #!/bin/bash
+# PMC passes (one counter group per run) over the GEMM microbenchmark and the bench step.
+# Usage (repo root, on the GPU box): bash tools/pmc_gemm.sh <tag>
 export TMPDIR=/tmp
-out=gpurun_out/pmc_gemm2
+tag=${1:-pmc}
+out=gpurun_out/$tag
 mkdir -p $out
-for set in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum"; do
-  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$tag -o g -- python tools/gemm_microbench.py > $out/$tag.log 2>&1 </dev/null
+i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/gemm_$i -o g -- python tools/gemm_microbench.py > $out/gemm_$i.log 2>&1 </dev/null
+done
+i=0
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/bench_$i -o g -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_$i.log 2>&1 </dev/null
 done
 ls $out
