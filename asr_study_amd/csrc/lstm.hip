@@ -108,6 +108,20 @@ __device__ __forceinline__ void xstore(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, uns
   __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, byte_off, 0, FAST ? 0 : kSc1);
 }
 
+// max over the 16 lanes of a DPP row (quad swaps, then half-row and row mirrors): four
+// VALU ops with a DPP modifier instead of four LDS-crossbar shuffles
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(
+                   __float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, false)));   // [1,0,3,2]
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(
+                   __float_as_int(v), __float_as_int(v), 0x4E, 0xF, 0xF, false)));   // [2,3,0,1]
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(
+                   __float_as_int(v), __float_as_int(v), 0x141, 0xF, 0xF, false)));  // half mirror
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(
+                   __float_as_int(v), __float_as_int(v), 0x140, 0xF, 0xF, false)));  // row mirror
+  return v;
+}
+
 // ---- split-fp16 arithmetic for the recurrent products ------------------------
 // x = hi + lo/2048 with hi = fp16(x), lo = fp16((x - hi) * 2048): 22 mantissa bits.
 // x*y ~= hi_x*hi_y + (hi_x*lo_y + lo_x*hi_y)/2048 (the lo*lo term is 2^-22 relative),
@@ -872,8 +886,7 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
       // power-of-two scale of this batch column: max over its 16 threads (one DPP row)
       float m = fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w)));
       zmax = fmaxf(zmax, m);
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+      m = row16_max(m);
       int ex = 0;
       if (m > 0.f) (void)frexpf(m, &ex); else ex = 9;
       ex = ex < -100 ? -100 : ex;                 // keep 2^(9-ex) finite for denormal maxima
