@@ -563,6 +563,181 @@ lstm_fwd_kernel_h(LstmParams p) {
   else fwd_body_h<NKK, false>(p, chain, wg, lds);
 }
 
+// forward, split-fp16, K split over the waves.  Wave w multiplies ALL 64 gate columns
+// of the workgroup (4 tiles of 16) with ITS quarter of h (32*NKW units): its MFMA
+// B-operand comes straight from its own gather (registers; no LDS staging of h, and a
+// wave whose producers are early starts multiplying while the others still wait); the
+// four partial gate tiles then meet in LDS (one barrier per step, double-buffered by step
+// parity) and wave w finishes unit group w as before.  LDS traffic per step drops from
+// 16 KB written + 64 KB read to 16 KB + 16 KB.
+template <int NKW, bool FAST>
+__device__ __forceinline__ void fwd_body_k(const LstmParams& p, int chain, int wg, float* lds) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, nl = lane & 15;
+  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
+  const int UG = H >> 2;
+  const int dir = chain / p.NB, bt = chain % p.NB;
+  const int ug = wg * 4 + w;                       // the unit group this wave FINISHES
+  const bool ug_ok = ug < UG;
+  const int n = bt * 16 + nl;
+  const int u = 4 * ug + g;
+  const int kbase = 32 * NKW * w;                  // first unit of this wave's K slice
+  f32x4* part = reinterpret_cast<f32x4*>(lds);     // [2 parity][4 waves][4 tiles][64 lanes]
+
+  // stationary A fragments: tile j = gate columns of unit group wg*4+j, this wave's K slice
+  h8 ufh[4][NKW], ufl[4][NKW];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ugj = wg * 4 + j;
+#pragma unroll
+    for (int kk = 0; kk < NKW; ++kk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = kbase + 32 * kk + 8 * g + e;
+        const float x = (ugj < UG && k < H) ? p.U[((size_t)(dir * H + k)) * H4 + 16 * ugj + nl] : 0.f;
+        _Float16 hi, lo;
+        split_f16(x, hi, lo);
+        ufh[j][kk][e] = hi; ufl[j][kk][e] = lo;
+      }
+    }
+  }
+  float mask = 1.f;
+  if (ug_ok && p.mask_u) mask = p.mask_u[((size_t)dir * p.n_pad + n) * H + u];
+  float c = 0.f;
+  bool dead = false;
+  unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;    // [2][UG][16][4]
+  const int slot_words = UG * (p.xstride / 4);
+  const int s_end = p.s_begin + p.s_count;
+  if (ug_ok && p.s_begin > 0) {
+    const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
+    c = p.cell[(((size_t)tpp * p.n_pad + n) * 2 + dir) * H + u];
+  }
+  auto load_zx = [&](int ss) -> float4 {
+    if (!ug_ok || ss >= s_end) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int tt = dir == 0 ? ss : p.T - 1 - ss;
+    return *reinterpret_cast<const float4*>(
+        p.zx + (((size_t)tt * p.n_pad + n) * 2 + dir) * H4 + 4 * u);
+  };
+  float4 zx_next = load_zx(p.s_begin);
+  constexpr int NL = 2 * NKW;                      // 16-byte groups per lane
+  // group i = (kk, half): units kbase + 32kk + 8g + 4*half .. +3 of sample nl
+  unsigned off[NL];
+  bool use[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int gu = (kbase + 32 * (i >> 1) + 8 * g) / 4 + (i & 1);
+    use[i] = gu < UG;
+    off[i] = (unsigned)(gu * p.xstride + nl * 16);
+  }
+  const bool prof = (p.dbg & 32) && wg == 0 && chain == p.chain_begin && lane == 0;
+  long long pt[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+  for (int s = p.s_begin; s < s_end; ++s) {
+    if (prof) tk0 = wall_clock64();
+    const int t = dir == 0 ? s : p.T - 1 - s;
+    const float4 zx4 = zx_next;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
+      __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          xch + (size_t)((s - 1) & 1) * slot_words, 0, slot_words * 4, 0x00020000);
+      u32x4 v[NL];
+      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
+                              p.prepoll, p.repoll);
+      if (prof) tk1 = wall_clock64();
+      zx_next = load_zx(s + 1);
+      // exchanged word = fp16 hi << 16 | fp16 lo; tag bit (lo's LSB) cleared
+      h8 bh[NKW], bl[NKW];
+#pragma unroll
+      for (int kk = 0; kk < NKW; ++kk) {
+        u32x4 q0 = v[2 * kk], q1 = v[2 * kk + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          q0[e] = use[2 * kk] ? (q0[e] & ~1u) : 0u;
+          q1[e] = use[2 * kk + 1] ? (q1[e] & ~1u) : 0u;
+        }
+        u32x4 hi, lo;
+        hi[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x07060302u);
+        hi[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x07060302u);
+        hi[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x07060302u);
+        hi[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x07060302u);
+        lo[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x05040100u);
+        lo[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x05040100u);
+        lo[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x05040100u);
+        lo[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x05040100u);
+        bh[kk] = __builtin_bit_cast(h8, hi);
+        bl[kk] = __builtin_bit_cast(h8, lo);
+      }
+      f32x4* mine = part + ((size_t)(s & 1) * 4 + w) * 4 * 64;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac0 = am, ac1 = am;
+#pragma unroll
+        for (int kk = 0; kk < NKW; ++kk) {
+          am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[j][kk], bh[kk], am, 0, 0, 0);
+          ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[j][kk], bl[kk], ac0, 0, 0, 0);
+          ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[j][kk], bh[kk], ac1, 0, 0, 0);
+        }
+        mine[j * 64 + lane] = am + (ac0 + ac1) * (1.f / kLoScale);
+      }
+      __syncthreads();
+      if (prof) tk2 = wall_clock64();
+      const f32x4* all = part + (size_t)(s & 1) * 4 * 4 * 64 + (size_t)w * 64 + lane;
+      a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
+    } else {
+      zx_next = load_zx(s + 1);
+    }
+    if (prof) { asm volatile("" :: "v"(a[0])); tk3 = wall_clock64(); }
+    if (ug_ok) {
+      const float gi = hard_sigmoid(a[0] + zx4.x);
+      const float gf = hard_sigmoid(a[1] + zx4.y);
+      const float gg = fast_tanh(a[2] + zx4.z);
+      const float go = hard_sigmoid(a[3] + zx4.w);
+      c = gf * c + gi * gg;
+      const float h = go * fast_tanh(c);
+      if (s + 1 < p.T) {
+        const unsigned wtag = (unsigned)(s >> 1) & 1u;
+        _Float16 ph, pl;
+        split_f16(h * mask, ph, pl);
+        const unsigned w0 = ((((unsigned)__builtin_bit_cast(unsigned short, ph) << 16) |
+                              (unsigned)__builtin_bit_cast(unsigned short, pl)) & ~1u) | wtag;
+        // every lane stores its own word: [ug][sample][unit g] -- the four words of a
+        // 16-byte group carry their own tags, so no cross-row shuffle is needed
+        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+            xch + (size_t)(s & 1) * slot_words, 0, slot_words * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(w0, wr, (unsigned)(ug * p.xstride + nl * 16 + g * 4),
+                                              0, FAST ? 0 : kSc1);
+      }
+      const size_t row = (size_t)t * p.n_pad + n;
+      p.y[row * H2 + dir * H + u] = h;
+      p.cell[(row * 2 + dir) * H + u] = c;
+      *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
+          make_float4(gi, gf, gg, go);
+    }
+    if (prof && s > 0) {
+      const long long tk4 = wall_clock64();
+      pt[0] += tk1 - tk0; pt[1] += tk2 - tk1; pt[2] += tk3 - tk2; pt[3] += tk4 - tk3;
+    }
+  }
+  if (prof) {
+    long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
+    for (int i = 0; i < 4; ++i) out[i] = pt[i];
+  }
+}
+
+template <int NKW>
+__global__ void __launch_bounds__(kThreads)
+lstm_fwd_kernel_k(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int chain_local, wg;
+  if (!map_block(p, chain_local, wg)) return;
+  const int chain = p.chain_begin + chain_local;
+  const bool fast = chain_on_one_xcd(p, chain, wg, reinterpret_cast<int*>(lds));
+  if (fast) fwd_body_k<NKW, true>(p, chain, wg, lds);
+  else fwd_body_k<NKW, false>(p, chain, wg, lds);
+}
+
 // ---------------------------------------------------------------------------
 // backward (BPTT).  WG `cw` of a chain owns units [16 cw, 16 cw + 16) = gate
 // columns j in [64 cw, 64 cw + 64).  TPW = output tiles (16 units) per wave.
@@ -990,6 +1165,13 @@ kern_t pick_fwd_h(int nkk) {
     default: return lstm_fwd_kernel_h<16>;
   }
 }
+kern_t pick_fwd_k(int nkk) {
+  switch (nkk) {
+    case 4: return lstm_fwd_kernel_k<1>;
+    case 8: return lstm_fwd_kernel_k<2>;
+    default: return lstm_fwd_kernel_k<4>;
+  }
+}
 kern_t pick_bwd_h(int tpw) {
   switch (tpw) {
     case 1: return lstm_bwd_kernel_h<1>;
@@ -1050,6 +1232,11 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       pl.NKK = nkk <= 4 ? 4 : nkk <= 8 ? 8 : 16;
       pl.shm = (size_t)4 * 16 * (32 * pl.NKK + 8) * 2;
       k = pick_fwd_h(pl.NKK);
+      // K split over the waves (fwd_body_k): wins from H = 256 up, not for narrow layers
+      if (env_int("ASR_LSTM_KSPLIT", pl.NKK >= 8 ? 1 : 0)) {
+        pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
+        k = pick_fwd_k(pl.NKK);
+      }
     }
   } else {
     pl.R = 16; pl.MAXR = 0;
@@ -1172,7 +1359,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   // measured optimum on MI355X (tools/sweep_poll.sh): forward 14-16 naps (~0.4 us),
   // BPTT 8 for chains of <= 16 workgroups and none for wider ones
   p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.P <= 16 ? 8 : 0)
-                  : env_int("ASR_LSTM_PREPOLL_F", pl.P <= 16 ? 14 : 16);
+                  : env_int("ASR_LSTM_PREPOLL_F", pl.P <= 16 ? 12 : 16);
   p.repoll = bwd ? env_int("ASR_LSTM_REPOLL_B", 1) : env_int("ASR_LSTM_REPOLL_F", 1);
   p.xstride = fwd_xstride();
   const int steps_per_launch = stepwise ? 1 : (r_end - r_begin);
