@@ -96,6 +96,7 @@ SIGNATURES = {
                                 C.c_float, C.c_int, void_p]),
     'asr_sgd_step': (C.c_int, [void_p, void_p, void_p, C.c_int64, void_p, C.c_int, void_p,
                                C.c_float, C.c_float, C.c_float, void_p]),
+    'asr_axpby': (C.c_int, [C.c_int64, C.c_float, void_p, C.c_float, void_p, void_p, void_p]),
 }
 
 _lib = None

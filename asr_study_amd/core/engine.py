@@ -132,6 +132,12 @@ class Model(object):
                     ws += [W.astype(np.float32), U.astype(np.float32), b.astype(np.float32)]
                 init.append((s, 'bilstm', ws))
                 f_real, f_pad = 2 * s.H, 2 * s.Hp
+            elif s.kind == 'merge':
+                s.mode, s.skip = st['mode'], int(st['skip'])
+                src = self.stages[s.skip]
+                if (src.f_out, src.f_out_pad) != (f_real, f_pad):
+                    raise ValueError('merge: widths differ (%d vs %d)' % (src.f_out, f_real))
+                s.coef = 1.0 if s.mode == 'sum' else 0.5
             else:
                 raise ValueError(s.kind)
             s.f_out, s.f_out_pad = f_real, f_pad
@@ -284,6 +290,9 @@ class Model(object):
                             >= s.value).to(torch.float32) / (1.0 - s.value)
                     rec['mask'] = keep
                     a = a * keep
+            elif s.kind == 'merge':       # residual: c * (new + skip)
+                out = self._buf('merge%d' % si, a.shape)
+                a = ops.axpby(s.coef, a, s.coef, self._acts[s.skip]['out'], out)
             elif s.kind == 'dense':
                 out = self._buf('dense%d' % si, (T, n_pad, s.n_out))
                 ops.gemm(a, self.params, out, rows, s.n_out, s.f_in_pad, b_off=s.oW,
@@ -422,10 +431,19 @@ class Model(object):
                     ev.record(self._side)
                     self._dz_free[par] = ev
 
+        skip_grads = {}        # stage index -> gradient to add to that stage's OUTPUT
         for si in range(len(self.stages) - 1, -1, -1):
             s = self.stages[si]
             rec = self._acts[si]
             a_in = rec['in']
+            if si in skip_grads:            # the residual branch rejoins here
+                g = skip_grads.pop(si)
+                da = ops.axpby(1.0, da, 1.0, g, self._buf('dskip%d' % si, da.shape))
+            if s.kind == 'merge':
+                if s.coef != 1.0:
+                    da = ops.axpby(s.coef, da, 0.0, da, self._buf('dmerge%d' % si, da.shape))
+                skip_grads[s.skip] = da
+                continue
             first = not any(st.kind in ('dense', 'bilstm') for st in self.stages[:si])
             if s.kind == 'noise':
                 continue
@@ -439,7 +457,7 @@ class Model(object):
                          c_off=s.oW, split_k=split, b_absmax=gmx)
                 ops.colsum(da, rows, s.n_out, s.n_out, self._gview(s.ob, s.n_out))
                 if not first:
-                    dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
+                    dx = self._buf('da_s%d' % si, (T, n_pad, s.f_in_pad))
                     ops.gemm(da, self.params, dx, rows, s.f_in_pad, s.n_out, trans_b=True,
                              b_off=s.oW, a_absmax=gmx)
                     da = dx
@@ -462,7 +480,7 @@ class Model(object):
                 if pipe_b:
                     # after S BPTT steps the gate gradients of frames [T-S, S) are final
                     # in both directions: their dX GEMMs overlap the last quarter
-                    dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
+                    dx = self._buf('da_s%d' % si, (T, n_pad, s.f_in_pad))
                     ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp,
                                      mask_u=BU, mode=self.lstm_mode, dz_absmax=zmx, steps=(0, S))
                     ev = torch.cuda.Event()
@@ -523,7 +541,7 @@ class Model(object):
                     main.wait_event(dx_inner)
                     da = dx
                 elif not first:
-                    dx = self._buf('da%d' % (si % 2), (T, n_pad, s.f_in_pad))
+                    dx = self._buf('da_s%d' % si, (T, n_pad, s.f_in_pad))
                     self._dx_gemm(dz, s, dx, BW, 0, rows, n_pad, zmx)
                     da = dx
                 if not self.overlap:

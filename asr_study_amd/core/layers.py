@@ -7,8 +7,8 @@ N x Bidirectional(LSTM) -> TimeDistributed(Dense)) and hands its two ends to
 (no tensors, no math); ``ctc_model`` turns the chain into the list of stages the
 HIP engine (core/engine.py) executes.  ``LSTM`` keeps the reference override's
 signature (core/layers.py:366-386: zoneout_h/zoneout_c/layer_norm/mi on top of the
-Keras LSTM arguments); the optional cell variants are accepted but only their
-defaults (off) are implemented in this round.
+Keras LSTM arguments); of the optional variants the residual ``merge`` is implemented,
+zoneout / layer_norm / mi only at their defaults (off).
 """
 
 
@@ -122,5 +122,19 @@ class Bidirectional(Layer):
         return 2 * self.lstm.output_dim
 
 
+class Merge(Layer):
+    """keras.layers.merge([a, b], mode): element-wise 'sum' or 'ave' of two tensors of
+    the same width (brsmv1's residual connection, core/models.py:273-276)."""
+
+    def __init__(self, mode, skip):
+        if mode not in ('sum', 'ave'):
+            raise NotImplementedError('merge mode %r (implemented: sum, ave)' % (mode,))
+        self.mode = mode
+        self.skip = skip
+
+
 def merge(inputs, mode=None):
-    raise NotImplementedError('residual merge is not built yet (SURVEY.md row N4)')
+    a, b = inputs
+    if a.features != b.features:
+        raise ValueError('merge: widths differ (%s vs %s)' % (a.features, b.features))
+    return Merge(mode, b)(a)

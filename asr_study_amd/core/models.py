@@ -11,7 +11,7 @@ surface; here that object is core.engine.Model, which runs on the HIP kernels.
 from . import ctc_utils
 from .engine import Model
 from .layers import (Input, GaussianNoise, TimeDistributed, Dense, LSTM, Bidirectional,
-                     Dropout, merge, l2)
+                     Dropout, Merge, merge, l2)
 
 
 def ctc_model(inputs, output, **kwargs):
@@ -26,8 +26,21 @@ def ctc_model(inputs, output, **kwargs):
     if root is not inputs:
         raise ValueError('output is not connected to inputs')
     spec = []
+    # outputs[i] = the symbolic tensor stage i produces (to resolve merge() skip inputs)
+    outputs, cur = [], output
+    while cur.producer is not None:
+        outputs.append(cur)
+        cur = cur.parent
+    outputs = outputs[::-1]
     for layer in chain:
-        if isinstance(layer, GaussianNoise):
+        if isinstance(layer, Merge):
+            if layer.skip is inputs:
+                raise NotImplementedError('merge with the raw model input')
+            src = [i for i, t in enumerate(outputs) if t is layer.skip]
+            if not src:
+                raise ValueError('merge: the skip input is not on the path from inputs')
+            spec.append({'type': 'merge', 'mode': layer.mode, 'skip': src[0]})
+        elif isinstance(layer, GaussianNoise):
             spec.append({'type': 'noise', 'value': layer.sigma})
         elif isinstance(layer, Dropout):
             spec.append({'type': 'dropout', 'value': layer.p})

@@ -169,3 +169,34 @@ extern "C" int asr_sgd_step(float* params, const float* grads, float* vel, int64
   ASR_CHECK_LAUNCH();
   return ASR_OK;
 }
+
+namespace {
+__global__ void __launch_bounds__(256)
+axpby_kernel(int64_t n, float a, const float* __restrict__ x, float b,
+             const float* __restrict__ y, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 p = reinterpret_cast<const float4*>(x)[i];
+    const float4 q = reinterpret_cast<const float4*>(y)[i];
+    reinterpret_cast<float4*>(out)[i] =
+        make_float4(a * p.x + b * q.x, a * p.y + b * q.y, a * p.z + b * q.z, a * p.w + b * q.w);
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = a * x[i] + b * y[i];
+}
+}  // namespace
+
+extern "C" int asr_axpby(int64_t n, float a, const float* x, float b, const float* y, float* out,
+                         asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(x && y && out && n > 0, "axpby: bad arguments");
+  ASR_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                  reinterpret_cast<uintptr_t>(out)) & 15) == 0, "axpby: 16-byte alignment");
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, a, x, b, y, out);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}

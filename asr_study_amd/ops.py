@@ -299,3 +299,15 @@ def frontend_features(cfg, audio, offsets, lengths, host_lengths, n_pad, tables,
         _ptr(tables.get('dct')), _ptr(out), int(t_out), _ptr(frames), _ptr(ws), nbytes,
         _stream()), 'asr_frontend_features')
     return out, frames
+
+
+def axpby(a, x, b, y, out=None):
+    """out = a * x + b * y over contiguous float32 CUDA tensors of equal size (the residual
+    merge of brsmv1 and its gradient); out defaults to a new tensor."""
+    _check_f32(x, y, out)
+    assert x.numel() == y.numel()
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.load().asr_axpby(x.numel(), float(a), _ptr(x), float(b), _ptr(y), _ptr(out),
+                               _stream()), 'asr_axpby')
+    return out

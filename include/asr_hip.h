@@ -260,6 +260,12 @@ int asr_sgd_step(float* params, const float* grads, float* vel, int64_t n,
                  const double* norm_dev, float clipnorm, float lr,
                  float momentum, asr_stream_t stream);
 
+/* out[i] = a * x[i] + b * y[i] (out may alias x or y).  The residual connection of    */
+/* brsmv1(residual=...): keras merge([new_o, o], mode='sum' | 'ave'),                 */
+/* core/models.py:273-276, and its gradient accumulation.                            */
+int asr_axpby(int64_t n, float a, const float* x, float b, const float* y, float* out,
+              asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,7 +168,18 @@ def model_forward(params, x, masks=None):
             hs, cache = lstm_forward(o, p['W'], p['U'], p['b'], rev, BW, BU)
             outs.append(hs); lc[dname] = cache
         caches['layers'].append(lc)
-        o = np.concatenate(outs, axis=-1)
+        new_o = np.concatenate(outs, axis=-1)
+        # brsmv1(residual=mode): o = merge([new_o, o], mode) (core/models.py:273-276);
+        # Keras-1.2.2 merge modes 'sum' (a + b) and 'ave' ((a + b) / 2)
+        mode = params.get('residual')
+        if mode == 'sum':
+            o = new_o + o
+        elif mode == 'ave':
+            o = 0.5 * (new_o + o)
+        elif mode is None:
+            o = new_o
+        else:
+            raise NotImplementedError(mode)
     caches['dense_x'] = o
     logits = o @ params['dense']['W'] + params['dense']['b']
     return logits, caches
@@ -181,17 +192,23 @@ def model_backward(params, caches, dlogits):
     grads['dense'] = {'W': xd.reshape(T * N, D).T @ dlogits.reshape(T * N, -1),
                       'b': dlogits.sum(axis=(0, 1))}
     do = dlogits @ params['dense']['W'].T
+    mode = params.get('residual')
     for li in range(len(params['layers']) - 1, -1, -1):
         H = params['layers'][li]['fwd']['U'].shape[0]
         g = {}
         dx_total = None
+        d_skip = None
+        if mode is not None:        # o = c * (new_o + o_prev): both branches get c * do
+            c = 1.0 if mode == 'sum' else 0.5
+            do = c * do
+            d_skip = do
         for dname, sl in (('fwd', slice(0, H)), ('bwd', slice(H, 2 * H))):
             dx, dW, dU, db = lstm_backward(np.ascontiguousarray(do[..., sl]),
                                            caches['layers'][li][dname])
             g[dname] = {'W': dW, 'U': dU, 'b': db}
             dx_total = dx if dx_total is None else dx_total + dx
         grads['layers'][li] = g
-        do = dx_total
+        do = dx_total if d_skip is None else dx_total + d_skip
     if 'in_dense' in params:
         xi = caches['in_dense_x']
         T, N, D = xi.shape

@@ -168,3 +168,30 @@ def test_infeasible_label_raises_like_tf():
     x = np.zeros((1, 3, 5), np.float32)
     with pytest.raises(ValueError):
         model.loss_and_grads(model.to_slab(x), [[1, 1, 1]], [3])
+
+
+@pytest.mark.parametrize('mode', ['sum', 'ave'])
+def test_brsmv1_residual_connections(mode):
+    """brsmv1(residual=mode): TimeDistributed(Dense(2H)) in front, then
+    o = merge([Bidirectional(LSTM)(o), o], mode) per layer (core/models.py:253-255,
+    273-276) -- logits, loss and every gradient vs the oracle."""
+    from asr_study_amd.core import models
+    rs = np.random.RandomState(7)
+    N, T, F, C, H, L = 4, 19, 9, 7, 8, 3
+    model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
+                          dropout=0.0, weight_decay=0.0, residual=mode, seed=2)
+    w = [a + rs.randn(*a.shape).astype(np.float32) * 0.2 for a in model.get_weights()]
+    model.set_weights(w)
+    x, labels, lens = _batch(rs, N, T, F, C)
+    params = _oracle_params(w, L, in_dense=True)
+    params['residual'] = mode
+    xt = np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float64)
+    want = OL.loss_and_grads(params, xt, labels, lens)
+    slab = model.to_slab(x)
+    ctc, logits, _ = model.loss_and_grads(slab, labels, lens, training=False)
+    torch.cuda.synchronize()
+    assert report('residual logits', logits.cpu().numpy()[:, :N], want['logits']) < 1e-4
+    np.testing.assert_allclose(ctc.cpu().numpy(), want['ctc'], rtol=1e-4)
+    for (name, g), gg in zip(OL.flatten(want['grads']), model.get_gradients()):
+        scale = max(1e-3, np.abs(g).max())
+        assert report('residual grad ' + name, gg, g) < 1e-4 * scale + 1e-6, name

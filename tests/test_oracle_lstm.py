@@ -120,3 +120,40 @@ def test_init_shapes_and_forget_bias():
     np.testing.assert_allclose(u @ u.T, 1.21 * np.eye(8), atol=1e-5)
     assert p['layers'][1]['fwd']['W'].shape == (16, 32)
     assert p['dense']['W'].shape == (16, 28)
+
+
+def test_residual_merge_gradients_match_finite_differences():
+    """brsmv1(residual='sum'|'ave') (core/models.py:253-255,273-276): in-Dense to 2H, then
+    o = merge([BiLSTM(o), o]); the oracle's backward is checked against central
+    differences of sum(logits * w)."""
+    import copy
+    rs = np.random.RandomState(0)
+    T, N, F, H, C = 7, 3, 5, 4, 6
+    p = L.init_model(seed=1, num_features=F, num_hiddens=H, num_layers=2, num_classes=C,
+                      dtype=np.float64)
+    p['in_dense'] = {'W': rs.randn(F, 2 * H) * 0.3, 'b': rs.randn(2 * H) * 0.1}
+    for d in ('fwd', 'bwd'):
+        p['layers'][0][d]['W'] = rs.randn(2 * H, 4 * H) * 0.3
+    x = rs.randn(T, N, F)
+    for mode in ('sum', 'ave'):
+        p['residual'] = mode
+        logits, caches = L.model_forward(p, x)
+        w = rs.randn(*logits.shape)
+        g = L.model_backward(p, caches, w)
+
+        def loss(q):
+            return float((L.model_forward(q, x)[0] * w).sum())
+        for path in (('in_dense', 'W'), ('layers', 0, 'fwd', 'U'), ('layers', 1, 'bwd', 'W'),
+                     ('dense', 'W'), ('in_dense', 'b')):
+            q = copy.deepcopy(p)
+            arr, gr = q, g
+            for k in path[:-1]:
+                arr, gr = arr[k], gr[k]
+            arr, gr = arr[path[-1]], gr[path[-1]]
+            idx = tuple(rs.randint(0, d) for d in arr.shape)
+            arr[idx] += 1e-6
+            lp = loss(q)
+            arr[idx] -= 2e-6
+            lm = loss(q)
+            num = (lp - lm) / 2e-6
+            assert abs(gr[idx] - num) < 1e-5 * max(1.0, abs(num)), (mode, path)
