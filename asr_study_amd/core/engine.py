@@ -50,6 +50,51 @@ class Stage(object):
     pass
 
 
+class _Feeder(object):
+    """Bounded producer queue over a batch generator (Keras' GeneratorEnqueuer with one
+    worker THREAD, train.py:215-216).  The generator's exception, if any, is re-raised in
+    the consumer."""
+
+    def __init__(self, generator, max_q_size=10, device=None):
+        import queue
+        import threading
+        self._q = queue.Queue(maxsize=max(1, int(max_q_size)))
+        self._stop = threading.Event()
+        self._gen = generator
+
+        def work():
+            try:
+                if device is not None and device.type == 'cuda':
+                    torch.cuda.set_device(device)    # the current device is per thread
+                while not self._stop.is_set():
+                    item = next(self._gen)
+                    while not self._stop.is_set():
+                        try:
+                            self._q.put((item, None), timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+            except BaseException as e:           # StopIteration included: surfaces in get()
+                self._q.put((None, e))
+        self._t = threading.Thread(target=work, name='asr-batch-feeder', daemon=True)
+        self._t.start()
+
+    def get(self):
+        item, err = self._q.get()
+        if err is not None:
+            raise err
+        return item
+
+    def close(self):
+        self._stop.set()
+        try:
+            while True:
+                self._q.get_nowait()
+        except Exception:
+            pass
+        self._t.join(timeout=5.0)
+
+
 class Model(object):
     """The object ``ctc_model(inputs, output)`` returns (core/models.py:31-52)."""
 
@@ -666,12 +711,21 @@ class Model(object):
         self.optimizer.step(self)
         dec, dlen = ops.ctc_greedy(logits, sl, N)
         if not sync:
-            return ctc, dec, dlen
+            # snapshots of this step's small result tensors (the buffers behind them are
+            # reused by the next step): metrics can then be fetched one step later
+            return ctc.clone(), dec.clone(), dlen.clone(), self._norm[1:2].clone()
         return self._metrics(ctc, dec, dlen, labels)
 
-    def _metrics(self, ctc, dec, dlen, labels, hyps=None):
+    def _lagged(self, pending):
+        (ctc, dec, dlen, pen), labels, _ = pending
+        return self._metrics(ctc, dec, dlen, labels, pen=pen)
+
+    def _metrics(self, ctc, dec, dlen, labels, hyps=None, pen=None):
         ctc_h = ctc.cpu().numpy().astype(np.float64)
-        pen = float(self._norm[1].item()) if self.optimizer is not None else 0.0
+        if pen is not None:
+            pen = float(pen.item())
+        else:
+            pen = float(self._norm[1].item()) if self.optimizer is not None else 0.0
         if hyps is None:
             dec_h, dlen_h = dec.cpu().numpy(), dlen.cpu().numpy()
             hyps = [dec_h[n, :dlen_h[n]].tolist() for n in range(len(labels))]
@@ -732,37 +786,51 @@ class Model(object):
     def fit_generator(self, generator, samples_per_epoch, nb_epoch, verbose=1, callbacks=None,
                       validation_data=None, nb_val_samples=None, max_q_size=10, nb_worker=1,
                       initial_epoch=0, **kwargs):
-        """Keras-1.2.2 signature (train.py:213-217).  One host thread feeds batches
-        (the reference uses one generator thread, nb_worker=1)."""
+        """Keras-1.2.2 signature (train.py:213-217).  Like Keras' generator queue
+        (``nb_worker=1``: ONE producer thread, ``max_q_size`` batches deep) the batches
+        are drawn on a background thread, so HDF5 reads / padding / label parsing overlap
+        the GPU step; the per-batch metrics of step i are fetched while step i+1 runs
+        (the step itself never synchronises with the host)."""
         callbacks = callbacks or []
         history = []
         for cb in callbacks:
             cb.set_model(self)
             cb.on_train_begin()
-        for epoch in range(initial_epoch, nb_epoch):
-            t0 = time.time()
-            seen, sums = 0, np.zeros(4)
-            while seen < samples_per_epoch:
-                inputs, outputs = next(generator)
-                n = len(np.asarray(inputs[2]).reshape(-1))
-                m = self.train_on_batch(inputs, outputs)
-                sums += np.array(m) * n
-                seen += n
-            logs = dict(zip(self.metrics_names, (sums / max(seen, 1)).tolist()))
-            if validation_data is not None:
-                val = self.evaluate_generator(validation_data, nb_val_samples)
-                for k, v in zip(self.metrics_names, val):
-                    logs['val_' + k] = v
-            if verbose:
-                shown = ' - '.join('%s: %.4f' % (k, logs[k]) for k in
-                                   ('loss', 'decoder_ler', 'val_loss', 'val_decoder_ler')
-                                   if k in logs)
-                print('Epoch %d/%d - %.0fs - %s' % (epoch + 1, nb_epoch, time.time() - t0, shown))
-            history.append(logs)
-            for cb in callbacks:
-                cb.on_epoch_end(epoch, logs)
-            if self.stop_training:
-                break
+        feeder = _Feeder(generator, max_q_size, self.device)
+        try:
+            for epoch in range(initial_epoch, nb_epoch):
+                t0 = time.time()
+                seen, sums = 0, np.zeros(4)
+                pending = None              # (device results, labels, n) of the previous step
+                while seen < samples_per_epoch:
+                    inputs, outputs = feeder.get()
+                    slab, labels, lens = self._unpack_inputs(inputs)
+                    n = len(labels)
+                    res = self.train_on_batch([('slab', slab), labels, lens], outputs, sync=False)
+                    if pending is not None:
+                        sums += np.array(self._lagged(pending)) * pending[2]
+                    pending = (res, labels, n)
+                    seen += n
+                if pending is not None:
+                    sums += np.array(self._lagged(pending)) * pending[2]
+                logs = dict(zip(self.metrics_names, (sums / max(seen, 1)).tolist()))
+                if validation_data is not None:
+                    val = self.evaluate_generator(validation_data, nb_val_samples)
+                    for k, v in zip(self.metrics_names, val):
+                        logs['val_' + k] = v
+                if verbose:
+                    shown = ' - '.join('%s: %.4f' % (k, logs[k]) for k in
+                                       ('loss', 'decoder_ler', 'val_loss', 'val_decoder_ler')
+                                       if k in logs)
+                    print('Epoch %d/%d - %.0fs - %s' % (epoch + 1, nb_epoch, time.time() - t0,
+                                                        shown))
+                history.append(logs)
+                for cb in callbacks:
+                    cb.on_epoch_end(epoch, logs)
+                if self.stop_training:
+                    break
+        finally:
+            feeder.close()
         for cb in callbacks:
             cb.on_train_end()
         return history

@@ -150,3 +150,29 @@ def test_keras_layout_writer_roundtrip_and_h5py_view(tmp_path):
                              stderr=subprocess.PIPE, timeout=60)
         if out.returncode == 0:
             assert "forward_lstm_1_W:0 (5, 16) float32" in out.stdout.decode()
+
+
+def test_batch_feeder_thread_orders_bounds_and_propagates_errors():
+    """fit_generator's producer thread (Keras generator queue, one worker): batches come
+    out in generator order, at most max_q_size are drawn ahead, a generator error is
+    re-raised in the consumer, close() stops the thread."""
+    import threading
+    import time
+    from asr_study_amd.core.engine import _Feeder
+    drawn = []
+
+    def gen():
+        for i in range(1000):
+            drawn.append(i)
+            if i == 7:
+                raise RuntimeError('bad batch')
+            yield i
+    f = _Feeder(gen(), max_q_size=3)
+    time.sleep(0.3)
+    assert len(drawn) <= 3 + 2                 # queue depth + the item in flight
+    got = [f.get() for _ in range(7)]
+    assert got == list(range(7))
+    with pytest.raises(RuntimeError):
+        f.get()
+    f.close()
+    assert not any(t.name == 'asr-batch-feeder' and t.is_alive() for t in threading.enumerate())
