@@ -128,7 +128,10 @@ class Model(object):
         off = 0
         self.stages = []
         segs = []
-        f_real, f_pad = self.num_features, self.num_features
+        # the input features are padded to a multiple of 4 columns (zero column(s), zero
+        # weight rows) so that the first layer's GEMMs qualify for the 16-byte fast path
+        f_real, f_pad = self.num_features, _pad4(self.num_features)
+        self.f_in_pad0 = f_pad
         init = []
 
         def take(n):
@@ -304,8 +307,18 @@ class Model(object):
         {stage_index: (BW (2, n_pad, f_in_pad), BU (2, n_pad, Hp))}.
         """
         T, n_pad, F = x.shape
-        assert F == self.num_features and n_pad % 16 == 0
+        assert F in (self.num_features, self.f_in_pad0) and n_pad % 16 == 0
         rows = T * n_pad
+        if F != self.f_in_pad0:
+            # (T, n_pad, F) -> zero-padded (T, n_pad, pad4(F)); the pad columns of the
+            # buffer are written once (zeros) and never touched again
+            key = ('xpad', (T, n_pad, self.f_in_pad0))
+            fresh = key not in self._bufs
+            xp = self._buf('xpad', (T, n_pad, self.f_in_pad0))
+            if fresh:
+                xp.zero_()
+            xp[:, :, :F].copy_(x)
+            x = xp
         a = x
         self._acts = []
         drawn = [None]
@@ -329,6 +342,8 @@ class Model(object):
                 if training and s.value > 0:
                     noise = torch.randn(a.shape, generator=self._rng, device=self.device)
                     a = a + s.value * noise
+                    if s.f_out_pad != s.f_out and si == 0:
+                        a[:, :, s.f_out:] = 0.0        # keep the input pad columns zero
             elif s.kind == 'dropout':
                 if training and s.value > 0:
                     keep = (torch.rand(a.shape, generator=self._rng, device=self.device)

@@ -65,7 +65,7 @@ def test_brsmv1_small_forward_backward_adam(H, wd, use_masks):
         si = 1                                           # stage 0 is GaussianNoise
         for li in range(L):
             Hp = (H + 3) // 4 * 4
-            f_in_pad = n_in if li == 0 else 2 * Hp
+            f_in_pad = (n_in + 3) // 4 * 4 if li == 0 else 2 * Hp
             mo = {}
             BW = np.ones((2, n_pad, f_in_pad), np.float32)
             BU = np.ones((2, n_pad, Hp), np.float32)
@@ -74,7 +74,7 @@ def test_brsmv1_small_forward_backward_adam(H, wd, use_masks):
                 bu = ((rs.rand(N, H) > 0.2) / 0.8)
                 mo[d] = (bw, bu)
                 if li == 0:
-                    BW[di, :N] = bw
+                    BW[di, :N, :n_in] = bw
                 else:       # padded feature layout [fwd Hp | bwd Hp]
                     BW[di, :N, :H] = bw[:, :H]
                     BW[di, :N, Hp:Hp + H] = bw[:, H:]
