@@ -72,7 +72,10 @@ ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ la
                       int T, int N, int n_pad, int C, int l_max,
                       float* __restrict__ alpha, float* __restrict__ beta,
                       double* __restrict__ logz, float* __restrict__ loss, int do_beta) {
-  constexpr int UNR = 4;
+  // frames per prefetch group: the emissions of the NEXT group are loaded while this one
+  // is processed, so the group must outlast one L2-miss latency (~1-2 us); rows are
+  // re-centred once per group
+  constexpr int UNR = PPL == 1 ? 16 : (PPL == 2 ? 8 : 4);
   const int lane = threadIdx.x;
   const int n = do_beta ? (blockIdx.x >> 1) : blockIdx.x;
   const int dir = do_beta ? (blockIdx.x & 1) : 0;

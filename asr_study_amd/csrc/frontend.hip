@@ -176,7 +176,10 @@ __device__ __forceinline__ float delta_at(const float* __restrict__ x, int ld, i
   return acc / 10.0f;
 }
 
-__global__ void __launch_bounds__(256)
+// one 1024-thread workgroup per utterance: 16 row walkers per feature column
+constexpr int kFinalizeThreads = 1024;
+
+__global__ void __launch_bounds__(1024)
 fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
                    float* __restrict__ full, int max_frames, int fb, int ffull,
                    float* __restrict__ out, int t_out, int n_pad, int f_out,
@@ -190,13 +193,13 @@ fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
   float* x = full + (size_t)utt * max_frames * ffull;
   // ---- deltas (global scratch, visible block-wide after the barrier)
   if (cfg.d) {
-    for (int e = tid; e < T * fb; e += 256) {
+    for (int e = tid; e < T * fb; e += kFinalizeThreads) {
       const int t = e / fb, c = e % fb;
       x[(size_t)t * ffull + fb + c] = delta_at(x, ffull, T, t, c);
     }
     __syncthreads();
     if (cfg.dd) {
-      for (int e = tid; e < T * fb; e += 256) {
+      for (int e = tid; e < T * fb; e += kFinalizeThreads) {
         const int t = e / fb, c = e % fb;
         x[(size_t)t * ffull + 2 * fb + c] = delta_at(x + fb, ffull, T, t, c);
       }
@@ -214,7 +217,7 @@ fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
   };
   (void)nctx;
   // ---- column statistics: thread (cx, ty) walks t = ty, ty+TY, ... of column cx
-  constexpr int CX = 64, TY = 4;
+  constexpr int CX = 64, TY = kFinalizeThreads / 64;
   __shared__ double s_sum[TY][CX];
   __shared__ double s_sq[TY][CX];
   __shared__ float s_mean[CX];
@@ -228,7 +231,12 @@ fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
     s_sum[ty][cx] = sum;
     __syncthreads();
     double mean = 0.0;
-    if (col < f_out) mean = (s_sum[0][cx] + s_sum[1][cx] + s_sum[2][cx] + s_sum[3][cx]) / Ts;
+    if (col < f_out) {
+      double tot = 0.0;
+#pragma unroll
+      for (int i = 0; i < TY; ++i) tot += s_sum[i][cx];
+      mean = tot / Ts;
+    }
     double sq = 0.0;
     if (col < f_out)
       for (int ts = ty; ts < Ts; ts += TY) {
@@ -238,7 +246,10 @@ fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
     s_sq[ty][cx] = sq;
     __syncthreads();
     if (ty == 0 && col < f_out) {
-      const double var = (s_sq[0][cx] + s_sq[1][cx] + s_sq[2][cx] + s_sq[3][cx]) / Ts;
+      double tot = 0.0;
+#pragma unroll
+      for (int i = 0; i < TY; ++i) tot += s_sq[i][cx];
+      const double var = tot / Ts;
       s_mean[cx] = cfg.mean_norm ? (float)mean : 0.f;
       double sd = sqrt(var);
       if (!cfg.mean_norm) {
@@ -333,7 +344,7 @@ extern "C" int asr_frontend_features(const asr_frontend_cfg* cfg, const float* a
   hipLaunchKernelGGL(fe_frames_kernel, grid, dim3(256), 0, stream, *cfg, audio, offsets,
                      lengths, window, mel, mel_range, dct, full, max_frames, ffull);
   ASR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(fe_finalize_kernel, dim3(n_utt), dim3(256), 0, stream, *cfg, lengths,
+  hipLaunchKernelGGL(fe_finalize_kernel, dim3(n_utt), dim3(kFinalizeThreads), 0, stream, *cfg, lengths,
                      full, max_frames, fb, ffull, out, t_out, n_pad, f_out, out_frames);
   ASR_CHECK_LAUNCH();
   if (n_pad > n_utt) {
