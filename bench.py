@@ -254,8 +254,8 @@ def main():
         alg_bytes = {'fwd': 4 * slab_b + slab_b + slab_b + 4 * slab_b,
                      'bwd': slab_b + 4 * slab_b + slab_b + 4 * slab_b}
         # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE),
-        # profiles/r1c_bench_cfg2_hbm_traffic.md; measured at cfg2 only
-        pmc = {'cfg2': {'fwd': 643.94e6, 'bwd': 647.85e6}}.get(args.config, {})
+        # profiles/r1f_bench_cfg2_hbm_traffic.md; measured at cfg2 only
+        pmc = {'cfg2': {'fwd': 644.87e6, 'bwd': 647.96e6}}.get(args.config, {})
 
         def roof(kind, ms, kernel):
             ach = flops / (ms * 1e-3) / 1e12 if ms else None
