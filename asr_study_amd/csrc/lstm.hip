@@ -1348,7 +1348,8 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   }
   if (r_begin == 0) {
     if (p.dz_absmax) ASR_CHECK_HIP(hipMemsetAsync(p.dz_absmax, 0, sizeof(unsigned), stream));
-    ASR_CHECK_HIP(hipMemsetAsync(ws, 0, kStatusBytes, stream));
+    // status words and the (adjacent) XCC table in one fill
+    ASR_CHECK_HIP(hipMemsetAsync(ws, 0, kStatusBytes + cb_, stream));
     ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes + cb_, 0xFF, xb, stream));
   }
   const int chains = 2 * p.NB;
@@ -1365,7 +1366,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   const int steps_per_launch = stepwise ? 1 : (r_end - r_begin);
   for (int s0 = r_begin; s0 < r_end; s0 += steps_per_launch) {
     // the XCC table is rebuilt by every persistent launch (placement may differ)
-    if (!stepwise) ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes, 0, cb_, stream));
+    if (!stepwise && s0 > 0) ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes, 0, cb_, stream));
     for (int cb = 0; cb < chains; cb += pl.chains_per_launch) {
       const int nch = (chains - cb) < pl.chains_per_launch ? (chains - cb) : pl.chains_per_launch;
       p.chain_begin = cb;

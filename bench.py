@@ -274,6 +274,11 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
+            'arithmetic': ('fp32 storage and accumulation; matrix products as split-fp16 (hi+lo) '
+                           'MFMAs, 2^-22 relative error per product (parity tolerance 1e-4); '
+                           'ASR_LSTM_PREC=0 ASR_GEMM_PREC=0 selects exact fp32 MFMA')
+            if os.environ.get('ASR_GEMM_PREC', '1') != '0' or
+            os.environ.get('ASR_LSTM_PREC', '1') != '0' else 'exact fp32 MFMA everywhere',
             'config': {'workload': '%s: %s' % (args.config, cfg['desc']),
                        'global_batch': world * N, 'utterance_seconds': 10.0, 'frames': T,
                        'dropout': args.dropout, 'optimizer': 'adam(clipnorm=400)',
