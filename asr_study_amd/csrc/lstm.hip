@@ -122,6 +122,16 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
+// quad-lane exchanges (DPP quad_perm [1,0,3,2] and [2,3,0,1])
+__device__ __forceinline__ float quad_swap1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1,
+                                                    0xF, 0xF, false));
+}
+__device__ __forceinline__ float quad_swap2(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E,
+                                                    0xF, 0xF, false));
+}
+
 // ---- split-fp16 arithmetic for the recurrent products ------------------------
 // x = hi + lo/2048 with hi = fp16(x), lo = fp16((x - hi) * 2048): 22 mantissa bits.
 // x*y ~= hi_x*hi_y + (hi_x*lo_y + lo_x*hi_y)/2048 (the lo*lo term is 2^-22 relative),
@@ -947,10 +957,11 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
   const int P = p.P;
   const int dir = chain / p.NB, bt = chain % p.NB;
   constexpr int DZH = 72;                         // LDS row stride of the dz tiles (halfs)
-  float* part = lds;                              // [4 waves][256] partial dh sums
-  float* sinv = lds + 4 * 256;                    // [16] 1/scale per batch column
-  _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZH] hi
-  _Float16* dzl = dzh + 16 * DZH;                           // [16][DZH] lo
+  // dz tiles for the MFMA stage, double-buffered by step parity: with no barrier between
+  // gather and cell math, a wave may write step s+1's tile while another still multiplies
+  // step s's (the one barrier per step keeps them at most one step apart)
+  constexpr int kTileFloats = 16 + (2 * 16 * DZH) / 2;        // sinv + hi + lo, in floats
+  float* sinv0 = lds;
 
   h8 ufh[TPW][2], ufl[TPW][2];
 #pragma unroll
@@ -1003,6 +1014,9 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
 
   for (int s = p.s_begin; s < s_end; ++s) {
     if (prof) tk0 = wall_clock64();
+    float* sinv = sinv0 + (size_t)(s & 1) * kTileFloats;      // [16] 1/scale per batch column
+    _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZH] hi
+    _Float16* dzl = dzh + 16 * DZH;                           // [16][DZH] lo
     const int t = dir == 0 ? p.T - 1 - s : s;
     const float dyv = nx_dy, cv = nx_c, cpv = nx_cp;
     const float4 gt = nx_g;
@@ -1012,21 +1026,26 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
       __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)((s - 1) & 1) * slot_words + (size_t)cw * P * 256, 0, P * 256 * 4,
           0x00020000);
+      // Lane (sample s4 = lane>>4 of this wave's four, unit quad q = (lane>>2)&3, sub =
+      // lane&3) gathers the 16-byte group (sample, quad) from the producers sub*TPW+i:
+      // the four loads are summed in registers and the four `sub` lanes with two DPP quad
+      // permutes -- every lane then holds the complete dh of its (sample, quad) and picks
+      // its own unit.  No LDS round trip and no barrier between gather and cell math.
       unsigned off[NL];
       bool use[NL];
       u32x4 v[NL];
+      const int sub = lane & 3;
+      const int grp_in_tile = (4 * w + (lane >> 4)) * 4 + ((lane >> 2) & 3);   // 16-B groups
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        const int grp = tid + i * kThreads;
-        use[i] = grp < P * 64;
-        off[i] = (unsigned)grp * 16u;
+        const int pr = sub * TPW + i;
+        use[i] = pr < P;
+        off[i] = (unsigned)((pr * 64 + grp_in_tile) * 16);
       }
       gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
                               p.prepoll, p.repoll);
       if (prof) tk1 = wall_clock64();
       load_slabs(s + 1);
-      // wave w holds producers w, w+4, ...: add them in registers, then 4 partial
-      // tiles (one per wave) meet in LDS instead of P
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
@@ -1035,10 +1054,12 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
           acc.z += __uint_as_float(v[i][2] & ~1u); acc.w += __uint_as_float(v[i][3] & ~1u);
         }
       }
-      *reinterpret_cast<float4*>(part + 4 * tid) = acc;
-      __syncthreads();
+      acc.x += quad_swap1(acc.x); acc.y += quad_swap1(acc.y);
+      acc.z += quad_swap1(acc.z); acc.w += quad_swap1(acc.w);
+      acc.x += quad_swap2(acc.x); acc.y += quad_swap2(acc.y);
+      acc.z += quad_swap2(acc.z); acc.w += quad_swap2(acc.w);
       if (prof) tk2 = wall_clock64();
-      dh_rec = (part[tid] + part[256 + tid]) + (part[512 + tid] + part[768 + tid]);
+      dh_rec = sub == 0 ? acc.x : sub == 1 ? acc.y : sub == 2 ? acc.z : acc.w;
     } else {
       load_slabs(s + 1);
     }
@@ -1250,7 +1271,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     pl.xchain_words = (size_t)2 * pl.P * pl.P * 256;
     k = pick_bwd(pl.TPW);
     if (pl.prec == 1) {
-      pl.shm = (size_t)(4 * 256 + 16) * 4 + (size_t)2 * 16 * 72 * 2;
+      pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 72 * 2);
       k = pick_bwd_h(pl.TPW);
     }
   }
