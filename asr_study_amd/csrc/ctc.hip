@@ -43,8 +43,25 @@ __device__ __forceinline__ float wave_shift_down(float v, float fill) {
   return __int_as_float(r);
 }
 
+// The recursions run in BASE-2 log space: log-probabilities are stored as log2 p, so a
+// log-sum-exp is max + v_log_f32(v_exp_f32(..) + ..) on the native base-2 transcendentals
+// (no scaling multiplies, and the sum lies in [1, 3], so no denormal fix-up either).
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr double kLn2 = 0.6931471805599453;
+__device__ __forceinline__ float lse2_b2(float a, float b) {
+  const float m = fmaxf(a, b);
+  if (m == kNegInf) return m;
+  return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m));
+}
+__device__ __forceinline__ float lse3_b2(float a, float b, float c) {
+  const float m = fmaxf(fmaxf(a, b), c);
+  if (m == kNegInf) return m;
+  return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) +
+                                   __builtin_amdgcn_exp2f(c - m));
+}
+
 // ---------------------------------------------------------------------------
-// log-softmax over the class axis; one wave per (t, n) row.
+// log2-softmax over the class axis; one wave per (t, n) row.
 __global__ void __launch_bounds__(256)
 ctc_logsoftmax_kernel(const float* __restrict__ logits, float* __restrict__ logp,
                       int rows, int C) {
@@ -60,7 +77,7 @@ ctc_logsoftmax_kernel(const float* __restrict__ logits, float* __restrict__ logp
   for (int c = lane; c < C; c += 64) s += __expf(x[c] - m);
   s = asr_wave_sum(s);
   const float lse = m + __logf(s);
-  for (int c = lane; c < C; c += 64) y[c] = x[c] - lse;
+  for (int c = lane; c < C; c += 64) y[c] = (x[c] - lse) * kLog2e;
 }
 
 // ---------------------------------------------------------------------------
@@ -149,10 +166,10 @@ ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ la
 #pragma unroll
           for (int p = 0; p < PPL; ++p) {
             const float lp1 = (p == 0) ? lprev : sl[p - 1];
-            nsb[p] = asr_lse2(sb[p], lp1) + eb[u];
+            nsb[p] = lse2_b2(sb[p], lp1) + eb[u];
             const float sk = diffp[p] ? lp1 : kNegInf;
             const float e = valid[p] ? el[u][p] : kNegInf;
-            nsl[p] = asr_lse3(sl[p], sb[p], sk) + e;
+            nsl[p] = lse3_b2(sl[p], sb[p], sk) + e;
           }
           float2* out = reinterpret_cast<float2*>(alpha + ((size_t)t * N + n) * SP) + lane * PPL;
 #pragma unroll
@@ -178,9 +195,9 @@ ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ la
     if (lane == 0) {
       const float e1 = fin[2 * L];                          // final blank
       const float e2 = L > 0 ? fin[2 * (L - 1) + 1] : kNegInf;  // last label
-      const double lz = (double)asr_lse2(e1, e2) + off;
+      const double lz = (double)lse2_b2(e1, e2) + off;     // log2 p(l | x)
       logz[n] = lz;
-      loss[n] = (float)(-lz);
+      loss[n] = (float)(-lz * kLn2);
     }
   } else {
     // ----- beta (excludes the emission at t).  Virtual frame Tn has emission 0
@@ -221,15 +238,15 @@ ctc_alpha_beta_kernel(const float* __restrict__ logp, const int* __restrict__ la
             xb[p] = sb[p] + eb[u];
             xl[p] = valid[p] ? sl[p] + el[u][p] : kNegInf;
             // what the PREVIOUS pair's label state may move into from this pair
-            y[p] = asr_lse2(xb[p], diffp[p] ? xl[p] : kNegInf);
+            y[p] = lse2_b2(xb[p], diffp[p] ? xl[p] : kNegInf);
           }
           const float ynext = wave_shift_down(y[0], kNegInf);
           float2* out = reinterpret_cast<float2*>(beta + ((size_t)t * N + n) * SP) + lane * PPL;
 #pragma unroll
           for (int p = 0; p < PPL; ++p) {
             const float yn = (p == PPL - 1) ? ynext : y[p + 1];
-            sb[p] = asr_lse2(xb[p], xl[p]);
-            sl[p] = valid[p] ? asr_lse2(xl[p], yn) : kNegInf;
+            sb[p] = lse2_b2(xb[p], xl[p]);
+            sl[p] = valid[p] ? lse2_b2(xl[p], yn) : kNegInf;
             out[p] = make_float2(sb[p], sl[p]);
           }
         }
@@ -303,8 +320,8 @@ ctc_grad_kernel(const float* __restrict__ alpha, const float* __restrict__ beta,
   if (active && vmax > kNegInf) {
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
-      vb[p] = vb[p] > kNegInf ? __expf(vb[p] - vmax) : 0.f;
-      vl[p] = vl[p] > kNegInf ? __expf(vl[p] - vmax) : 0.f;
+      vb[p] = vb[p] > kNegInf ? __builtin_amdgcn_exp2f(vb[p] - vmax) : 0.f;
+      vl[p] = vl[p] > kNegInf ? __builtin_amdgcn_exp2f(vl[p] - vmax) : 0.f;
       zsum += vb[p] + vl[p];
     }
   }
@@ -332,7 +349,7 @@ ctc_grad_kernel(const float* __restrict__ alpha, const float* __restrict__ beta,
   if (in_range) {
     float* g = grad + ((size_t)t * n_pad + n) * C;
     for (int c = lane; c < C; c += 64) {
-      g[c] = active ? scale * (__expf(g[c]) - bins[c]) : 0.f;
+      g[c] = active ? scale * (__builtin_amdgcn_exp2f(g[c]) - bins[c]) : 0.f;
     }
   }
 }
