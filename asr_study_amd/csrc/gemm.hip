@@ -607,7 +607,9 @@ struct FastLoader {
   }
 };
 
-template <bool AMN, bool BMN, bool MASK>
+// NBUF = 2: double-buffered LDS (80 KB: 2 workgroups per CU, one barrier per slab);
+// NBUF = 1: one LDS buffer (40 KB: 4 workgroups per CU, two barriers per slab).
+template <bool AMN, bool BMN, bool MASK, int NBUF>
 __global__ void __launch_bounds__(256)
 gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_split, int splits,
                        Epilogue ep, HScales hs) {
@@ -656,7 +658,8 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
   const int lrow = lane & 31, lk = 8 * (lane >> 5);
   auto slab = [&](int kt, Frag16 (&fl_a)[1], Frag16 (&fl_m)[1], Frag16 (&fl_b)[1],
                   Frag16 (&fs_a)[1], Frag16 (&fs_m)[1], Frag16 (&fs_b)[1]) {
-    const int cur = kt & 1;
+    const int cur = NBUF == 2 ? (kt & 1) : 0;
+    const int nxt = NBUF == 2 ? (cur ^ 1) : 0;
     // past the last slab every offset is out of range: those loads return zeros, unused
     la.load(kt + 2, fl_a, fl_m);
     lb.load(kt + 2, fl_b, fmb);
@@ -696,8 +699,9 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], am[i][j], 0, 0, 0);
     }
     la.apply_mask(fs_a, fs_m);
-    h_tile_store(AMN, fs_a, sa, tile(cur ^ 1, 0), tile(cur ^ 1, 1), kq_rot);
-    h_tile_store(BMN, fs_b, sb, tile(cur ^ 1, 2), tile(cur ^ 1, 3), kq_rot);
+    if (NBUF == 1) __syncthreads();          // every wave has read the slab
+    h_tile_store(AMN, fs_a, sa, tile(nxt, 0), tile(nxt, 1), kq_rot);
+    h_tile_store(BMN, fs_b, sb, tile(nxt, 2), tile(nxt, 3), kq_rot);
     __syncthreads();
   };
   for (int kt = 0; kt < nk; kt += 2) {
@@ -939,18 +943,25 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
       fb_.p = B.p; fb_.ld = B.ld; fb_.mn_total = B.mn_total; fb_.extent = (unsigned)extent(B);
       fb_.scale = nullptr; fb_.pmask = 0; fb_.scale_ld = 0; fb_.scale_extent = 0;
       const int total = tiles_mn * sp;
+      static const int nbuf = [] { const char* v = getenv("ASR_GEMM_NBUF"); return v ? atoi(v) : 2; }();
       const int key = (A.mn_contig ? 4 : 0) | (B.mn_contig ? 2 : 0) | (A.scale ? 1 : 0);
 #define ASR_FAST_CASE(KEY, AMN, BMN, MASK)                                                    \
       case KEY: {                                                                              \
         static bool done = false;                                                              \
         if (!done) {                                                                           \
           ASR_CHECK_HIP(hipFuncSetAttribute(                                                   \
-              (const void*)gemm_f16x2_fast_kernel<AMN, BMN, MASK>,                             \
+              (const void*)gemm_f16x2_fast_kernel<AMN, BMN, MASK, 2>,                          \
               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                          \
           done = true;                                                                         \
         }                                                                                      \
-        hipLaunchKernelGGL((gemm_f16x2_fast_kernel<AMN, BMN, MASK>), dim3(total), dim3(256),   \
-                           shm, stream, fa_, fb_, a->M, a->N, a->K, kps, sp, ep, hs);          \
+        if (nbuf == 1)                                                                         \
+          hipLaunchKernelGGL((gemm_f16x2_fast_kernel<AMN, BMN, MASK, 1>), dim3(total),         \
+                             dim3(256), shm / 2, stream, fa_, fb_, a->M, a->N, a->K, kps, sp,  \
+                             ep, hs);                                                          \
+        else                                                                                   \
+          hipLaunchKernelGGL((gemm_f16x2_fast_kernel<AMN, BMN, MASK, 2>), dim3(total),         \
+                             dim3(256), shm, stream, fa_, fb_, a->M, a->N, a->K, kps, sp, ep,  \
+                             hs);                                                              \
       } break;
       switch (key) {
         ASR_FAST_CASE(0, false, false, false)
