@@ -43,7 +43,9 @@ class LstmArgs(C.Structure):
                 ('U', void_p), ('mask_u', void_p),
                 ('zx', void_p), ('y', void_p), ('cell', void_p), ('gates', void_p),
                 ('dy', void_p), ('dz', void_p), ('dz_absmax', void_p),
-                ('step_begin', C.c_int), ('step_count', C.c_int)]
+                ('step_begin', C.c_int), ('step_count', C.c_int),
+                ('mi', void_p), ('uh', void_p), ('zone_c', void_p), ('zone_h', void_p),
+                ('wx', void_p), ('dwx', void_p), ('dmi', void_p)]
 
 
 class Segment(C.Structure):

@@ -75,6 +75,15 @@ struct LstmParams {
   float* dz;
   float* dc_state;
   unsigned* dz_absmax;     // optional: max |dz| as float bits (atomicMax)
+  // optional cell variants (core/layers.py:432-469); all NULL on the default path
+  const float* mi;         // (2, 4, 4H): alpha, beta1, beta2, bias per direction
+  float* uh;               // (T, n_pad, 2, 4H) h_prev @ U (fwd writes, BPTT reads)
+  const float* zone_c;     // (T, 2, H) zoneout coefficient of the cell state, per frame
+  const float* zone_h;     // (T, 2, H) ... of the hidden state
+  const float* wx;         // BPTT + mi: x @ W of the forward pass (no bias)
+  float* dwx;              // BPTT + mi: d / d (x @ W); dz then holds d / d (h_prev @ U)
+  float* dmi;              // BPTT + mi: (NB, 2, 4, 4H) per-batch-tile sums of the parameter
+                           //            gradients d alpha, d beta1, d beta2, d bias
   unsigned* xbuf;          // exchange buffer (words)
   long long xchain_words;  // words per chain (2 slots)
   int* xcc;                // [chains][P] XCC id + 1 of every workgroup
@@ -396,7 +405,7 @@ lstm_fwd_kernel(LstmParams p) {
 
 
 // forward, split-fp16 MFMA variant.  NKK = number of K=32 MFMA steps (H <= 32*NKK).
-template <int NKK, bool FAST>
+template <int NKK, bool FAST, bool VAR>
 __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int wg, float* lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -430,6 +439,16 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
   float mask = 1.f;
   if (ug_ok && p.mask_u) mask = p.mask_u[((size_t)dir * p.n_pad + n) * H + u];
   float c = 0.f;
+  float hprev = 0.f;                                // VAR: this lane's own previous h
+  float4 mi_a = make_float4(0.f, 0.f, 0.f, 0.f), mi_b1 = mi_a, mi_b2 = mi_a, mi_b = mi_a;
+  const bool has_mi = VAR && p.mi != nullptr;
+  if (has_mi && ug_ok) {
+    const float* m = p.mi + (size_t)dir * 4 * H4 + 4 * u;
+    mi_a = *reinterpret_cast<const float4*>(m);
+    mi_b1 = *reinterpret_cast<const float4*>(m + H4);
+    mi_b2 = *reinterpret_cast<const float4*>(m + 2 * H4);
+    mi_b = *reinterpret_cast<const float4*>(m + 3 * H4);
+  }
   bool dead = false;
   unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;    // [2][UG][16][4]
   const int slot_words = UG * (p.xstride / 4);
@@ -437,6 +456,7 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
   if (ug_ok && p.s_begin > 0) {
     const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
     c = p.cell[(((size_t)tpp * p.n_pad + n) * 2 + dir) * H + u];
+    if (VAR) hprev = p.y[((size_t)tpp * p.n_pad + n) * H2 + dir * H + u];
   }
   for (int e = tid; e < 4 * tile_halfs; e += kThreads) hb[e] = (_Float16)0.f;
   __syncthreads();
@@ -447,6 +467,12 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
         p.zx + (((size_t)tt * p.n_pad + n) * 2 + dir) * H4 + 4 * u);
   };
   float4 zx_next = load_zx(p.s_begin);
+  auto load_zone = [&](const float* z, int ss) -> float {
+    if (!VAR || z == nullptr || !ug_ok || ss >= s_end) return 1.f;
+    const int tt = dir == 0 ? ss : p.T - 1 - ss;
+    return z[((size_t)tt * 2 + dir) * H + u];
+  };
+  float kc_next = load_zone(p.zone_c, p.s_begin), kh_next = load_zone(p.zone_h, p.s_begin);
   constexpr int NL = (KP * 4 + kThreads - 1) / kThreads;       // 16-B groups per thread
   const bool prof = (p.dbg & 32) && wg == 0 && chain == p.chain_begin && lane == 0;
   long long pt[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
@@ -454,6 +480,7 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
     if (prof) tk0 = wall_clock64();
     const int t = dir == 0 ? s : p.T - 1 - s;
     const float4 zx4 = zx_next;
+    const float kc = kc_next, kh = kh_next;
     f32x4 am0 = {0.f, 0.f, 0.f, 0.f}, am1 = am0, ac0 = am0, ac1 = am0;
     if (s > 0) {
       _Float16* th = hb + (size_t)(s & 1) * 2 * tile_halfs;      // hi tile, lo tile follows
@@ -474,6 +501,7 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
                               p.prepoll, p.repoll);
       if (prof) tk1 = wall_clock64();
       zx_next = load_zx(s + 1);
+      kc_next = load_zone(p.zone_c, s + 1); kh_next = load_zone(p.zone_h, s + 1);
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         if (use[i]) {
@@ -517,16 +545,29 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
       }
     } else {
       zx_next = load_zx(s + 1);
+      kc_next = load_zone(p.zone_c, s + 1); kh_next = load_zone(p.zone_h, s + 1);
     }
     const f32x4 a = (am0 + am1) + (ac0 + ac1) * (1.f / kLoScale);
     if (prof) { asm volatile("" :: "v"(a[0])); tk3 = wall_clock64(); }
     if (ug_ok) {
-      const float gi = hard_sigmoid(a[0] + zx4.x);
-      const float gf = hard_sigmoid(a[1] + zx4.y);
-      const float gg = fast_tanh(a[2] + zx4.z);
-      const float go = hard_sigmoid(a[3] + zx4.w);
-      c = gf * c + gi * gg;
-      const float h = go * fast_tanh(c);
+      float z0, z1, z2, z3;
+      if (has_mi) {       // z = alpha * Wx * Uh + beta1 * Uh + beta2 * Wx + b (layers.py:441-443)
+        z0 = mi_a.x * zx4.x * a[0] + mi_b1.x * a[0] + mi_b2.x * zx4.x + mi_b.x;
+        z1 = mi_a.y * zx4.y * a[1] + mi_b1.y * a[1] + mi_b2.y * zx4.y + mi_b.y;
+        z2 = mi_a.z * zx4.z * a[2] + mi_b1.z * a[2] + mi_b2.z * zx4.z + mi_b.z;
+        z3 = mi_a.w * zx4.w * a[3] + mi_b1.w * a[3] + mi_b2.w * zx4.w + mi_b.w;
+      } else {
+        z0 = a[0] + zx4.x; z1 = a[1] + zx4.y; z2 = a[2] + zx4.z; z3 = a[3] + zx4.w;
+      }
+      const float gi = hard_sigmoid(z0);
+      const float gf = hard_sigmoid(z1);
+      const float gg = fast_tanh(z2);
+      const float go = hard_sigmoid(z3);
+      float cn = gf * c + gi * gg;
+      if (VAR) cn = c + kc * (cn - c);              // zoneout of the cell state (:457-459)
+      c = cn;
+      float h = go * fast_tanh(c);
+      if (VAR) { h = hprev + kh * (h - hprev); hprev = h; }   // ... of the hidden state
       if (s + 1 < p.T) {
         const unsigned wtag = (unsigned)(s >> 1) & 1u;
         _Float16 ph, pl;
@@ -549,6 +590,9 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
       p.cell[(row * 2 + dir) * H + u] = c;
       *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
           make_float4(gi, gf, gg, go);
+      if (VAR && p.uh)
+        *reinterpret_cast<float4*>(p.uh + (row * 2 + dir) * H4 + 4 * u) =
+            make_float4(a[0], a[1], a[2], a[3]);
     }
     if (prof && s > 0) {
       const long long tk4 = wall_clock64();
@@ -569,8 +613,14 @@ lstm_fwd_kernel_h(LstmParams p) {
   if (!map_block(p, chain_local, wg)) return;
   const int chain = p.chain_begin + chain_local;
   const bool fast = chain_on_one_xcd(p, chain, wg, reinterpret_cast<int*>(lds));
-  if (fast) fwd_body_h<NKK, true>(p, chain, wg, lds);
-  else fwd_body_h<NKK, false>(p, chain, wg, lds);
+  const bool var = p.mi || p.zone_c || p.zone_h || p.uh;
+  if (var) {
+    if (fast) fwd_body_h<NKK, true, true>(p, chain, wg, lds);
+    else fwd_body_h<NKK, false, true>(p, chain, wg, lds);
+  } else {
+    if (fast) fwd_body_h<NKK, true, false>(p, chain, wg, lds);
+    else fwd_body_h<NKK, false, false>(p, chain, wg, lds);
+  }
 }
 
 // forward, split-fp16, K split over the waves.  Wave w multiplies ALL 64 gate columns
@@ -947,7 +997,7 @@ lstm_bwd_kernel(LstmParams p) {
 // magnitude, so each batch column n is scaled by its own power of two (max |dz|
 // over the WG's 64 columns -> [2^8, 2^9)) before the fp16 split and the partial
 // sums are unscaled exactly afterwards.
-template <int TPW, bool FAST>
+template <int TPW, bool FAST, bool VAR>
 __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int cw, float* lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -987,8 +1037,21 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
   float cmask = 1.f;
   if (cvalid && p.mask_u) cmask = p.mask_u[((size_t)dir * p.n_pad + cn) * H + cu];
   float dc = 0.f;
+  float dhz = 0.f;                                 // VAR: (1 - k_h) dh carried to the next step
   float zmax = 0.f;
-  if (cvalid && p.s_begin > 0) dc = p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu];
+  const bool has_mi = VAR && p.mi != nullptr;
+  float4 mi_a = make_float4(0.f, 0.f, 0.f, 0.f), mi_b1 = mi_a, mi_b2 = mi_a;
+  float4 g_a = mi_a, g_b1 = mi_a, g_b2 = mi_a, g_b = mi_a;     // parameter-gradient sums
+  if (has_mi && cvalid) {
+    const float* m = p.mi + (size_t)dir * 4 * H4 + 4 * cu;
+    mi_a = *reinterpret_cast<const float4*>(m);
+    mi_b1 = *reinterpret_cast<const float4*>(m + H4);
+    mi_b2 = *reinterpret_cast<const float4*>(m + 2 * H4);
+  }
+  if (cvalid && p.s_begin > 0) {
+    dc = p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu];
+    if (VAR) dhz = p.dc_state[((size_t)(2 + dir) * p.n_pad + cn) * H + cu];
+  }
   bool dead = false;
   unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;
   const size_t slot_words = (size_t)P * P * 256;
@@ -997,10 +1060,11 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
   const bool prof = (p.dbg & 32) && cw == 0 && chain == p.chain_begin && lane == 0;
   long long pt[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
 
-  float nx_dy = 0.f, nx_c = 0.f, nx_cp = 0.f;
-  float4 nx_g = make_float4(0.f, 0.f, 0.f, 0.f);
+  float nx_dy = 0.f, nx_c = 0.f, nx_cp = 0.f, nx_kc = 1.f, nx_kh = 1.f;
+  float4 nx_g = make_float4(0.f, 0.f, 0.f, 0.f), nx_uh = nx_g, nx_wx = nx_g;
   auto load_slabs = [&](int ss) {
     nx_dy = 0.f; nx_c = 0.f; nx_cp = 0.f; nx_g = make_float4(0.f, 0.f, 0.f, 0.f);
+    nx_kc = 1.f; nx_kh = 1.f; nx_uh = nx_g; nx_wx = nx_g;
     if (!cvalid || ss >= s_end) return;
     const int tt = dir == 0 ? p.T - 1 - ss : ss;
     const int tcc = dir == 0 ? tt - 1 : tt + 1;
@@ -1009,6 +1073,14 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
     nx_c = p.cell[(row * 2 + dir) * H + cu];
     if (ss + 1 < p.T) nx_cp = p.cell[(((size_t)tcc * p.n_pad + cn) * 2 + dir) * H + cu];
     nx_g = *reinterpret_cast<const float4*>(p.gates + (row * 2 + dir) * H4 + 4 * cu);
+    if (VAR) {
+      if (p.zone_c) nx_kc = p.zone_c[((size_t)tt * 2 + dir) * H + cu];
+      if (p.zone_h) nx_kh = p.zone_h[((size_t)tt * 2 + dir) * H + cu];
+      if (has_mi) {
+        nx_uh = *reinterpret_cast<const float4*>(p.uh + (row * 2 + dir) * H4 + 4 * cu);
+        nx_wx = *reinterpret_cast<const float4*>(p.wx + (row * 2 + dir) * H4 + 4 * cu);
+      }
+    }
   };
   load_slabs(p.s_begin);
 
@@ -1018,8 +1090,8 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
     _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZH] hi
     _Float16* dzl = dzh + 16 * DZH;                           // [16][DZH] lo
     const int t = dir == 0 ? p.T - 1 - s : s;
-    const float dyv = nx_dy, cv = nx_c, cpv = nx_cp;
-    const float4 gt = nx_g;
+    const float dyv = nx_dy, cv = nx_c, cpv = nx_cp, kc = nx_kc, kh = nx_kh;
+    const float4 gt = nx_g, uh4 = nx_uh, wx4 = nx_wx;
     float dh_rec = 0.f;
     if (s > 0) {
       const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
@@ -1067,17 +1139,43 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
       float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (cvalid) {
         const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
-        const float dh = dyv + cmask * dh_rec;
+        float dh = dyv + cmask * dh_rec;
+        if (VAR) {                      // h = h_prev + k_h (h~ - h_prev)
+          dh += dhz;
+          dhz = (1.f - kh) * dh;
+          dh *= kh;
+        }
         const float tch = fast_tanh(cv);
         const float d_o = dh * tch;
-        const float dcc = dc + dh * go * (1.f - tch * tch);
+        float dcc = dc + dh * go * (1.f - tch * tch);
+        float dcz = 0.f;
+        if (VAR) {                      // c = c_prev + k_c (c~ - c_prev)
+          dcz = (1.f - kc) * dcc;
+          dcc *= kc;
+        }
         const float d_i = dcc * gg, d_g = dcc * gi, d_f = dcc * cpv;
-        dc = dcc * gf;
+        dc = dcc * gf + dcz;
         z4.x = d_i * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
         z4.y = d_f * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
         z4.z = d_g * (1.f - gg * gg);
         z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
-        *reinterpret_cast<float4*>(p.dz + (((size_t)t * p.n_pad + cn) * 2 + dir) * H4 + 4 * cu) = z4;
+        const size_t zoff = (((size_t)t * p.n_pad + cn) * 2 + dir) * H4 + 4 * cu;
+        if (has_mi) {
+          // z = alpha Wx Uh + beta1 Uh + beta2 Wx + b: the recurrent product sees
+          // dz (alpha Wx + beta1), the input projection dz (alpha Uh + beta2)
+          g_a.x += z4.x * wx4.x * uh4.x; g_a.y += z4.y * wx4.y * uh4.y;
+          g_a.z += z4.z * wx4.z * uh4.z; g_a.w += z4.w * wx4.w * uh4.w;
+          g_b1.x += z4.x * uh4.x; g_b1.y += z4.y * uh4.y; g_b1.z += z4.z * uh4.z; g_b1.w += z4.w * uh4.w;
+          g_b2.x += z4.x * wx4.x; g_b2.y += z4.y * wx4.y; g_b2.z += z4.z * wx4.z; g_b2.w += z4.w * wx4.w;
+          g_b.x += z4.x; g_b.y += z4.y; g_b.z += z4.z; g_b.w += z4.w;
+          const float4 dwx = make_float4(z4.x * (mi_a.x * uh4.x + mi_b2.x), z4.y * (mi_a.y * uh4.y + mi_b2.y),
+                                         z4.z * (mi_a.z * uh4.z + mi_b2.z), z4.w * (mi_a.w * uh4.w + mi_b2.w));
+          *reinterpret_cast<float4*>(p.dwx + zoff) = dwx;
+          zmax = fmaxf(zmax, fmaxf(fmaxf(fabsf(dwx.x), fabsf(dwx.y)), fmaxf(fabsf(dwx.z), fabsf(dwx.w))));
+          z4.x *= mi_a.x * wx4.x + mi_b1.x; z4.y *= mi_a.y * wx4.y + mi_b1.y;
+          z4.z *= mi_a.z * wx4.z + mi_b1.z; z4.w *= mi_a.w * wx4.w + mi_b1.w;
+        }
+        *reinterpret_cast<float4*>(p.dz + zoff) = z4;
       }
       // power-of-two scale of this batch column: max over its 16 threads (one DPP row)
       float m = fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w)));
@@ -1141,7 +1239,33 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
     long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
     for (int i = 0; i < 4; ++i) out[i] = pt[i];
   }
-  if (cvalid && p.dc_state) p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu] = dc;
+  if (cvalid && p.dc_state) {
+    p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu] = dc;
+    if (VAR) p.dc_state[((size_t)(2 + dir) * p.n_pad + cn) * H + cu] = dhz;
+  }
+  if (has_mi && p.dmi) {
+    // sums over this tile's 16 samples (LDS float atomics, once per launch), then this
+    // workgroup's slice of the (NB, 2, 4, 4H) partial-gradient array (+= across slices)
+    __syncthreads();
+    float* accum = lds;                              // [4 params][64 gate columns]
+    accum[tid] = 0.f;
+    __syncthreads();
+    if (cvalid) {
+      const float4 gs[4] = {g_a, g_b1, g_b2, g_b};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float* a = accum + k * 64 + 4 * (tid & 15);
+        atomicAdd(a + 0, gs[k].x); atomicAdd(a + 1, gs[k].y);
+        atomicAdd(a + 2, gs[k].z); atomicAdd(a + 3, gs[k].w);
+      }
+    }
+    __syncthreads();
+    const int k = tid >> 6, jcol = 64 * cw + (tid & 63);
+    if (jcol < H4) {
+      float* dst = p.dmi + (((size_t)bt * 2 + dir) * 4 + k) * H4 + jcol;
+      *dst = (p.s_begin > 0 ? *dst : 0.f) + accum[tid];
+    }
+  }
   if (p.dz_absmax) {
     zmax = asr_wave_max(zmax);
     if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
@@ -1156,8 +1280,14 @@ lstm_bwd_kernel_h(LstmParams p) {
   if (!map_block(p, chain_local, cw)) return;
   const int chain = p.chain_begin + chain_local;
   const bool fast = chain_on_one_xcd(p, chain, cw, reinterpret_cast<int*>(lds));
-  if (fast) bwd_body_h<TPW, true>(p, chain, cw, lds);
-  else bwd_body_h<TPW, false>(p, chain, cw, lds);
+  const bool var = p.mi || p.zone_c || p.zone_h;
+  if (var) {
+    if (fast) bwd_body_h<TPW, true, true>(p, chain, cw, lds);
+    else bwd_body_h<TPW, false, true>(p, chain, cw, lds);
+  } else {
+    if (fast) bwd_body_h<TPW, true, false>(p, chain, cw, lds);
+    else bwd_body_h<TPW, false, false>(p, chain, cw, lds);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1254,7 +1384,8 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       pl.shm = (size_t)4 * 16 * (32 * pl.NKK + 8) * 2;
       k = pick_fwd_h(pl.NKK);
       // K split over the waves (fwd_body_k): wins from H = 256 up, not for narrow layers
-      if (env_int("ASR_LSTM_KSPLIT", pl.NKK >= 8 ? 1 : 0)) {
+      const bool variants = a->mi || a->zone_c || a->zone_h || a->uh;   // fwd_body_h only
+      if (!variants && env_int("ASR_LSTM_KSPLIT", pl.NKK >= 8 ? 1 : 0)) {
         pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
         k = pick_fwd_k(pl.NKK);
       }
@@ -1353,6 +1484,17 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.U = a->U; p.mask_u = a->mask_u; p.zx = a->zx; p.y = a->y; p.cell = a->cell;
   p.gates = a->gates; p.dy = a->dy; p.dz = a->dz;
   p.dz_absmax = bwd ? reinterpret_cast<unsigned*>(a->dz_absmax) : nullptr;
+  p.mi = a->mi; p.uh = a->uh; p.zone_c = a->zone_c; p.zone_h = a->zone_h;
+  p.wx = a->wx; p.dwx = a->dwx; p.dmi = a->dmi;
+  if (a->mi) {
+    ASR_CHECK_ARG(a->uh, "lstm: mi needs the uh slab");
+    if (bwd) ASR_CHECK_ARG(a->wx && a->dwx && a->dmi, "lstm bwd: mi needs wx, dwx and dmi");
+    ASR_CHECK_ARG(env_int("ASR_LSTM_PREC", 1) == 1 && a->mode == 0,
+                  "lstm: the cell variants run on the split-fp16 persistent kernels only");
+  }
+  if (a->zone_c || a->zone_h)
+    ASR_CHECK_ARG(env_int("ASR_LSTM_PREC", 1) == 1 && a->mode == 0,
+                  "lstm: the cell variants run on the split-fp16 persistent kernels only");
   p.status = reinterpret_cast<int*>(ws);
   p.xcc = reinterpret_cast<int*>(ws + kStatusBytes);
   p.xbuf = reinterpret_cast<unsigned*>(ws + kStatusBytes + cb_);
@@ -1407,7 +1549,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
 extern "C" size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward) {
   if (!a || a->n_pad <= 0 || a->H <= 0) return 0;
   return kStatusBytes + xcc_bytes(a) + xbuf_bytes(a, backward != 0) +
-         asr_align_up((size_t)2 * a->n_pad * a->H * sizeof(float), 256);
+         asr_align_up((size_t)4 * a->n_pad * a->H * sizeof(float), 256);
 }
 
 extern "C" int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,

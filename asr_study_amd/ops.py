@@ -108,25 +108,28 @@ def colsum(X, M, N, ldx, out, beta=0.0, x_off=0, ws_name='colsum'):
 
 # --------------------------------------------------------------------------- LSTM
 def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=None,
-               dy=None, dz=None, mode=0, dz_absmax=None, steps=None):
+               dy=None, dz=None, mode=0, dz_absmax=None, steps=None, mi=None, uh=None,
+               zone_c=None, zone_h=None, wx=None, dwx=None, dmi=None):
     a = L.LstmArgs()
     a.T, a.n_pad, a.H, a.mode = int(T), int(n_pad), int(H), int(mode)
     a.step_begin, a.step_count = (0, 0) if steps is None else (int(steps[0]), int(steps[1]))
     a.U = U.data_ptr()
     for name, t in (('mask_u', mask_u), ('zx', zx), ('y', y), ('cell', cell),
-                    ('gates', gates), ('dy', dy), ('dz', dz), ('dz_absmax', dz_absmax)):
+                    ('gates', gates), ('dy', dy), ('dz', dz), ('dz_absmax', dz_absmax),
+                    ('mi', mi), ('uh', uh), ('zone_c', zone_c), ('zone_h', zone_h),
+                    ('wx', wx), ('dwx', dwx), ('dmi', dmi)):
         setattr(a, name, t.data_ptr() if t is not None else None)
     return a
 
 
 def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=False,
-                 steps=None):
+                 steps=None, mi=None, uh=None, zone_c=None, zone_h=None):
     """steps=(begin, count): only that slice of the recurrence (consecutive slices from 0
     on the same stream continue one sequence); None = all T steps."""
     lib = L.load()
     _check_f32(zx, U, y, cell, gates, mask_u)
     a = _lstm_args(T, n_pad, H, U, mask_u, zx=zx, y=y, cell=cell, gates=gates, mode=mode,
-                   steps=steps)
+                   steps=steps, mi=mi, uh=uh, zone_c=zone_c, zone_h=zone_h)
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 0)
     ws = WS.get('lstm_fwd', nbytes, zx.device)
     L.check(lib.asr_lstm_seq_fwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_fwd')
@@ -136,11 +139,13 @@ def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=
 
 
 def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check=False,
-                 dz_absmax=None, steps=None):
+                 dz_absmax=None, steps=None, mi=None, uh=None, zone_c=None, zone_h=None,
+                 wx=None, dwx=None, dmi=None):
     lib = L.load()
     _check_f32(dy, U, cell, gates, dz, mask_u)
     a = _lstm_args(T, n_pad, H, U, mask_u, cell=cell, gates=gates, dy=dy, dz=dz, mode=mode,
-                   dz_absmax=dz_absmax, steps=steps)
+                   dz_absmax=dz_absmax, steps=steps, mi=mi, uh=uh, zone_c=zone_c,
+                   zone_h=zone_h, wx=wx, dwx=dwx, dmi=dmi)
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 1)
     ws = WS.get('lstm_bwd', nbytes, dy.device)
     L.check(lib.asr_lstm_seq_bwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_bwd')

@@ -176,6 +176,25 @@ typedef struct asr_lstm_args {
   /* Lets the caller overlap the GEMMs that feed / consume the outer frames   */
   /* with the recurrence over the inner ones.                                 */
   int step_begin, step_count;
+  /* Optional cell variants of the reference's LSTM override (core/layers.py:432-469);  */
+  /* all NULL = the plain cell.  Frames are indexed by t (slab row), not by step.       */
+  /* mi: multiplicative integration z = alpha*Wx*Uh + beta1*Uh + beta2*Wx + b           */
+  /*     (:441-443): (2, 4, 4H) = per direction alpha, beta1, beta2, b (unit-major,     */
+  /*     gate-minor); zx must then be x@W WITHOUT the bias.  uh (T, n_pad, 2, 4H)       */
+  /*     receives h_prev@U in the forward call and is read back by the backward call,   */
+  /*     which also needs wx (= the forward zx) and writes dwx (T, n_pad, 2, 4H) =      */
+  /*     d/d(x@W) -- dz then holds d/d(h_prev@U) -- and dmi (n_pad/16, 2, 4, 4H), the   */
+  /*     per-batch-tile sums of d alpha, d beta1, d beta2, d b (sum over axis 0).       */
+  /* zone_c / zone_h: zoneout (:457-467), new = prev + k*(candidate - prev) with the    */
+  /*     coefficient k (T, 2, H): the per-frame keep mask in training, 1 - level at     */
+  /*     test time.                                                                     */
+  const float* mi;
+  float* uh;
+  const float* zone_c;
+  const float* zone_h;
+  const float* wx;
+  float* dwx;
+  float* dmi;
 } asr_lstm_args;
 size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
 int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,

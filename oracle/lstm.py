@@ -33,11 +33,17 @@ def hard_sigmoid_grad(x):
     return np.where((y >= 0.0) & (y <= 1.0), 0.2, 0.0).astype(x.dtype)
 
 
-def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None):
+def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, kh=None):
     """One direction.  x (T,N,in); W (in,4H); U (H,4H); b (4H).
 
     BW (N,in) / BU (N,H): variational dropout masks (already scaled by 1/(1-p))
-    or None.  Returns (h_seq (T,N,H), cache).
+    or None.  Optional cell variants of the reference override (core/layers.py:432-469):
+    ``mi`` = (alpha, beta1, beta2), each (4H,): multiplicative integration
+    z = alpha*Wx*Uh + beta1*Uh + beta2*Wx + b (:441-443, core/layers_utils.py:45-51);
+    ``kc`` / ``kh`` (T,H): zoneout coefficients of the cell / hidden state,
+    new = prev + k * (candidate - prev) -- k is the per-step keep-mask (shared over the
+    batch, noise_shape=(H,)) in training and the constant 1 - level at test time
+    (core/layers_utils.py:34-42; :457-467).  Returns (h_seq (T,N,H), cache).
     """
     T, N, _ = x.shape
     H = U.shape[0]
@@ -49,34 +55,50 @@ def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None):
     cs = np.zeros((T, N, H), dt)
     gates = np.zeros((T, N, 4 * H), dt)     # post-activation i,f,g,o
     zs = np.zeros((T, N, 4 * H), dt)        # pre-activation
+    uhs = np.zeros((T, N, 4 * H), dt)       # h_prev @ U
+    wxs = np.zeros((T, N, 4 * H), dt)       # x @ W
     order = range(T - 1, -1, -1) if reverse else range(T)
     for t in order:
         hm = h if BU is None else h * BU
-        z = xs[t] @ W + hm @ U + b
+        wx, uh = xs[t] @ W, hm @ U
+        if mi is not None:
+            z = mi[0] * wx * uh + mi[1] * uh + mi[2] * wx + b
+        else:
+            z = wx + uh + b
         i = hard_sigmoid(z[:, :H])
         f = hard_sigmoid(z[:, H:2 * H])
         g = np.tanh(z[:, 2 * H:3 * H])
         o = hard_sigmoid(z[:, 3 * H:])
-        c = f * c + i * g
-        h = o * np.tanh(c)
-        hs[t], cs[t], zs[t] = h, c, z
+        c_new = f * c + i * g
+        if kc is not None:
+            c_new = c + kc[t][None] * (c_new - c)
+        h_new = o * np.tanh(c_new)
+        if kh is not None:
+            h_new = h + kh[t][None] * (h_new - h)
+        h, c = h_new, c_new
+        hs[t], cs[t], zs[t], uhs[t], wxs[t] = h, c, z, uh, wx
         gates[t] = np.concatenate([i, f, g, o], axis=1)
     cache = dict(x=x, xs=xs, W=W, U=U, BW=BW, BU=BU, hs=hs, cs=cs, zs=zs,
-                 gates=gates, reverse=reverse)
+                 gates=gates, reverse=reverse, mi=mi, kc=kc, kh=kh, uhs=uhs, wxs=wxs)
     return hs, cache
 
 
 def lstm_backward(dhs, cache):
-    """BPTT for one direction.  dhs (T,N,H) -> dx, dW, dU, db."""
+    """BPTT for one direction.  dhs (T,N,H) -> dx, dW, dU, db (and, with multiplicative
+    integration, cache['dmi'] = (dalpha, dbeta1, dbeta2))."""
     x, xs, W, U = cache['x'], cache['xs'], cache['W'], cache['U']
     BW, BU = cache['BW'], cache['BU']
     hs, cs, zs, gates = cache['hs'], cache['cs'], cache['zs'], cache['gates']
+    mi, kc, kh = cache.get('mi'), cache.get('kc'), cache.get('kh')
     reverse = cache['reverse']
     T, N, H = hs.shape
     dt = x.dtype
     dW = np.zeros_like(W); dU = np.zeros_like(U); db = np.zeros(4 * H, dt)
+    dmi = [np.zeros(4 * H, dt) for _ in range(3)]
     dxs = np.zeros_like(xs)
     dzs = np.zeros((T, N, 4 * H), dt)
+    das = np.zeros((T, N, 4 * H), dt)
+    dwxs = np.zeros((T, N, 4 * H), dt)
     dh_next = np.zeros((N, H), dt)
     dc_next = np.zeros((N, H), dt)
     order = list(range(T - 1, -1, -1) if reverse else range(T))
@@ -89,26 +111,46 @@ def lstm_backward(dhs, cache):
         g, o = gates[t][:, 2 * H:3 * H], gates[t][:, 3 * H:]
         z = zs[t]
         dh = dhs[t] + dh_next
+        dh_zone = 0.0
+        if kh is not None:                  # h = h_prev + kh (h~ - h_prev)
+            dh_zone = (1.0 - kh[t][None]) * dh
+            dh = kh[t][None] * dh
         tc = np.tanh(cs[t])
         do = dh * tc
         dc = dc_next + dh * o * (1.0 - tc * tc)
+        dc_zone = 0.0
+        if kc is not None:                  # c = c_prev + kc (c~ - c_prev)
+            dc_zone = (1.0 - kc[t][None]) * dc
+            dc = kc[t][None] * dc
         di, dg, df = dc * g, dc * i, dc * c_prev
-        dc_next = dc * f
+        dc_next = dc * f + dc_zone
         dz = np.concatenate([
             di * hard_sigmoid_grad(z[:, :H]),
             df * hard_sigmoid_grad(z[:, H:2 * H]),
             dg * (1.0 - g * g),
             do * hard_sigmoid_grad(z[:, 3 * H:])], axis=1)
         dzs[t] = dz
+        if mi is not None:
+            wx, uh = cache['wxs'][t], cache['uhs'][t]
+            da = dz * (mi[0] * wx + mi[1])      # d loss / d (h_prev @ U)
+            dwx = dz * (mi[0] * uh + mi[2])     # d loss / d (x @ W)
+            dmi[0] += (dz * wx * uh).sum(axis=0)
+            dmi[1] += (dz * uh).sum(axis=0)
+            dmi[2] += (dz * wx).sum(axis=0)
+        else:
+            da = dwx = dz
+        das[t], dwxs[t] = da, dwx
         hm = h_prev if BU is None else h_prev * BU
-        dW += xs[t].T @ dz
-        dU += hm.T @ dz
+        dW += xs[t].T @ dwx
+        dU += hm.T @ da
         db += dz.sum(axis=0)
-        dxs[t] = dz @ W.T
-        dhm = dz @ U.T
-        dh_next = dhm if BU is None else dhm * BU
+        dxs[t] = dwx @ W.T
+        dhm = da @ U.T
+        dh_next = (dhm if BU is None else dhm * BU) + dh_zone
     dx = dxs if BW is None else dxs * BW[None]
     cache['dzs'] = dzs          # gate pre-activation gradients (kernel parity tests)
+    cache['das'], cache['dwxs'] = das, dwxs
+    cache['dmi'] = dmi if mi is not None else None
     return dx, dW, dU, db
 
 
@@ -151,8 +193,10 @@ def init_model(seed=0, num_features=39, num_hiddens=256, num_layers=5,
     return params
 
 
-def model_forward(params, x, masks=None):
-    """x (T,N,F) -> logits (T,N,C), caches.  masks[l][dir] = (BW, BU) or None."""
+def model_forward(params, x, masks=None, zone=None):
+    """x (T,N,F) -> logits (T,N,C), caches.  masks[l][dir] = (BW, BU) or None;
+    zone[l][dir] = (kc, kh) zoneout coefficients ((T,H) each, or None); a direction's
+    parameter dict may carry 'mi' = [alpha, beta1, beta2] (multiplicative integration)."""
     caches = {'layers': []}
     o = x
     if 'in_dense' in params:
@@ -165,7 +209,10 @@ def model_forward(params, x, masks=None):
             BW = BU = None
             if masks is not None and masks[li] is not None:
                 BW, BU = masks[li][dname]
-            hs, cache = lstm_forward(o, p['W'], p['U'], p['b'], rev, BW, BU)
+            kc = kh = None
+            if zone is not None and zone[li] is not None:
+                kc, kh = zone[li][dname]
+            hs, cache = lstm_forward(o, p['W'], p['U'], p['b'], rev, BW, BU, p.get('mi'), kc, kh)
             outs.append(hs); lc[dname] = cache
         caches['layers'].append(lc)
         new_o = np.concatenate(outs, axis=-1)
@@ -206,6 +253,8 @@ def model_backward(params, caches, dlogits):
             dx, dW, dU, db = lstm_backward(np.ascontiguousarray(do[..., sl]),
                                            caches['layers'][li][dname])
             g[dname] = {'W': dW, 'U': dU, 'b': db}
+            if caches['layers'][li][dname].get('dmi') is not None:
+                g[dname]['mi'] = caches['layers'][li][dname]['dmi']
             dx_total = dx if dx_total is None else dx_total + dx
         grads['layers'][li] = g
         do = dx_total if d_skip is None else dx_total + d_skip
@@ -232,12 +281,12 @@ def l2_penalty(params, weight_decay, in_dense_l2=False):
     return tot
 
 
-def loss_and_grads(params, x, labels, seq_len, weight_decay=0.0, masks=None):
+def loss_and_grads(params, x, labels, seq_len, weight_decay=0.0, masks=None, zone=None):
     """ctc_model() training objective and its gradients.
 
     Returns dict(loss (scalar: mean ctc + l2), ctc (N,), logits, grads).
     """
-    logits, caches = model_forward(params, x, masks)
+    logits, caches = model_forward(params, x, masks, zone)
     T, N, C = logits.shape
     ctc_n, dlog = _ctc.ctc_loss_grad(logits, labels, seq_len, dtype=logits.dtype)
     dlog = dlog / N                       # mean over the batch
@@ -262,5 +311,8 @@ def flatten(tree):
         for d in ('fwd', 'bwd'):
             for k in ('W', 'U', 'b'):
                 out.append(('layer%d/%s/%s' % (li, d, k), layer[d][k]))
+            if layer[d].get('mi') is not None:       # Keras add_weight order (layers.py:389-404)
+                for k, a in zip(('mi_alpha', 'mi_beta1', 'mi_beta2'), layer[d]['mi']):
+                    out.append(('layer%d/%s/%s' % (li, d, k), a))
     out += [('dense/W', tree['dense']['W']), ('dense/b', tree['dense']['b'])]
     return out

@@ -130,3 +130,88 @@ def test_step_ranges_continue_one_sequence(T, N, H, cuts):
     for name, a, b in zip(('y', 'cell', 'gates', 'dz', 'absmax'), whole, parts):
         assert np.array_equal(a, b), name
     assert np.abs(whole[3]).max() == whole[4][0]
+
+
+@pytest.mark.parametrize('T,N,H,use_mi,use_zone', [
+    (23, 5, 16, True, False),
+    (23, 5, 16, False, True),
+    (40, 20, 100, True, True),       # ragged K, two batch tiles
+    (31, 16, 256, True, True),
+])
+def test_cell_variants_multiplicative_integration_and_zoneout(T, N, H, use_mi, use_zone):
+    """asr_lstm_args.mi / zone_c / zone_h (core/layers.py:441-443, 457-467) vs the oracle:
+    activations 1e-4; d/d(h@U), d/d(x@W) and the MI parameter gradients 1e-4 * max."""
+    from asr_study_amd import ops
+    F = 7
+    rs, x, p, masks = _case(T, N, F, H, 3 * T + H, False)
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    mi = zone = None
+    mi_d = zc_d = zh_d = None
+    if use_mi:
+        mi = {d: [1.0 + 0.3 * rs.randn(4 * H), 0.6 + 0.3 * rs.randn(4 * H),
+                  0.7 + 0.3 * rs.randn(4 * H)] for d in ('fwd', 'bwd')}
+    if use_zone:
+        zone = {d: ((rs.rand(T, H) > 0.3).astype(np.float64), np.full((T, H), 0.85))
+                for d in ('fwd', 'bwd')}
+    dhs = {d: rs.randn(T, N, H) for d in ('fwd', 'bwd')}
+    want = {}
+    for d, rev in (('fwd', False), ('bwd', True)):
+        hs, cache = OL.lstm_forward(x, p[d]['W'], p[d]['U'], p[d]['b'], rev, None, None,
+                                    mi[d] if mi else None, *(zone[d] if zone else (None, None)))
+        OL.lstm_backward(dhs[d], cache)
+        want[d] = dict(hs=hs, cache=cache)
+    # pack: zx = x@W (+ b unless mi), unit-major
+    zx = np.zeros((T, n_pad, 2, 4 * H), np.float32)
+    U = np.zeros((2, H, 4 * H), np.float32)
+    mi_h = np.zeros((2, 4, 4 * H), np.float32)
+    for di, d in enumerate(('fwd', 'bwd')):
+        z = x @ p[d]['W'] + (0 if use_mi else p[d]['b'])
+        zx[:, :N, di] = gate_major_to_unit_major(z, H)
+        if not use_mi:
+            zx[:, N:, di] = gate_major_to_unit_major(p[d]['b'][None, None], H)
+        U[di] = gate_major_to_unit_major(p[d]['U'], H)
+        if use_mi:
+            for k in range(3):
+                mi_h[di, k] = gate_major_to_unit_major(mi[d][k], H)
+            mi_h[di, 3] = gate_major_to_unit_major(p[d]['b'], H)
+    if use_mi:
+        mi_d = to_dev(mi_h)
+    if use_zone:
+        zc_d = to_dev(np.stack([zone['fwd'][0], zone['bwd'][0]], axis=1).astype(np.float32))
+        zh_d = to_dev(np.stack([zone['fwd'][1], zone['bwd'][1]], axis=1).astype(np.float32))
+    zx_d, U_d = to_dev(zx), to_dev(U)
+    y = torch.zeros(T, n_pad, 2 * H, device=dev)
+    cell = torch.zeros(T, n_pad, 2, H, device=dev)
+    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    uh = torch.zeros(T, n_pad, 2, 4 * H, device=dev) if use_mi else None
+    ops.lstm_seq_fwd(zx_d, U_d, y, cell, gates, T, n_pad, H, check=True, mi=mi_d, uh=uh,
+                     zone_c=zc_d, zone_h=zh_d)
+    yh, ch = y.cpu().numpy(), cell.cpu().numpy()
+    tag = 'variants T%d N%d H%d mi%d z%d' % (T, N, H, use_mi, use_zone)
+    for di, d in enumerate(('fwd', 'bwd')):
+        assert report('h %s %s' % (d, tag), yh[:, :N, di * H:(di + 1) * H], want[d]['hs']) < 1e-4
+        assert report('c %s %s' % (d, tag), ch[:, :N, di], want[d]['cache']['cs']) < 1e-4
+    dy = np.zeros((T, n_pad, 2 * H), np.float32)
+    dy[:, :N, :H], dy[:, :N, H:] = dhs['fwd'], dhs['bwd']
+    dz = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    dwx = torch.zeros(T, n_pad, 2, 4 * H, device=dev) if use_mi else None
+    dmi = torch.zeros(n_pad // 16, 2, 4, 4 * H, device=dev) if use_mi else None
+    ops.lstm_seq_bwd(to_dev(dy), U_d, cell, gates, dz, T, n_pad, H, check=True, mi=mi_d, uh=uh,
+                     zone_c=zc_d, zone_h=zh_d, wx=zx_d if use_mi else None, dwx=dwx, dmi=dmi)
+    dzh = dz.cpu().numpy()
+    for di, d in enumerate(('fwd', 'bwd')):
+        c = want[d]['cache']
+        w = gate_major_to_unit_major(c['das'], H)
+        scale = max(1.0, np.abs(w).max())
+        assert report('d(h@U) %s %s' % (d, tag), dzh[:, :N, di], w) < 1e-4 * scale
+        if use_mi:
+            w2 = gate_major_to_unit_major(c['dwxs'], H)
+            assert report('d(x@W) %s %s' % (d, tag), dwx.cpu().numpy()[:, :N, di], w2) \
+                < 1e-4 * max(1.0, np.abs(w2).max())
+            got = dmi.cpu().numpy().sum(axis=0)[di]
+            db = gate_major_to_unit_major(c['dzs'].sum(axis=(0, 1)), H)
+            for k, ref in enumerate([gate_major_to_unit_major(g, H) for g in c['dmi']] + [db]):
+                assert report('dmi[%d] %s %s' % (k, d, tag), got[k], ref) \
+                    < 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.all(dzh[:, N:] == 0)
