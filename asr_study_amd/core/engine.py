@@ -162,12 +162,20 @@ class Model(object):
                 s.Hp = _pad4(s.H)
                 s.dropout_W, s.dropout_U = st.get('dropout_W', 0.0), st.get('dropout_U', 0.0)
                 s.l2_W, s.l2_U = st.get('l2_W', 0.0), st.get('l2_U', 0.0)
+                s.mi = st.get('mi')                     # [alpha, beta1, beta2] inits or None
+                s.zoneout_c = float(st.get('zoneout_c') or 0.0)
+                s.zoneout_h = float(st.get('zoneout_h') or 0.0)
                 s.oW = take(f_pad * 8 * s.Hp)
                 s.oU = take(2 * s.Hp * 4 * s.Hp)
-                s.ob = take(8 * s.Hp)
                 segs += [(s.oW, _pad4(f_pad * 8 * s.Hp), s.l2_W),
-                         (s.oU, _pad4(2 * s.Hp * 4 * s.Hp), s.l2_U),
-                         (s.ob, _pad4(8 * s.Hp), 0.0)]
+                         (s.oU, _pad4(2 * s.Hp * 4 * s.Hp), s.l2_U)]
+                if s.mi is None:
+                    s.ob = take(8 * s.Hp)
+                    segs.append((s.ob, _pad4(8 * s.Hp), 0.0))
+                else:       # (2, 4, 4Hp): alpha, beta1, beta2, bias per direction
+                    s.omi = take(32 * s.Hp)
+                    s.ob = None
+                    segs.append((s.omi, _pad4(32 * s.Hp), 0.0))
                 ws = []
                 for _ in range(2):      # Keras-1.2.2 consume_less='gpu' init
                     lim = math.sqrt(6.0 / (f_real + 4 * s.H))
@@ -178,6 +186,8 @@ class Model(object):
                     b = np.zeros(4 * s.H)
                     b[s.H:2 * s.H] = 1.0
                     ws += [W.astype(np.float32), U.astype(np.float32), b.astype(np.float32)]
+                    if s.mi is not None:            # k_init: constant vectors (core/initializers.py)
+                        ws += [np.full(4 * s.H, float(k), np.float32) for k in s.mi]
                 init.append((s, 'bilstm', ws))
                 f_real, f_pad = 2 * s.H, 2 * s.Hp
             elif s.kind == 'merge':
@@ -233,14 +243,22 @@ class Model(object):
                 Wp = np.zeros((s.f_in_pad, 2, 4 * s.Hp), np.float32)
                 Up = np.zeros((2, s.Hp, 4 * s.Hp), np.float32)
                 bp = np.zeros((2, 4 * s.Hp), np.float32)
+                mip = np.zeros((2, 4, 4 * s.Hp), np.float32)
                 for d in range(2):
                     W, U, b = [np.asarray(next(it), np.float32) for _ in range(3)]
                     Wp[rows, d] = _gm2um(W, s.H, s.Hp)
                     Up[d, :s.H] = _gm2um(U, s.H, s.Hp)
                     bp[d] = _gm2um(b, s.H, s.Hp)
+                    if s.mi is not None:            # Keras order: W, U, b, alpha, beta1, beta2
+                        for k in range(3):
+                            mip[d, k] = _gm2um(np.asarray(next(it), np.float32), s.H, s.Hp)
+                        mip[d, 3] = bp[d]
                 host[s.oW:s.oW + Wp.size] = Wp.ravel()
                 host[s.oU:s.oU + Up.size] = Up.ravel()
-                host[s.ob:s.ob + bp.size] = bp.ravel()
+                if s.mi is None:
+                    host[s.ob:s.ob + bp.size] = bp.ravel()
+                else:
+                    host[s.omi:s.omi + mip.size] = mip.ravel()
         self.params.copy_(torch.from_numpy(host))
 
     def _unpack(self, flat):
@@ -254,10 +272,16 @@ class Model(object):
                 rows = self._real_rows(s)
                 Wp = flat[s.oW:s.oW + s.f_in_pad * 8 * s.Hp].reshape(s.f_in_pad, 2, 4 * s.Hp)
                 Up = flat[s.oU:s.oU + 2 * s.Hp * 4 * s.Hp].reshape(2, s.Hp, 4 * s.Hp)
-                bp = flat[s.ob:s.ob + 8 * s.Hp].reshape(2, 4 * s.Hp)
+                if s.mi is None:
+                    bp = flat[s.ob:s.ob + 8 * s.Hp].reshape(2, 4 * s.Hp)
+                else:
+                    mip = flat[s.omi:s.omi + 32 * s.Hp].reshape(2, 4, 4 * s.Hp)
+                    bp = mip[:, 3]
                 for d in range(2):
                     out += [_um2gm(Wp[rows, d], s.H, s.Hp), _um2gm(Up[d, :s.H], s.H, s.Hp),
                             _um2gm(bp[d], s.H, s.Hp)]
+                    if s.mi is not None:
+                        out += [_um2gm(mip[d, k], s.H, s.Hp) for k in range(3)]
         return out
 
     def get_weights(self):
@@ -330,7 +354,7 @@ class Model(object):
         def stage_masks(i):
             st = self.stages[i]
             if masks is not None and i in masks:
-                return masks[i]
+                return masks[i][:2]
             if training and (st.dropout_W > 0 or st.dropout_U > 0):
                 if drawn[0] is None:
                     drawn[0] = self._draw_all_masks(n_pad)
@@ -360,9 +384,15 @@ class Model(object):
                 a = out
             elif s.kind == 'bilstm':
                 Hp = s.Hp
-                BW, BU = stage_masks(si)
+                BW, BU = stage_masks(si)[:2]
                 rec['BW'], rec['BU'] = BW, BU
-                zx = self._buf('zx%d_%d' % (nb % 2, Hp), (T, n_pad, 2, 4 * Hp))
+                var = self._variant_args(s, si, T, n_pad, training, masks)
+                rec['var'] = var
+                if s.mi is None:
+                    zx = self._buf('zx%d_%d' % (nb % 2, Hp), (T, n_pad, 2, 4 * Hp))
+                else:       # x@W is needed again by BPTT: one buffer per layer
+                    zx = self._buf('zxmi%d' % si, (T, n_pad, 2, 4 * Hp))
+                    rec['zx'] = zx
                 nb += 1
                 main = torch.cuda.current_stream(self.device)
                 inner_done = pre.pop(si, None)
@@ -377,7 +407,8 @@ class Model(object):
                 gates = self._buf('gates%d' % si, (T, n_pad, 2, 4 * Hp))
                 U = self._view(s.oU, 2 * Hp * 4 * Hp)
                 nxt = self.stages[si + 1] if si + 1 < len(self.stages) else None
-                if pipe and nxt is not None and nxt.kind == 'bilstm':
+                if pipe and nxt is not None and nxt.kind == 'bilstm' and not var \
+                        and nxt.mi is None:
                     # after S = 3T/4 steps the frames [T-S, S) of y are final in BOTH
                     # directions: the next layer's input projection of those frames runs
                     # on the pipe stream while this recurrence finishes its last quarter
@@ -397,19 +428,49 @@ class Model(object):
                                                  mode=self.lstm_mode, steps=(S, T - S))
                 else:
                     rec['ws'] = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
-                                                 mode=self.lstm_mode)
+                                                 mode=self.lstm_mode, **var)
                 rec.update(y=y, cell=cell, gates=gates)
                 a = y
             rec['out'] = a
             self._acts.append(rec)
         return a
 
+    def _variant_args(self, s, si, T, n_pad, training, masks):
+        """Keyword arguments of the optional cell variants for ops.lstm_seq_fwd (and, with
+        the backward extras added later, lstm_seq_bwd): {} for the plain cell."""
+        var = {}
+        if s.mi is not None:
+            var['mi'] = self._view(s.omi, 32 * s.Hp)
+            var['uh'] = self._buf('uh%d' % si, (T, n_pad, 2, 4 * s.Hp))
+        if s.zoneout_c > 0 or s.zoneout_h > 0:
+            if masks is not None and si in masks and len(masks[si]) == 4:
+                kc, kh = masks[si][2], masks[si][3]          # explicit (T, 2, Hp) coefficients
+            else:
+                def coef(level, name):
+                    if not (0 < level < 1):
+                        return None
+                    buf = self._buf('%s%d' % (name, si), (T, 2, s.Hp))
+                    if training:    # keep mask, shared over the batch, fresh every frame
+                        buf.copy_((torch.rand(buf.shape, generator=self._rng, device=self.device)
+                                   >= level).to(torch.float32))
+                    else:           # test phase: (h - h_prev) * (1 - level) + h_prev
+                        buf.fill_(1.0 - level)
+                    return buf
+                kc, kh = coef(s.zoneout_c, 'zonec'), coef(s.zoneout_h, 'zoneh')
+            if kc is not None:
+                var['zone_c'] = kc
+            if kh is not None:
+                var['zone_h'] = kh
+        return var
+
     def _gate_gemm(self, a, s, zx, BW, r0, r1, n_pad):
         """zx[r0:r1] = (a[r0:r1] (.) B_W) @ W + b over slab rows [r0, r1) (whole frames)."""
         m, Hp = r1 - r0, s.Hp
         if m <= 0:
             return
-        bias = self._view(s.ob, 8 * Hp)
+        # with multiplicative integration the bias enters inside the cell (z = alpha Wx Uh
+        # + beta1 Uh + beta2 Wx + b), so the projection is the bare product
+        bias = self._view(s.ob, 8 * Hp) if s.mi is None else None
         if BW is None:
             ops.gemm(a, self.params, zx, m, 8 * Hp, s.f_in_pad, a_off=r0 * s.f_in_pad,
                      b_off=s.oW, c_off=r0 * 8 * Hp, bias=bias)
@@ -417,7 +478,8 @@ class Model(object):
         for d in range(2):      # each direction has its own input mask (two Keras layers)
             ops.gemm(a, self.params, zx, m, 4 * Hp, s.f_in_pad, ldb=8 * Hp, ldc=8 * Hp,
                      a_off=r0 * s.f_in_pad, b_off=s.oW + d * 4 * Hp,
-                     c_off=r0 * 8 * Hp + d * 4 * Hp, bias=bias[d * 4 * Hp:(d + 1) * 4 * Hp],
+                     c_off=r0 * 8 * Hp + d * 4 * Hp,
+                     bias=None if bias is None else bias[d * 4 * Hp:(d + 1) * 4 * Hp],
                      a_scale=BW[d], a_scale_period=n_pad)
 
     def _dx_gemm(self, dz, s, dx, BW, r0, r1, n_pad, zmx):
@@ -533,8 +595,14 @@ class Model(object):
                     main.wait_event(self._dz_free[par])
                 U = self._view(s.oU, 2 * Hp * 4 * Hp)
                 zmx = self._buf('dzmax%d' % par, (1,))
+                var = dict(rec.get('var') or {})
+                gsrc = dz                  # slab the dW / dX GEMMs read
+                if s.mi is not None:
+                    gsrc = self._buf('dwx%d' % par, (T, n_pad, 2, 4 * Hp))
+                    dmi = self._buf('dmi%d' % si, (n_pad // 16, 2, 4, 4 * Hp))
+                    var.update(wx=rec['zx'], dwx=gsrc, dmi=dmi)
                 pipe_b = (self.pipeline and self._pipe is not None and not first
-                          and self.lstm_mode == 0 and T >= 16)
+                          and self.lstm_mode == 0 and T >= 16 and not var)
                 S = (3 * T) // 4
                 dx = None
                 if pipe_b:
@@ -557,7 +625,7 @@ class Model(object):
                 else:
                     rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad,
                                                    Hp, mask_u=BU, mode=self.lstm_mode,
-                                                   dz_absmax=zmx)
+                                                   dz_absmax=zmx, **var)
                     flush_side()    # previous layer's dW/dU/db now overlap this BPTT
                 y = rec['y']
 
@@ -577,8 +645,9 @@ class Model(object):
                         else:
                             self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
 
-                def grads_W(wsn, s=s, dz=dz, a_in=a_in, BW=BW, Hp=Hp, zmx=zmx):
-                    # dW = (x (.) B_W)^T dz, db = colsum(dz)
+                def grads_W(wsn, s=s, dz=gsrc, a_in=a_in, BW=BW, Hp=Hp, zmx=zmx,
+                            dmi=var.get('dmi')):
+                    # dW = (x (.) B_W)^T d(x@W), db = colsum(dz)
                     if BW is None:
                         ops.gemm(a_in, dz, self.grads, s.f_in_pad, 8 * Hp, rows, trans_a=True,
                                  c_off=s.oW, split_k=split, ws_name=wsn, b_absmax=zmx)
@@ -588,8 +657,12 @@ class Model(object):
                                      ldb=8 * Hp, ldc=8 * Hp, b_off=d * 4 * Hp,
                                      c_off=s.oW + d * 4 * Hp, split_k=split, a_scale=BW[d],
                                      a_scale_period=n_pad, ws_name=wsn, b_absmax=zmx)
-                    ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp),
-                               ws_name=wsn + '_cs')
+                    if dmi is None:
+                        ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp),
+                                   ws_name=wsn + '_cs')
+                    else:   # d alpha, d beta1, d beta2, d b: per-batch-tile sums from BPTT
+                        ops.colsum(dmi, n_pad // 16, 32 * Hp, 32 * Hp,
+                                   self._gview(s.omi, 32 * Hp), ws_name=wsn + '_cs')
 
                 def weight_grads(wsn, gu=grads_U, gw=grads_W):
                     gu(wsn)
@@ -602,7 +675,7 @@ class Model(object):
                     da = dx
                 elif not first:
                     dx = self._buf('da_s%d' % si, (T, n_pad, s.f_in_pad))
-                    self._dx_gemm(dz, s, dx, BW, 0, rows, n_pad, zmx)
+                    self._dx_gemm(gsrc, s, dx, BW, 0, rows, n_pad, zmx)
                     da = dx
                 if not self.overlap:
                     weight_grads('gemm')

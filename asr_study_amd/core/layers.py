@@ -7,8 +7,8 @@ N x Bidirectional(LSTM) -> TimeDistributed(Dense)) and hands its two ends to
 (no tensors, no math); ``ctc_model`` turns the chain into the list of stages the
 HIP engine (core/engine.py) executes.  ``LSTM`` keeps the reference override's
 signature (core/layers.py:366-386: zoneout_h/zoneout_c/layer_norm/mi on top of the
-Keras LSTM arguments); of the optional variants the residual ``merge`` is implemented,
-zoneout / layer_norm / mi only at their defaults (off).
+Keras LSTM arguments); of the optional variants the residual ``merge``, multiplicative
+integration and zoneout are implemented, layer_norm is not.
 """
 
 
@@ -87,17 +87,23 @@ class LSTM(object):
     """core/layers.py:356-479 (reference override of keras.layers.LSTM).
 
     Implemented: consume_less='gpu' fused layout, hard_sigmoid inner activation,
-    tanh activation, variational dropout_W / dropout_U, W/U l2 regularisers.
+    tanh activation, variational dropout_W / dropout_U, W/U l2 regularisers,
+    multiplicative integration (mi=[alpha, beta1, beta2] inits) and zoneout_c / zoneout_h.
     """
 
     def __init__(self, output_dim, zoneout_h=0., zoneout_c=0., layer_norm=None, mi=None,
                  return_sequences=True, consume_less='gpu', W_regularizer=None,
                  U_regularizer=None, dropout_W=0., dropout_U=0., activation='tanh',
                  inner_activation='hard_sigmoid', **kwargs):
-        if zoneout_h or zoneout_c or layer_norm is not None or mi is not None:
+        if layer_norm is not None:
             raise NotImplementedError(
-                'zoneout / layer_norm / mi cell variants are not built yet '
-                '(SURVEY.md row N4); use the defaults (off)')
+                'layer_norm is not built yet (SURVEY.md row N4): it needs three extra '
+                'cross-workgroup reductions per recurrent step')
+        if mi is not None and len(mi) != 3:
+            raise ValueError('mi = [alpha_init, beta1_init, beta2_init]')
+        self.mi = None if mi is None else [float(v) for v in mi]
+        self.zoneout_h = float(zoneout_h or 0.0)
+        self.zoneout_c = float(zoneout_c or 0.0)
         if activation != 'tanh' or inner_activation != 'hard_sigmoid':
             raise NotImplementedError('only tanh / hard_sigmoid are implemented')
         if not return_sequences:

@@ -195,3 +195,64 @@ def test_brsmv1_residual_connections(mode):
     for (name, g), gg in zip(OL.flatten(want['grads']), model.get_gradients()):
         scale = max(1e-3, np.abs(g).max())
         assert report('residual grad ' + name, gg, g) < 1e-4 * scale + 1e-6, name
+
+
+def test_brsmv1_multiplicative_integration_and_zoneout():
+    """brsmv1(mi=[...], zoneout=...) (core/models.py:260-271, core/layers.py:389-404,
+    441-443, 457-467): weights in Keras order [W, U, b, alpha, beta1, beta2] per direction,
+    logits / loss / every gradient (incl. d alpha, d beta1, d beta2) vs the oracle, with
+    explicit zoneout keep masks; then the test-phase (1 - level) path."""
+    from asr_study_amd.core import models
+    rs = np.random.RandomState(11)
+    N, T, F, C, H, L = 5, 21, 9, 7, 12, 2
+    model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
+                          dropout=0.0, weight_decay=0.0, mi=[1.0, 0.5, 0.5], zoneout=0.25, seed=5)
+    w = [a + rs.randn(*a.shape).astype(np.float32) * 0.15 for a in model.get_weights()]
+    assert len(w) == L * 12 + 2
+    model.set_weights(w)
+    for a, b in zip(model.get_weights(), w):
+        assert np.array_equal(a, b)
+    it = iter([a.astype(np.float64) for a in w])
+    params = {'layers': []}
+    for _ in range(L):
+        layer = {}
+        for d in ('fwd', 'bwd'):
+            layer[d] = {'W': next(it), 'U': next(it), 'b': next(it)}
+            layer[d]['mi'] = [next(it), next(it), next(it)]
+        params['layers'].append(layer)
+    params['dense'] = {'W': next(it), 'b': next(it)}
+    x, labels, lens = _batch(rs, N, T, F, C)
+    xt = np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float64)
+    n_pad, Hp = 16, 12
+    zone, masks_g = [], {}
+    si = 1                                               # stage 0 is GaussianNoise
+    for li in range(L):
+        z = {}
+        KC = np.ones((T, 2, Hp), np.float32)
+        KH = np.ones((T, 2, Hp), np.float32)
+        for di, d in enumerate(('fwd', 'bwd')):
+            kc = (rs.rand(T, H) > 0.25).astype(np.float64)
+            kh = (rs.rand(T, H) > 0.25).astype(np.float64)
+            z[d] = (kc, kh)
+            KC[:, di, :H], KH[:, di, :H] = kc, kh
+        zone.append(z)
+        masks_g[si] = (None, None, torch.from_numpy(KC).cuda(), torch.from_numpy(KH).cuda())
+        si += 1
+    want = OL.loss_and_grads(params, xt, labels, lens, zone=zone)
+    slab = model.to_slab(x)
+    ctc, logits, _ = model.loss_and_grads(slab, labels, lens, training=True, masks=masks_g)
+    torch.cuda.synchronize()
+    assert report('mi+zoneout logits', logits.cpu().numpy()[:, :N], want['logits']) < 1e-4
+    np.testing.assert_allclose(ctc.cpu().numpy(), want['ctc'], rtol=1e-4)
+    got = model.get_gradients()
+    flat = OL.flatten(want['grads'])
+    assert len(flat) == len(got)
+    for (name, g), gg in zip(flat, got):
+        scale = max(1e-3, np.abs(g).max())
+        assert report('mi+zoneout grad ' + name, gg, g) < 1e-4 * scale + 1e-6, name
+    # test phase: constant coefficients 1 - level
+    zone_t = [{d: (np.full((T, H), 0.75), np.full((T, H), 0.75)) for d in ('fwd', 'bwd')}
+              for _ in range(L)]
+    want_t = OL.model_forward(params, xt, zone=zone_t)[0]
+    logits_t = model.forward(slab, training=False).cpu().numpy()[:, :N]
+    assert report('mi+zoneout test-phase logits', logits_t, want_t) < 1e-4
