@@ -157,3 +157,42 @@ def test_residual_merge_gradients_match_finite_differences():
             lm = loss(q)
             num = (lp - lm) / 2e-6
             assert abs(gr[idx] - num) < 1e-5 * max(1.0, abs(num)), (mode, path)
+
+
+def test_multiplicative_integration_and_zoneout_gradients_match_finite_differences():
+    """Cell variants of the reference override (core/layers.py:441-443 MI, :457-467 zoneout
+    with per-frame coefficients): the oracle's BPTT -- dx, dW, dU, db and d alpha / d beta1 /
+    d beta2 -- against central differences, both directions, with dropout masks."""
+    rs = np.random.RandomState(3)
+    T, N, F, H = 6, 3, 4, 5
+    x = rs.randn(T, N, F)
+    W, U, b = rs.randn(F, 4 * H) * 0.4, rs.randn(H, 4 * H) * 0.4, rs.randn(4 * H) * 0.2
+    mi = [1 + 0.3 * rs.randn(4 * H), 0.5 + 0.3 * rs.randn(4 * H), 0.5 + 0.3 * rs.randn(4 * H)]
+    kc = (rs.rand(T, H) > 0.3).astype(float)
+    kh = np.full((T, H), 0.8)
+    BU, BW = (rs.rand(N, H) > 0.2) / 0.8, (rs.rand(N, F) > 0.2) / 0.8
+    w = rs.randn(T, N, H)
+    for rev in (False, True):
+        def loss():
+            return float((L.lstm_forward(x, W, U, b, rev, BW, BU, mi, kc, kh)[0] * w).sum())
+        hs, cache = L.lstm_forward(x, W, U, b, rev, BW, BU, mi, kc, kh)
+        dx, dW, dU, db = L.lstm_backward(w.copy(), cache)
+        for name, arr, g in (('x', x, dx), ('W', W, dW), ('U', U, dU), ('b', b, db),
+                             ('alpha', mi[0], cache['dmi'][0]), ('beta1', mi[1], cache['dmi'][1]),
+                             ('beta2', mi[2], cache['dmi'][2])):
+            for _ in range(3):
+                idx = tuple(rs.randint(0, d) for d in arr.shape)
+                o = arr[idx]
+                arr[idx] = o + 1e-6
+                lp = loss()
+                arr[idx] = o - 1e-6
+                lm = loss()
+                arr[idx] = o
+                num = (lp - lm) / 2e-6
+                assert abs(g[idx] - num) < 1e-5 * max(1.0, abs(num)), (name, idx)
+    # zoneout at k = 1 and mi = (0, 1, 1) reduce to the plain cell
+    plain = L.lstm_forward(x, W, U, b, False, BW, BU)[0]
+    ident = L.lstm_forward(x, W, U, b, False, BW, BU,
+                           [np.zeros(4 * H), np.ones(4 * H), np.ones(4 * H)],
+                           np.ones((T, H)), np.ones((T, H)))[0]
+    assert np.allclose(plain, ident, atol=1e-12)
