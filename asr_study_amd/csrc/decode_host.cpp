@@ -20,7 +20,6 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
-#include <set>
 #include <thread>
 #include <vector>
 
@@ -36,16 +35,50 @@ inline double lse(double a, double b) {
 }
 
 struct Node {
-  int parent, label, first_child;
+  int parent, label;
+  int children;          // index into the child table (C-1 slots), -1 = never expanded
+  int order;             // creation rank AS IF all C-1 children were created when their
+                         // parent first expanded (the tie-break of the eviction order)
   double ob, ol, ot, nb, nl, nt;
 };
 
-struct BottomLess {   // orders the beam worst-first: lowest total, newest entry first
+// The beam as a binary min-heap ordered worst-first: lowest total, newest entry first
+// (the order TensorFlow's TopN with its BeamComparer evicts in).  An entry's total does
+// not change while it sits in the heap, so a plain heap (no allocation per insert, unlike
+// a std::set) gives exactly the same bottom element.
+struct Beam {
   const std::vector<Node>* nodes;
-  bool operator()(int a, int b) const {
+  std::vector<int> heap;
+  bool worse(int a, int b) const {              // a is evicted before b
     const double ta = (*nodes)[a].nt, tb = (*nodes)[b].nt;
     if (ta != tb) return ta < tb;
-    return a > b;
+    return (*nodes)[a].order > (*nodes)[b].order;
+  }
+  size_t size() const { return heap.size(); }
+  int bottom() const { return heap[0]; }
+  void push(int v) {
+    size_t i = heap.size();
+    heap.push_back(v);
+    while (i > 0) {
+      const size_t par = (i - 1) / 2;
+      if (!worse(heap[i], heap[par])) break;
+      std::swap(heap[i], heap[par]);
+      i = par;
+    }
+  }
+  void pop() {
+    heap[0] = heap.back();
+    heap.pop_back();
+    size_t i = 0;
+    const size_t n = heap.size();
+    for (;;) {
+      size_t l = 2 * i + 1, r = l + 1, m = i;
+      if (l < n && worse(heap[l], heap[m])) m = l;
+      if (r < n && worse(heap[r], heap[m])) m = r;
+      if (m == i) break;
+      std::swap(heap[i], heap[m]);
+      i = m;
+    }
   }
 };
 
@@ -53,10 +86,15 @@ void beam_one(const float* logits, size_t row_stride, int T, int C, int beam_wid
               bool merge_repeated, std::vector<int>* out, float* score) {
   const int blank = C - 1;
   std::vector<Node> nodes;
-  nodes.reserve((size_t)beam_width * (C - 1) * 4 + 16);
-  nodes.push_back(Node{-1, -1, -1, kLogZero, kLogZero, kLogZero, 0.0, kLogZero, 0.0});
+  std::vector<int> child_table;                  // (C-1) slots per expanded node, -1 = absent
+  nodes.reserve((size_t)beam_width * 64 + 16);
+  nodes.push_back(Node{-1, -1, -1, 0, kLogZero, kLogZero, kLogZero, 0.0, kLogZero, 0.0});
+  int next_order = 1;
+  std::vector<int> order_base;                   // per child-table block
   std::vector<int> leaves(1, 0), branches;
   std::vector<double> inp(C);
+  Beam beam;
+  beam.nodes = &nodes;
   for (int t = 0; t < T; ++t) {
     const float* x = logits + (size_t)t * row_stride;
     double mx = x[0];
@@ -65,14 +103,12 @@ void beam_one(const float* logits, size_t row_stride, int T, int C, int beam_wid
     branches = leaves;
     std::sort(branches.begin(), branches.end(), [&](int a, int b) {
       if (nodes[a].nt != nodes[b].nt) return nodes[a].nt > nodes[b].nt;
-      return a < b;
+      return nodes[a].order < nodes[b].order;
     });
     for (int b : branches) {
       Node& e = nodes[b];
       e.ob = e.nb; e.ol = e.nl; e.ot = e.nt;
     }
-    BottomLess cmp{&nodes};
-    std::set<int, BottomLess> beam(cmp);
     for (int b : branches) {
       Node& e = nodes[b];
       if (e.parent >= 0) {
@@ -86,50 +122,60 @@ void beam_one(const float* logits, size_t row_stride, int T, int C, int beam_wid
       e.nb = e.ot + inp[blank];
       e.nt = lse(e.nb, e.nl);
     }
-    for (int b : branches) beam.insert(b);
+    beam.heap.clear();
+    for (int b : branches) beam.push(b);
     auto is_candidate = [&](double total) {
       return total > kLogZero &&
-             ((int)beam.size() < beam_width || total > nodes[*beam.begin()].nt);
+             ((int)beam.size() < beam_width || total > nodes[beam.bottom()].nt);
     };
     for (int b : branches) {
       if (!is_candidate(nodes[b].ot)) continue;
-      if (nodes[b].first_child < 0) {
-        const int first = (int)nodes.size();
-        for (int c = 0; c < C; ++c) {
-          if (c == blank) continue;
-          nodes.push_back(Node{b, c, -1, kLogZero, kLogZero, kLogZero, kLogZero, kLogZero,
-                               kLogZero});
-        }
-        nodes[b].first_child = first;
+      if (nodes[b].children < 0) {               // children are created when they first
+        nodes[b].children = (int)child_table.size();      // enter the beam, not before
+        child_table.insert(child_table.end(), (size_t)(C - 1), -1);
+        order_base.resize(child_table.size() / (C - 1), 0);
+        order_base[nodes[b].children / (C - 1)] = next_order;
+        next_order += C - 1;
       }
-      const int first = nodes[b].first_child;
+      const int slots = nodes[b].children;
       const double b_ob = nodes[b].ob, b_ot = nodes[b].ot;
       const int b_label = nodes[b].label;
-      for (int ci = 0; ci < C - 1; ++ci) {
-        Node& ch = nodes[first + ci];
-        if (ch.nt != kLogZero) continue;           // already in the beam
-        ch.nb = kLogZero;
-        const double prev = (ch.label == b_label) ? b_ob : b_ot;
-        ch.nl = prev == kLogZero ? kLogZero : inp[ch.label] + prev;
-        ch.nt = ch.nl;
-        if (is_candidate(ch.nt)) {
-          if ((int)beam.size() == beam_width) {
-            const int bottom = *beam.begin();
-            beam.erase(beam.begin());
-            nodes[bottom].nb = nodes[bottom].nl = nodes[bottom].nt = kLogZero;
-          }
-          beam.insert(first + ci);
-        } else {
-          ch.ob = ch.ol = ch.ot = kLogZero;
-          ch.nb = ch.nl = ch.nt = kLogZero;
+      for (int c = 0; c < C - 1; ++c) {          // label ids 0 .. C-2 (blank is C-1)
+        const int idx = child_table[slots + c];
+        if (idx >= 0 && nodes[idx].nt != kLogZero) continue;   // already in the beam
+        const double prev = (c == b_label) ? b_ob : b_ot;
+        const double nl = prev == kLogZero ? kLogZero : inp[c] + prev;
+        if (!is_candidate(nl)) {
+          // TF resets the rejected child's OLD probabilities too: if that child is itself
+          // a branch of this frame (evicted a moment ago), it must not expand later on
+          if (idx >= 0) nodes[idx].ob = nodes[idx].ol = nodes[idx].ot = kLogZero;
+          continue;
         }
+        int id = idx;
+        if (id < 0) {
+          id = (int)nodes.size();
+          nodes.push_back(Node{b, c, -1, order_base[slots / (C - 1)] + c, kLogZero, kLogZero,
+                               kLogZero, kLogZero, kLogZero, kLogZero});
+          child_table[slots + c] = id;
+        }
+        nodes[id].nb = kLogZero;
+        nodes[id].nl = nl;
+        nodes[id].nt = nl;
+        if ((int)beam.size() == beam_width) {
+          const int bottom = beam.bottom();
+          beam.pop();
+          nodes[bottom].nb = nodes[bottom].nl = nodes[bottom].nt = kLogZero;
+        }
+        beam.push(id);
       }
     }
-    leaves.assign(beam.begin(), beam.end());
+    leaves = beam.heap;
   }
   int best = leaves[0];
   for (int b : leaves) {
-    if (nodes[b].nt > nodes[best].nt || (nodes[b].nt == nodes[best].nt && b < best)) best = b;
+    if (nodes[b].nt > nodes[best].nt ||
+        (nodes[b].nt == nodes[best].nt && nodes[b].order < nodes[best].order))
+      best = b;
   }
   out->clear();
   int prev = -1;

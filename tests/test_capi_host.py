@@ -85,3 +85,21 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(L, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(L.AsrHipError):
         L.load()
+
+
+def test_beam_search_host_tie_breaking_follows_creation_order():
+    """Quantised logits force exact score ties: eviction order and final ranking then depend
+    on the entries' creation rank (children are ranked as if all C-1 were created when their
+    parent first expanded, as TensorFlow's decoder allocates them).  Compared with the
+    oracle run in float64 (the library computes in double)."""
+    from asr_study_amd import ops
+    from oracle import decode as OD
+    for seed in range(0, 400, 2):
+        rs = np.random.RandomState(seed)
+        C, T, W = rs.randint(3, 8), rs.randint(3, 16), rs.randint(1, 9)
+        q = 1 + seed % 3
+        lg = np.zeros((T, 16, C), np.float32)
+        lg[:, 0] = np.round(rs.randn(T, C) * 1.5 * q) / q
+        got, _ = ops.ctc_beam_search_host(lg, np.array([T]), 1, W, True)
+        want, _ = OD.beam_search_decode_one(lg[:T, 0].astype(np.float64), W, dtype=np.float64)
+        assert got[0] == want[0], seed
