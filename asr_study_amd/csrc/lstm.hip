@@ -613,14 +613,22 @@ lstm_fwd_kernel_h(LstmParams p) {
   if (!map_block(p, chain_local, wg)) return;
   const int chain = p.chain_begin + chain_local;
   const bool fast = chain_on_one_xcd(p, chain, wg, reinterpret_cast<int*>(lds));
-  const bool var = p.mi || p.zone_c || p.zone_h || p.uh;
-  if (var) {
-    if (fast) fwd_body_h<NKK, true, true>(p, chain, wg, lds);
-    else fwd_body_h<NKK, false, true>(p, chain, wg, lds);
-  } else {
-    if (fast) fwd_body_h<NKK, true, false>(p, chain, wg, lds);
-    else fwd_body_h<NKK, false, false>(p, chain, wg, lds);
-  }
+  if (fast) fwd_body_h<NKK, true, false>(p, chain, wg, lds);
+  else fwd_body_h<NKK, false, false>(p, chain, wg, lds);
+}
+
+// the cell variants (mi / zoneout) live in their own kernels so that their extra
+// registers never touch the allocation of the default ones
+template <int NKK>
+__global__ void __launch_bounds__(kThreads)
+lstm_fwd_kernel_hv(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int chain_local, wg;
+  if (!map_block(p, chain_local, wg)) return;
+  const int chain = p.chain_begin + chain_local;
+  const bool fast = chain_on_one_xcd(p, chain, wg, reinterpret_cast<int*>(lds));
+  if (fast) fwd_body_h<NKK, true, true>(p, chain, wg, lds);
+  else fwd_body_h<NKK, false, true>(p, chain, wg, lds);
 }
 
 // forward, split-fp16, K split over the waves.  Wave w multiplies ALL 64 gate columns
@@ -1280,14 +1288,20 @@ lstm_bwd_kernel_h(LstmParams p) {
   if (!map_block(p, chain_local, cw)) return;
   const int chain = p.chain_begin + chain_local;
   const bool fast = chain_on_one_xcd(p, chain, cw, reinterpret_cast<int*>(lds));
-  const bool var = p.mi || p.zone_c || p.zone_h;
-  if (var) {
-    if (fast) bwd_body_h<TPW, true, true>(p, chain, cw, lds);
-    else bwd_body_h<TPW, false, true>(p, chain, cw, lds);
-  } else {
-    if (fast) bwd_body_h<TPW, true, false>(p, chain, cw, lds);
-    else bwd_body_h<TPW, false, false>(p, chain, cw, lds);
-  }
+  if (fast) bwd_body_h<TPW, true, false>(p, chain, cw, lds);
+  else bwd_body_h<TPW, false, false>(p, chain, cw, lds);
+}
+
+template <int TPW>
+__global__ void __launch_bounds__(kThreads)
+lstm_bwd_kernel_hv(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int chain_local, cw;
+  if (!map_block(p, chain_local, cw)) return;
+  const int chain = p.chain_begin + chain_local;
+  const bool fast = chain_on_one_xcd(p, chain, cw, reinterpret_cast<int*>(lds));
+  if (fast) bwd_body_h<TPW, true, true>(p, chain, cw, lds);
+  else bwd_body_h<TPW, false, true>(p, chain, cw, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -1314,6 +1328,21 @@ kern_t pick_fwd_h(int nkk) {
     case 4: return lstm_fwd_kernel_h<4>;
     case 8: return lstm_fwd_kernel_h<8>;
     default: return lstm_fwd_kernel_h<16>;
+  }
+}
+kern_t pick_fwd_hv(int nkk) {
+  switch (nkk) {
+    case 4: return lstm_fwd_kernel_hv<4>;
+    case 8: return lstm_fwd_kernel_hv<8>;
+    default: return lstm_fwd_kernel_hv<16>;
+  }
+}
+kern_t pick_bwd_hv(int tpw) {
+  switch (tpw) {
+    case 1: return lstm_bwd_kernel_hv<1>;
+    case 2: return lstm_bwd_kernel_hv<2>;
+    case 4: return lstm_bwd_kernel_hv<4>;
+    default: return lstm_bwd_kernel_hv<8>;
   }
 }
 kern_t pick_fwd_k(int nkk) {
@@ -1385,6 +1414,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       k = pick_fwd_h(pl.NKK);
       // K split over the waves (fwd_body_k): wins from H = 256 up, not for narrow layers
       const bool variants = a->mi || a->zone_c || a->zone_h || a->uh;   // fwd_body_h only
+      if (variants) k = pick_fwd_hv(pl.NKK);
       if (!variants && env_int("ASR_LSTM_KSPLIT", pl.NKK >= 8 ? 1 : 0)) {
         pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
         k = pick_fwd_k(pl.NKK);
@@ -1403,7 +1433,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     k = pick_bwd(pl.TPW);
     if (pl.prec == 1) {
       pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 72 * 2);
-      k = pick_bwd_h(pl.TPW);
+      k = (a->mi || a->zone_c || a->zone_h) ? pick_bwd_hv(pl.TPW) : pick_bwd_h(pl.TPW);
     }
   }
   if (pl.shm < (size_t)pl.P * 4 + 16) pl.shm = (size_t)pl.P * 4 + 16;

@@ -65,6 +65,7 @@ def main():
             tb = timeit(lambda: ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mode=mode),
                         reps=reps, warm=1)
             ops.lstm_status(ops.WS.get('lstm_bwd', 0, torch.device(dev)))
+            print('fast chains bwd:', ops.lstm_fast_chains(ops.WS.get('lstm_bwd', 0, torch.device(dev))))
             if int(os.environ.get('ASR_LSTM_DBG', '0')) & 32:
                 for nm in ('lstm_fwd', 'lstm_bwd'):
                     pr = ops.lstm_profile(ops.WS.get(nm, 0, torch.device(dev)))
