@@ -103,3 +103,41 @@ def test_beam_search_host_tie_breaking_follows_creation_order():
         got, _ = ops.ctc_beam_search_host(lg, np.array([T]), 1, W, True)
         want, _ = OD.beam_search_decode_one(lg[:T, 0].astype(np.float64), W, dtype=np.float64)
         assert got[0] == want[0], seed
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The argument structs of include/asr_hip.h are mirrored by hand in _lib.py: compile a
+    C program that prints sizeof / a few offsetof of every struct with gcc and compare with
+    ctypes (catches ABI drift when a field is added on one side only)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from asr_study_amd import _lib
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / 'layout.c'
+    src.write_text('''
+#include <stdio.h>
+#include <stddef.h>
+#include "asr_hip.h"
+int main(void) {
+  printf("frontend %zu %zu\\n", sizeof(asr_frontend_cfg), offsetof(asr_frontend_cfg, eps));
+  printf("gemm %zu %zu %zu\\n", sizeof(asr_gemm_args), offsetof(asr_gemm_args, bias),
+         offsetof(asr_gemm_args, b_absmax));
+  printf("lstm %zu %zu %zu %zu\\n", sizeof(asr_lstm_args), offsetof(asr_lstm_args, dz_absmax),
+         offsetof(asr_lstm_args, step_begin), offsetof(asr_lstm_args, dmi));
+  printf("segment %zu %zu\\n", sizeof(asr_segment), offsetof(asr_segment, l2));
+  return 0;
+}
+''')
+    exe = tmp_path / 'layout'
+    subprocess.check_call([gcc, '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)])
+    out = dict((ln.split()[0], [int(v) for v in ln.split()[1:]])
+               for ln in subprocess.check_output([str(exe)]).decode().splitlines())
+    F, G, Ls, S = _lib.FrontendCfg, _lib.GemmArgs, _lib.LstmArgs, _lib.Segment
+    assert out['frontend'] == [C.sizeof(F), F.eps.offset]
+    assert out['gemm'] == [C.sizeof(G), G.bias.offset, G.b_absmax.offset]
+    assert out['lstm'] == [C.sizeof(Ls), Ls.dz_absmax.offset, Ls.step_begin.offset, Ls.dmi.offset]
+    assert out['segment'] == [C.sizeof(S), S.l2.offset]

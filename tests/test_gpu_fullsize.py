@@ -1,6 +1,7 @@
 """-m gpu: properties of the hot path at BASELINE.json's FULL cfg2 size (brsmv1
 5xBiLSTM(256), 32 utterances x 10 s = 999 frames), where the float64 oracle would need
-minutes: size-independent invariants instead of element-wise comparison.
+minutes (and the same at cfg3: 5xBiLSTM(512), 64 utterances, 80 log-mel features):
+size-independent invariants instead of element-wise comparison.
 
 * utterances are independent: the logits / CTC losses of a 32-utterance batch equal, bit
   for bit, those of its two 16-utterance halves (no arithmetic crosses a batch row);
@@ -25,45 +26,56 @@ def _inputs(n, seed):
     return sigs, labels
 
 
-@pytest.mark.timeout(600)
-def test_cfg2_batch_rows_are_independent_and_gradients_additive():
+CASES = {
+    # BASELINE.json configs[1] / configs[2] at full size
+    'cfg2': dict(F=39, H=256, N=32, feat='mfcc'),
+    'cfg3': dict(F=80, H=512, N=64, feat='logfbank80'),
+}
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('name', ['cfg2', 'cfg3'])
+def test_fullsize_batch_rows_are_independent_and_gradients_additive(name):
     from asr_study_amd import ops
     from asr_study_amd.core import models, optimizers
     from asr_study_amd.preprocessing import audio
+    cfg = CASES[name]
+    N, half = cfg['N'], cfg['N'] // 2
     dev = torch.device('cuda:0')
-    model = models.brsmv1(num_features=39, num_classes=28, num_hiddens=256, num_layers=5,
-                          dropout=0.0, weight_decay=1e-4, seed=0, device=dev)
+    model = models.brsmv1(num_features=cfg['F'], num_classes=28, num_hiddens=cfg['H'],
+                          num_layers=5, dropout=0.0, weight_decay=1e-4, seed=0, device=dev)
     model.compile(optimizer=optimizers.Adam(lr=1e-3, clipnorm=400))
-    feat = audio.MFCC(device=dev)
-    sigs, labels = _inputs(32, 5)
+    feat = audio.MFCC(device=dev) if cfg['feat'] == 'mfcc' else \
+        audio.LogFbank(num_filt=80, device=dev)
+    sigs, labels = _inputs(N, 5)
     slab, frames = feat.batch(sigs)
-    assert slab.shape == (999, 32, 39) and int(frames.min()) == 999
-    lens = [999] * 32
+    assert slab.shape == (999, N, cfg['F']) and int(frames.min()) == 999
+    lens = [999] * N
 
     def run(rows):
         sub = slab[:, rows].contiguous()
         ctc, logits, _ = model.loss_and_grads(sub, [labels[i] for i in rows],
                                               [lens[i] for i in rows], training=False,
-                                              n_global=32)
+                                              n_global=N)
         torch.cuda.synchronize()
         return (ctc.cpu().numpy().copy(), logits[:, :len(rows)].cpu().numpy().copy(),
                 model.grads.cpu().numpy().copy())
-    full_ctc, full_logits, full_grad = run(list(range(32)))
-    a_ctc, a_logits, a_grad = run(list(range(16)))
-    b_ctc, b_logits, b_grad = run(list(range(16, 32)))
-    for name in ('lstm_fwd', 'lstm_bwd'):
-        ops.lstm_status(ops.WS.get(name, 0, dev))
+    full_ctc, full_logits, full_grad = run(list(range(N)))
+    a_ctc, a_logits, a_grad = run(list(range(half)))
+    b_ctc, b_logits, b_grad = run(list(range(half, N)))
+    for ws in ('lstm_fwd', 'lstm_bwd'):
+        ops.lstm_status(ops.WS.get(ws, 0, dev))
     assert np.all(np.isfinite(full_ctc)) and np.all(full_ctc > 0)
     # forward: bit-exact independence of batch rows
-    assert np.array_equal(full_logits[:, :16], a_logits)
-    assert np.array_equal(full_logits[:, 16:], b_logits)
+    assert np.array_equal(full_logits[:, :half], a_logits)
+    assert np.array_equal(full_logits[:, half:], b_logits)
     assert np.array_equal(full_ctc, np.concatenate([a_ctc, b_ctc]))
-    # backward: additivity to fp32 round-off of a 32k-term reduction
+    # backward: additivity to fp32 round-off of a 32k-64k-term reduction
     gsum = a_grad + b_grad
     scale = np.abs(full_grad).max()
     assert scale > 0
     err = np.abs(full_grad - gsum).max()
-    print('cfg2 gradient additivity: max|g|=%.3e max err=%.3e' % (scale, err))
+    print('%s gradient additivity: max|g|=%.3e max err=%.3e' % (name, scale, err))
     assert err < 2e-5 * scale
     # one clipped Adam step: bounded update, finite weights
     before = model.params.clone()
