@@ -116,7 +116,10 @@ class Model(object):
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         # the GEMMs either side of a recurrence are pipelined against its last quarter
         # (frames whose both directions are already final), on a third stream
-        self.pipeline = self.overlap and _os.environ.get('ASR_PIPELINE', '0') == '1'
+        # 'auto': only when a layer's recurrence leaves at least half of the CUs to the GEMMs
+        # it is pipelined against (cfg2: 64 of 256 workgroups; not cfg3's 256 of 256)
+        self._pipeline_mode = _os.environ.get('ASR_PIPELINE', 'auto')
+        self.pipeline = self.overlap and self._pipeline_mode == '1'
         self._pipe = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         self._rng = torch.Generator(device=self.device)
         self._rng.manual_seed(int(seed) + 12345)
@@ -347,7 +350,8 @@ class Model(object):
         self._acts = []
         drawn = [None]
         nb = 0
-        pipe = self.pipeline and self._pipe is not None and self.lstm_mode == 0 and T >= 16
+        self._pipe_now = self._pipeline_on(n_pad)
+        pipe = self._pipe_now and self._pipe is not None and self.lstm_mode == 0 and T >= 16
         S = (3 * T) // 4
         pre = {}
 
@@ -434,6 +438,16 @@ class Model(object):
             rec['out'] = a
             self._acts.append(rec)
         return a
+
+    def _pipeline_on(self, n_pad):
+        if not self.overlap or self._pipeline_mode == '0':
+            return False
+        if self._pipeline_mode == '1':
+            return True
+        if not hasattr(self, '_num_cu'):
+            self._num_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        widest = max([(st.Hp + 15) // 16 for st in self.stages if st.kind == 'bilstm'] + [0])
+        return 0 < 2 * (n_pad // 16) * widest <= self._num_cu // 2
 
     def _variant_args(self, s, si, T, n_pad, training, masks):
         """Keyword arguments of the optional cell variants for ops.lstm_seq_fwd (and, with
@@ -601,8 +615,8 @@ class Model(object):
                     gsrc = self._buf('dwx%d' % par, (T, n_pad, 2, 4 * Hp))
                     dmi = self._buf('dmi%d' % si, (n_pad // 16, 2, 4, 4 * Hp))
                     var.update(wx=rec['zx'], dwx=gsrc, dmi=dmi)
-                pipe_b = (self.pipeline and self._pipe is not None and not first
-                          and self.lstm_mode == 0 and T >= 16 and not var)
+                pipe_b = (getattr(self, '_pipe_now', False) and self._pipe is not None
+                          and not first and self.lstm_mode == 0 and T >= 16 and not var)
                 S = (3 * T) // 4
                 dx = None
                 if pipe_b:
