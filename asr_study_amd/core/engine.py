@@ -119,6 +119,8 @@ class Model(object):
         # 'auto': only when a layer's recurrence leaves at least half of the CUs to the GEMMs
         # it is pipelined against (cfg2: 64 of 256 workgroups; not cfg3's 256 of 256)
         self._pipeline_mode = _os.environ.get('ASR_PIPELINE', 'auto')
+        # the recurrence is cut after split/16 of its steps (frames [T-S, S) are final then)
+        self._pipe_split16 = min(15, max(9, int(_os.environ.get('ASR_PIPE_SPLIT', '12'))))
         self.pipeline = self.overlap and self._pipeline_mode == '1'
         self._pipe = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         self._rng = torch.Generator(device=self.device)
@@ -352,7 +354,7 @@ class Model(object):
         nb = 0
         self._pipe_now = self._pipeline_on(n_pad)
         pipe = self._pipe_now and self._pipe is not None and self.lstm_mode == 0 and T >= 16
-        S = (3 * T) // 4
+        S = (self._pipe_split16 * T) // 16
         pre = {}
 
         def stage_masks(i):
@@ -617,7 +619,7 @@ class Model(object):
                     var.update(wx=rec['zx'], dwx=gsrc, dmi=dmi)
                 pipe_b = (getattr(self, '_pipe_now', False) and self._pipe is not None
                           and not first and self.lstm_mode == 0 and T >= 16 and not var)
-                S = (3 * T) // 4
+                S = (self._pipe_split16 * T) // 16
                 dx = None
                 if pipe_b:
                     # after S BPTT steps the gate gradients of frames [T-S, S) are final
