@@ -146,7 +146,9 @@ def main():
             e0.record()
             r = orig(*a, **k)
             e1.record()
-            lstm_ev[name].append((e0, e1))
+            # a layer's recurrence may be launched in slices (asr_lstm_args.step_count)
+            steps = k.get('steps')
+            lstm_ev[name].append((e0, e1, int(steps[1]) if steps else None))
             return r
         return orig, timed
 
@@ -241,10 +243,14 @@ def main():
         n_pad = ops.pad16(N)
         ms = dt / args.steps * 1e3
         value = world * N * 10.0 / (dt / args.steps)
-        def avg_ms(name):
+        def lstm_times(name):
             ev = lstm_ev[name]
-            return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
-        fwd_ms, bwd_ms = avg_ms('lstm_seq_fwd'), avg_ms('lstm_seq_bwd')
+            if not ev:
+                return None, None, None
+            tot = float(sum(a.elapsed_time(b) for a, b, _ in ev))
+            steps = float(sum(T if n is None else n for _, _, n in ev))
+            return tot / len(ev), tot, steps        # ms per launch, total ms, total steps
+        fwd_t, bwd_t = lstm_times('lstm_seq_fwd'), lstm_times('lstm_seq_bwd')
         # dominant kernels: the persistent recurrent kernels (one launch per layer and
         # pass, both directions).  Algorithmic flops per launch = 2*T*n_pad*2 dirs*H*4H
         # (h@U forward, dz@U^T in BPTT); algorithmic HBM bytes per launch:
@@ -253,21 +259,32 @@ def main():
         slab_b = 4.0 * T * n_pad * 2 * H
         alg_bytes = {'fwd': 4 * slab_b + slab_b + slab_b + 4 * slab_b,
                      'bwd': slab_b + 4 * slab_b + slab_b + 4 * slab_b}
-        # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE),
-        # profiles/r1f_bench_cfg2_hbm_traffic.md; measured at cfg2 only
-        pmc = {'cfg2': {'fwd': 644.87e6, 'bwd': 647.96e6}}.get(args.config, {})
+        # HBM traffic per LAYER from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE; per-launch
+        # average x launches per layer), profiles/r1g_bench_cfg2_hbm_traffic.md; cfg2 only
+        pmc = {'cfg2': {'fwd': 647.6e6, 'bwd': 654.7e6}}.get(args.config, {})
 
-        def roof(kind, ms, kernel):
-            ach = flops / (ms * 1e-3) / 1e12 if ms else None
-            return {'kernel': kernel, 'bound': 'mfma', 'achieved': round(ach, 3) if ach else None,
+        def roof(kind, times, kernel):
+            per_launch_ms, tot_ms, tot_steps = times
+            if not tot_ms:
+                return {'kernel': kernel, 'bound': 'mfma', 'achieved': None,
+                        'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
+                        'traffic': None}
+            # a launch covers steps_per_launch of the layer's T dependent steps: its share
+            # of the layer's algorithmic flops / bytes / PMC traffic is that fraction
+            share = tot_steps / T / (tot_ms / per_launch_ms)      # avg fraction of a layer
+            ach = flops * (tot_steps / T) / (tot_ms * 1e-3) / 1e12
+            return {'kernel': kernel, 'bound': 'mfma', 'achieved': round(ach, 3),
                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4) if ach else None,
-                    'traffic': pmc.get(kind), 'algorithmic_bytes': alg_bytes[kind],
-                    'avg_launch_ms': round(ms, 4) if ms else None,
-                    'us_per_timestep': round(ms * 1e3 / T, 3) if ms else None,
-                    'flops_per_launch': flops,
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    'traffic': round(pmc[kind] * share, 1) if kind in pmc else None,
+                    'algorithmic_bytes': round(alg_bytes[kind] * share, 1),
+                    'avg_launch_ms': round(per_launch_ms, 4),
+                    'steps_per_launch': round(tot_steps / (tot_ms / per_launch_ms), 1),
+                    'us_per_timestep': round(tot_ms * 1e3 / tot_steps, 3),
+                    'flops_per_launch': flops * share,
                     'note': 'latency-bound recurrence (T dependent steps, cross-workgroup '
-                            'hand-off per step): see DESIGN.md 5 for the per-step anatomy'}
+                            'hand-off per step; a layer is launched in two slices when its '
+                            'neighbouring GEMMs are pipelined): DESIGN.md 5'}
         line = {
             'metric': 'audio-seconds/sec trained (MFCC+BiLSTM+CTC)',
             'value': round(value, 1), 'unit': 'audio-seconds/s', 'n_gpus': world,
@@ -283,9 +300,9 @@ def main():
                        'global_batch': world * N, 'utterance_seconds': 10.0, 'frames': T,
                        'dropout': args.dropout, 'optimizer': 'adam(clipnorm=400)',
                        'parallelism': 'dp%d' % world, 'params': model.count_params()},
-            'roofline': roof('bwd', bwd_ms, 'lstm_bwd_kernel_h (persistent BPTT of one BiLSTM '
+            'roofline': roof('bwd', bwd_t, 'lstm_bwd_kernel_h (persistent BPTT of one BiLSTM '
                                             'layer, both directions)'),
-            'roofline_lstm_fwd': roof('fwd', fwd_ms, 'lstm_fwd_kernel_h (persistent forward '
+            'roofline_lstm_fwd': roof('fwd', fwd_t, 'lstm_fwd_kernel_k (persistent forward '
                                                      'recurrence of one BiLSTM layer)'),
         }
         line.update(extra)
