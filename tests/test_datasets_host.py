@@ -176,3 +176,41 @@ def test_batch_feeder_thread_orders_bounds_and_propagates_errors():
         f.get()
     f.close()
     assert not any(t.name == 'asr-batch-feeder' and t.is_alive() for t in threading.enumerate())
+
+
+def test_cli_argument_merging_and_flag_tables():
+    """train.py --load / eval.py / predict.py: defaults < arguments stored in the checkpoint <
+    arguments given on the command line (train.py:107-112, eval.py:60); the flag tables
+    carry the reference's defaults (train.py:46-88, eval.py:26-49)."""
+    from asr_study_amd import cli
+    from asr_study_amd.utils import generic_utils as utils
+    ap = cli.make_parser('t', cli.TRAIN_FLAGS)
+    d = ap.parse_args([])
+    assert (d.model, d.num_epochs, d.lr, d.clipnorm, d.batch_size, d.opt, d.label_parser) == \
+        ('brsmv1', 100, 0.001, 400, 32, 'adam', 'simple_char_parser')
+    argv = ['--lr', '0.01', '--batch_size', '32', '--dataset', 'a.h5']
+    args = ap.parse_args(argv)
+    explicit = utils.parse_nondefault_args(args, ap.parse_args([]), argv)
+    # batch_size equals its default but was NAMED on the command line: still explicit
+    assert set(explicit.values()) == {'lr', 'batch_size', 'dataset'}
+    stored = {'lr': 0.5, 'batch_size': 8, 'model': 'eyben', 'num_epochs': 7}
+    merged = cli.merged_args(args, stored, explicit)
+    assert (merged.lr, merged.batch_size, merged.model, merged.num_epochs, merged.opt) == \
+        (0.01, 32, 'eyben', 7, 'adam')
+    ev = cli.make_parser('e', cli.EVAL_FLAGS).parse_args(['--model', 'm.h5', '--dataset', 'd.h5'])
+    assert (ev.subset, ev.beam_width, ev.batch_size) == ('test', 400, 32)
+    pr = cli.make_parser('p', cli.PREDICT_FLAGS).parse_args(['--model', 'm.h5', '--file', 'a.wav'])
+    assert pr.dataset is None and pr.no_decoder is False and pr.subset == 'test'
+
+
+def test_get_from_module_resolves_plugins_case_insensitively():
+    from asr_study_amd.utils import generic_utils as utils
+    from asr_study_amd.preprocessing import text
+    assert utils.get_from_module('preprocessing.text', 'Simple_Char_Parser') is text.simple_char_parser
+    assert utils.get_from_module('preprocessing.audio', None) is None
+    assert utils.get_from_module('preprocessing.audio', 'none') is None
+    dummy = utils.get_from_module('datasets*', 'dummy', regex=True,
+                                  params=['num_speakers', '2', 'num_utterances_per_speaker', '1'])
+    assert type(dummy).__name__ == 'Dummy'
+    with pytest.raises(KeyError):
+        utils.get_from_module('core.models', 'no_such_model')
