@@ -148,6 +148,7 @@ class Model(object):
         for st in self.spec:
             s = Stage()
             s.kind = st['type']
+            s.p_lo = off                    # this stage's slice of the flat param / grad buffers
             s.f_in, s.f_in_pad = f_real, f_pad
             if s.kind in ('noise', 'dropout'):
                 s.value = st['value']
@@ -204,6 +205,7 @@ class Model(object):
             else:
                 raise ValueError(s.kind)
             s.f_out, s.f_out_pad = f_real, f_pad
+            s.p_hi = off
             self.stages.append(s)
         self.num_classes = f_real
         self.n_params = off
@@ -557,17 +559,27 @@ class Model(object):
         if not hasattr(self, '_dz_free'):
             self._dz_free = [None, None]
 
+        reduce_now = self._dist_active() and os.environ.get('ASR_AR_OVERLAP', '1') != '0'
+        self._ar_handles, self._ar_covered = [], []
+
         def flush_side():
             # enqueue deferred weight-gradient work on the side stream (called right
             # AFTER the next layer's BPTT kernel has been launched on the main stream)
             while pending:
-                fn, ready, par = pending.pop(0)
+                fn, ready, par, rng = pending.pop(0)
                 with torch.cuda.stream(self._side):
                     self._side.wait_event(ready)
                     fn('gemm_side')
                     ev = torch.cuda.Event()
                     ev.record(self._side)
                     self._dz_free[par] = ev
+                    if reduce_now and rng is not None:
+                        # this layer's gradients are final: their all-reduce (RCCL orders
+                        # itself after the side stream) overlaps the BPTT of the layers below
+                        import torch.distributed as dist
+                        self._ar_handles.append(
+                            dist.all_reduce(self.grads[rng[0]:rng[1]], async_op=True))
+                        self._ar_covered.append(rng)
 
         skip_grads = {}        # stage index -> gradient to add to that stage's OUTPUT
         for si in range(len(self.stages) - 1, -1, -1):
@@ -699,7 +711,7 @@ class Model(object):
                     # nothing left to hide behind: share the tail between both streams
                     ready = torch.cuda.Event()
                     ready.record(main)
-                    pending.append((grads_U, ready, par))
+                    pending.append((grads_U, ready, par, None))
                     flush_side()
                     grads_W('gemm')
                 else:
@@ -707,7 +719,7 @@ class Model(object):
                     # i.e. together with the next layer's BPTT kernel
                     ready = torch.cuda.Event()
                     ready.record(main)
-                    pending.append((weight_grads, ready, par))
+                    pending.append((weight_grads, ready, par, (s.p_lo, s.p_hi)))
                     da = dx
         flush_side()
         if self.overlap and self._side is not None:
@@ -788,15 +800,31 @@ class Model(object):
         dec, dlen = ops.ctc_greedy(logits, sl, N)
         return ctc, dec, dlen
 
-    def _allreduce(self):
+    def _dist_active(self):
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and (
-                dist.get_world_size() > 1 or os.environ.get('ASR_FORCE_ALLREDUCE') == '1'):
-            # RCCL orders itself after the kernels already enqueued on the current stream
-            # and the current stream after the collective (synchronous-op semantics)
-            dist.all_reduce(self.grads)
-            return dist.get_world_size()
-        return 1
+        return dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size() > 1 or os.environ.get('ASR_FORCE_ALLREDUCE') == '1')
+
+    def _allreduce(self):
+        """Sums the gradients over the ranks (RCCL).  Layers whose weight gradients were
+        finished on the side stream during BPTT were already reduced there, asynchronously
+        (backward()); here the current stream waits for those and the remaining slices of
+        the flat buffer (first layer, Dense) are reduced in place."""
+        import torch.distributed as dist
+        if not self._dist_active():
+            return 1
+        handles, covered = getattr(self, '_ar_handles', []), sorted(getattr(self, '_ar_covered', []))
+        for h in handles:
+            h.wait()                        # the current stream waits for the collective
+        pos = 0
+        for lo, hi in covered + [(self.n_params, self.n_params)]:
+            if lo > pos:
+                # RCCL orders itself after the kernels already enqueued on the current
+                # stream and the current stream after the collective
+                dist.all_reduce(self.grads[pos:lo])
+            pos = max(pos, hi)
+        self._ar_handles, self._ar_covered = [], []
+        return dist.get_world_size()
 
     def train_on_batch(self, inputs, outputs=None, masks=None, sync=True):
         """One optimisation step on a batch ``[x, labels, inputs_length]``.
