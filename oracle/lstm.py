@@ -33,7 +33,28 @@ def hard_sigmoid_grad(x):
     return np.where((y >= 0.0) & (y <= 1.0), 0.2, 0.0).astype(x.dtype)
 
 
-def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, kh=None):
+LN_EPS = 1e-5       # core/layers_utils.py:16
+
+
+def layer_norm(x, gain, bias):
+    """core/layers_utils.py:16-19: moments over axis 1 (biased variance), eps inside the
+    square root.  Returns (y, xhat, rstd)."""
+    mu = x.mean(axis=1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + LN_EPS)
+    xhat = (x - mu) * rstd
+    return xhat * gain + bias, xhat, rstd
+
+
+def layer_norm_backward(dy, xhat, rstd, gain):
+    """-> (dx, dgain, dbias) for y = xhat * gain + bias."""
+    g = dy * gain
+    dx = rstd * (g - g.mean(axis=1, keepdims=True) - xhat * (g * xhat).mean(axis=1, keepdims=True))
+    return dx, (dy * xhat).sum(axis=0), dy.sum(axis=0)
+
+
+def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, kh=None,
+                 ln=None):
     """One direction.  x (T,N,in); W (in,4H); U (H,4H); b (4H).
 
     BW (N,in) / BU (N,H): variational dropout masks (already scaled by 1/(1-p))
@@ -43,7 +64,10 @@ def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, 
     ``kc`` / ``kh`` (T,H): zoneout coefficients of the cell / hidden state,
     new = prev + k * (candidate - prev) -- k is the per-step keep-mask (shared over the
     batch, noise_shape=(H,)) in training and the constant 1 - level at test time
-    (core/layers_utils.py:34-42; :457-467).  Returns (h_seq (T,N,H), cache).
+    (core/layers_utils.py:34-42; :457-467).  ``ln`` = dict with (gain, bias) pairs under
+    'Uh' (4H), 'Wx' (4H), 'new_c' (H): layer normalisation of h@U, of x@W and of the cell
+    state that feeds the output (:432-436, :460-462; the carried c stays un-normalised).
+    Returns (h_seq (T,N,H), cache).
     """
     T, N, _ = x.shape
     H = U.shape[0]
@@ -55,12 +79,16 @@ def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, 
     cs = np.zeros((T, N, H), dt)
     gates = np.zeros((T, N, 4 * H), dt)     # post-activation i,f,g,o
     zs = np.zeros((T, N, 4 * H), dt)        # pre-activation
-    uhs = np.zeros((T, N, 4 * H), dt)       # h_prev @ U
-    wxs = np.zeros((T, N, 4 * H), dt)       # x @ W
+    uhs = np.zeros((T, N, 4 * H), dt)       # h_prev @ U   (after LN when ln is set)
+    wxs = np.zeros((T, N, 4 * H), dt)       # x @ W        (after LN when ln is set)
+    lnc = {}                                # per frame LN caches
     order = range(T - 1, -1, -1) if reverse else range(T)
     for t in order:
         hm = h if BU is None else h * BU
         wx, uh = xs[t] @ W, hm @ U
+        if ln is not None:
+            uh, uhat, urstd = layer_norm(uh, *ln['Uh'])
+            wx, what, wrstd = layer_norm(wx, *ln['Wx'])
         if mi is not None:
             z = mi[0] * wx * uh + mi[1] * uh + mi[2] * wx + b
         else:
@@ -72,14 +100,20 @@ def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, 
         c_new = f * c + i * g
         if kc is not None:
             c_new = c + kc[t][None] * (c_new - c)
-        h_new = o * np.tanh(c_new)
+        if ln is not None:
+            cn, chat, crstd = layer_norm(c_new, *ln['new_c'])
+            lnc[t] = (uhat, urstd, what, wrstd, chat, crstd, cn)
+        else:
+            cn = c_new
+        h_new = o * np.tanh(cn)
         if kh is not None:
             h_new = h + kh[t][None] * (h_new - h)
         h, c = h_new, c_new
         hs[t], cs[t], zs[t], uhs[t], wxs[t] = h, c, z, uh, wx
         gates[t] = np.concatenate([i, f, g, o], axis=1)
     cache = dict(x=x, xs=xs, W=W, U=U, BW=BW, BU=BU, hs=hs, cs=cs, zs=zs,
-                 gates=gates, reverse=reverse, mi=mi, kc=kc, kh=kh, uhs=uhs, wxs=wxs)
+                 gates=gates, reverse=reverse, mi=mi, kc=kc, kh=kh, uhs=uhs, wxs=wxs,
+                 ln=ln, lnc=lnc)
     return hs, cache
 
 
@@ -90,6 +124,9 @@ def lstm_backward(dhs, cache):
     BW, BU = cache['BW'], cache['BU']
     hs, cs, zs, gates = cache['hs'], cache['cs'], cache['zs'], cache['gates']
     mi, kc, kh = cache.get('mi'), cache.get('kc'), cache.get('kh')
+    ln, lnc = cache.get('ln'), cache.get('lnc')
+    dln = None if ln is None else {k: [np.zeros_like(v[0]), np.zeros_like(v[1])]
+                                   for k, v in ln.items()}
     reverse = cache['reverse']
     T, N, H = hs.shape
     dt = x.dtype
@@ -115,9 +152,17 @@ def lstm_backward(dhs, cache):
         if kh is not None:                  # h = h_prev + kh (h~ - h_prev)
             dh_zone = (1.0 - kh[t][None]) * dh
             dh = kh[t][None] * dh
-        tc = np.tanh(cs[t])
+        if ln is not None:
+            uhat, urstd, what, wrstd, chat, crstd, cn = lnc[t]
+            tc = np.tanh(cn)
+            dcn = dh * o * (1.0 - tc * tc)
+            dcl, dg_, db_ = layer_norm_backward(dcn, chat, crstd, ln['new_c'][0])
+            dln['new_c'][0] += dg_; dln['new_c'][1] += db_
+        else:
+            tc = np.tanh(cs[t])
+            dcl = dh * o * (1.0 - tc * tc)
         do = dh * tc
-        dc = dc_next + dh * o * (1.0 - tc * tc)
+        dc = dc_next + dcl
         dc_zone = 0.0
         if kc is not None:                  # c = c_prev + kc (c~ - c_prev)
             dc_zone = (1.0 - kc[t][None]) * dc
@@ -139,6 +184,11 @@ def lstm_backward(dhs, cache):
             dmi[2] += (dz * wx).sum(axis=0)
         else:
             da = dwx = dz
+        if ln is not None:      # back through the two input normalisations
+            da, dg_, db_ = layer_norm_backward(da, uhat, urstd, ln['Uh'][0])
+            dln['Uh'][0] += dg_; dln['Uh'][1] += db_
+            dwx, dg_, db_ = layer_norm_backward(dwx, what, wrstd, ln['Wx'][0])
+            dln['Wx'][0] += dg_; dln['Wx'][1] += db_
         das[t], dwxs[t] = da, dwx
         hm = h_prev if BU is None else h_prev * BU
         dW += xs[t].T @ dwx
@@ -151,6 +201,7 @@ def lstm_backward(dhs, cache):
     cache['dzs'] = dzs          # gate pre-activation gradients (kernel parity tests)
     cache['das'], cache['dwxs'] = das, dwxs
     cache['dmi'] = dmi if mi is not None else None
+    cache['dln'] = dln
     return dx, dW, dU, db
 
 

@@ -196,3 +196,44 @@ def test_multiplicative_integration_and_zoneout_gradients_match_finite_differenc
                            [np.zeros(4 * H), np.ones(4 * H), np.ones(4 * H)],
                            np.ones((T, H)), np.ones((T, H)))[0]
     assert np.allclose(plain, ident, atol=1e-12)
+
+
+def test_layer_normalisation_gradients_match_finite_differences():
+    """layer_norm option of the reference override (core/layers.py:407-436, 460-462;
+    core/layers_utils.py:16-19): LN of h@U, of x@W and of the cell state feeding the output,
+    with and without multiplicative integration, plus zoneout and dropout masks."""
+    rs = np.random.RandomState(5)
+    T, N, F, H = 5, 3, 4, 6
+    x = rs.randn(T, N, F)
+    W, U, b = rs.randn(F, 4 * H) * 0.5, rs.randn(H, 4 * H) * 0.5, rs.randn(4 * H) * 0.2
+    mi = [1 + 0.3 * rs.randn(4 * H), 0.5 + 0.3 * rs.randn(4 * H), 0.5 + 0.3 * rs.randn(4 * H)]
+    ln = {'Uh': [1 + 0.2 * rs.randn(4 * H), 0.1 * rs.randn(4 * H)],
+          'Wx': [1 + 0.2 * rs.randn(4 * H), 0.1 * rs.randn(4 * H)],
+          'new_c': [1 + 0.2 * rs.randn(H), 0.1 * rs.randn(H)]}
+    kc = (rs.rand(T, H) > 0.3).astype(float)
+    kh = np.full((T, H), 0.8)
+    BU, BW = (rs.rand(N, H) > 0.2) / 0.8, (rs.rand(N, F) > 0.2) / 0.8
+    w = rs.randn(T, N, H)
+    for use_mi in (None, mi):
+        for rev in (False, True):
+            def loss():
+                return float((L.lstm_forward(x, W, U, b, rev, BW, BU, use_mi, kc, kh, ln)[0] * w).sum())
+            hs, c = L.lstm_forward(x, W, U, b, rev, BW, BU, use_mi, kc, kh, ln)
+            dx, dW, dU, db = L.lstm_backward(w.copy(), c)
+            items = [('x', x, dx), ('W', W, dW), ('U', U, dU), ('b', b, db)]
+            for k in ('Uh', 'Wx', 'new_c'):
+                items += [(k + '_gain', ln[k][0], c['dln'][k][0]), (k + '_bias', ln[k][1], c['dln'][k][1])]
+            if use_mi is not None:
+                items += [('alpha', mi[0], c['dmi'][0]), ('beta1', mi[1], c['dmi'][1]),
+                          ('beta2', mi[2], c['dmi'][2])]
+            for name, arr, g in items:
+                for _ in range(2):
+                    idx = tuple(rs.randint(0, d) for d in arr.shape)
+                    o = arr[idx]
+                    arr[idx] = o + 1e-6
+                    lp = loss()
+                    arr[idx] = o - 1e-6
+                    lm = loss()
+                    arr[idx] = o
+                    num = (lp - lm) / 2e-6
+                    assert abs(g[idx] - num) < 2e-5 * max(1.0, abs(num)), (name, idx)
