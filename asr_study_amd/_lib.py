@@ -48,6 +48,15 @@ class LstmArgs(C.Structure):
                 ('wx', void_p), ('dwx', void_p), ('dmi', void_p)]
 
 
+class LstmLnArgs(C.Structure):
+    _fields_ = [('T', C.c_int), ('n_pad', C.c_int), ('H', C.c_int), ('has_mi', C.c_int),
+                ('U', void_p), ('mask_u', void_p), ('cellp', void_p),
+                ('zone_c', void_p), ('zone_h', void_p),
+                ('wx', void_p), ('uh', void_p), ('y', void_p), ('cell', void_p),
+                ('gates', void_p), ('dy', void_p), ('duh', void_p), ('dwx', void_p),
+                ('dparams', void_p)]
+
+
 class Segment(C.Structure):
     _fields_ = [('offset', C.c_int64), ('len', C.c_int64), ('l2', C.c_float),
                 ('reserved', C.c_float)]
@@ -99,6 +108,9 @@ SIGNATURES = {
     'asr_sgd_step': (C.c_int, [void_p, void_p, void_p, C.c_int64, void_p, C.c_int, void_p,
                                C.c_float, C.c_float, C.c_float, void_p]),
     'asr_axpby': (C.c_int, [C.c_int64, C.c_float, void_p, C.c_float, void_p, void_p, void_p]),
+    'asr_lstm_ln_workspace_bytes': (C.c_size_t, [C.POINTER(LstmLnArgs)]),
+    'asr_lstm_ln_seq_fwd': (C.c_int, [C.POINTER(LstmLnArgs), void_p]),
+    'asr_lstm_ln_seq_bwd': (C.c_int, [C.POINTER(LstmLnArgs), void_p, C.c_size_t, void_p]),
 }
 
 _lib = None

@@ -316,3 +316,37 @@ def axpby(a, x, b, y, out=None):
     L.check(L.load().asr_axpby(x.numel(), float(a), _ptr(x), float(b), _ptr(y), _ptr(out),
                                _stream()), 'asr_axpby')
     return out
+
+
+# --------------------------------------------------------------------------- LN cell
+def _lstm_ln_args(T, n_pad, H, U, cellp, wx, uh, y, cell, gates, has_mi, mask_u=None,
+                  zone_c=None, zone_h=None, dy=None, duh=None, dwx=None, dparams=None):
+    a = L.LstmLnArgs()
+    a.T, a.n_pad, a.H, a.has_mi = int(T), int(n_pad), int(H), int(bool(has_mi))
+    for name, t in (('U', U), ('mask_u', mask_u), ('cellp', cellp), ('zone_c', zone_c),
+                    ('zone_h', zone_h), ('wx', wx), ('uh', uh), ('y', y), ('cell', cell),
+                    ('gates', gates), ('dy', dy), ('duh', duh), ('dwx', dwx),
+                    ('dparams', dparams)):
+        setattr(a, name, t.data_ptr() if t is not None else None)
+    return a
+
+
+def lstm_ln_seq_fwd(wx, U, cellp, uh, y, cell, gates, T, n_pad, H, has_mi=False, mask_u=None,
+                    zone_c=None, zone_h=None):
+    """Layer-normalised cell, forward over the whole sequence (include/asr_hip.h K5-LN)."""
+    _check_f32(wx, U, cellp, uh, y, cell, gates, mask_u, zone_c, zone_h)
+    a = _lstm_ln_args(T, n_pad, H, U, cellp, wx, uh, y, cell, gates, has_mi, mask_u, zone_c,
+                      zone_h)
+    L.check(L.load().asr_lstm_ln_seq_fwd(C.byref(a), _stream()), 'asr_lstm_ln_seq_fwd')
+
+
+def lstm_ln_seq_bwd(dy, wx, U, cellp, uh, y, cell, gates, duh, dwx, dparams, T, n_pad, H,
+                    has_mi=False, mask_u=None, zone_c=None, zone_h=None):
+    _check_f32(dy, wx, U, cellp, uh, y, cell, gates, duh, dwx, dparams, mask_u, zone_c, zone_h)
+    a = _lstm_ln_args(T, n_pad, H, U, cellp, wx, uh, y, cell, gates, has_mi, mask_u, zone_c,
+                      zone_h, dy=dy, duh=duh, dwx=dwx, dparams=dparams)
+    lib = L.load()
+    nbytes = lib.asr_lstm_ln_workspace_bytes(C.byref(a))
+    ws = WS.get('lstm_ln', nbytes, dy.device)
+    L.check(lib.asr_lstm_ln_seq_bwd(C.byref(a), _ptr(ws), nbytes, _stream()),
+            'asr_lstm_ln_seq_bwd')

@@ -279,6 +279,42 @@ int asr_sgd_step(float* params, const float* grads, float* vel, int64_t n,
                  const double* norm_dev, float clipnorm, float lr,
                  float momentum, asr_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* K5-LN  Layer-normalised LSTM cell (layer_norm option of the reference's    */
+/* override: core/layers.py:407-436, 460-462; core/layers_utils.py:16-19):    */
+/* LN over the 4H row of h_prev@U, of x@W, and over the H row of the cell     */
+/* state that feeds the output (the carried c stays un-normalised); combines  */
+/* with multiplicative integration and zoneout.  Generic path: one workgroup  */
+/* per (sample, direction) row and step (see csrc/lstm_ln.hip), several times */
+/* slower than the persistent kernels.  cellp (2, 34H) per direction: alpha,  */
+/* beta1, beta2, b (4H each; alpha/beta ignored unless has_mi), gain/bias of  */
+/* LN(h@U) and of LN(x@W) (4H each), gain/bias of LN(c) (H each).  wx = x@W   */
+/* WITHOUT bias.  Backward writes duh / dwx = d/d(raw h@U) / d/d(raw x@W) and */
+/* dparams (n_pad, 2, 34H): per-row sums of the cellp gradients (sum axis 0). */
+/* ------------------------------------------------------------------------ */
+typedef struct asr_lstm_ln_args {
+  int T, n_pad, H;       /* n_pad % 16 == 0, H % 4 == 0, H <= 512              */
+  int has_mi;
+  const float* U;        /* (2, H, 4H)                                         */
+  const float* mask_u;   /* (2, n_pad, H) or NULL                              */
+  const float* cellp;    /* (2, 34H)                                           */
+  const float* zone_c;   /* (T, 2, H) or NULL                                  */
+  const float* zone_h;
+  const float* wx;       /* (T, n_pad, 2, 4H)                                  */
+  float* uh;             /* (T, n_pad, 2, 4H) raw h_prev@U: fwd out, bwd in     */
+  float* y;              /* (T, n_pad, 2H)                                     */
+  float* cell;           /* (T, n_pad, 2, H)                                   */
+  float* gates;          /* (T, n_pad, 2, 4H)                                  */
+  const float* dy;       /* backward: (T, n_pad, 2H)                           */
+  float* duh;            /* backward out                                       */
+  float* dwx;            /* backward out                                       */
+  float* dparams;        /* backward out                                       */
+} asr_lstm_ln_args;
+size_t asr_lstm_ln_workspace_bytes(const asr_lstm_ln_args* a);
+int asr_lstm_ln_seq_fwd(const asr_lstm_ln_args* a, asr_stream_t stream);
+int asr_lstm_ln_seq_bwd(const asr_lstm_ln_args* a, void* workspace, size_t ws_bytes,
+                        asr_stream_t stream);
+
 /* out[i] = a * x[i] + b * y[i] (out may alias x or y).  The residual connection of    */
 /* brsmv1(residual=...): keras merge([new_o, o], mode='sum' | 'ave'),                 */
 /* core/models.py:273-276, and its gradient accumulation.                            */

@@ -215,3 +215,85 @@ def test_cell_variants_multiplicative_integration_and_zoneout(T, N, H, use_mi, u
                 assert report('dmi[%d] %s %s' % (k, d, tag), got[k], ref) \
                     < 1e-4 * max(1.0, np.abs(ref).max())
     assert np.all(dzh[:, N:] == 0)
+
+
+@pytest.mark.parametrize('T,N,H,use_mi,use_zone,use_mask', [
+    (13, 5, 16, False, False, False),
+    (17, 20, 100, True, True, True),      # two batch tiles, ragged units per thread
+    (9, 16, 512, True, False, False),     # two units per thread
+])
+def test_layer_normalised_cell(T, N, H, use_mi, use_zone, use_mask):
+    """asr_lstm_ln_seq_fwd / _bwd (layer_norm option, core/layers.py:407-436, 460-462) vs the
+    oracle: h, c 1e-4; d/d(h@U), d/d(x@W) and every parameter gradient 1e-4 * max."""
+    from asr_study_amd import ops
+    F = 7
+    rs, x, p, masks = _case(T, N, F, H, 5 * T + H, use_mask)
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    ln = {d: {'Uh': [1 + 0.2 * rs.randn(4 * H), 0.1 * rs.randn(4 * H)],
+              'Wx': [1 + 0.2 * rs.randn(4 * H), 0.1 * rs.randn(4 * H)],
+              'new_c': [1 + 0.2 * rs.randn(H), 0.1 * rs.randn(H)]} for d in ('fwd', 'bwd')}
+    mi = {d: [1.0 + 0.3 * rs.randn(4 * H), 0.6 + 0.3 * rs.randn(4 * H),
+              0.7 + 0.3 * rs.randn(4 * H)] for d in ('fwd', 'bwd')} if use_mi else None
+    zone = {d: ((rs.rand(T, H) > 0.3).astype(np.float64), np.full((T, H), 0.85))
+            for d in ('fwd', 'bwd')} if use_zone else None
+    dhs = {d: rs.randn(T, N, H) for d in ('fwd', 'bwd')}
+    want = {}
+    for d, rev in (('fwd', False), ('bwd', True)):
+        hs, cache = OL.lstm_forward(x, p[d]['W'], p[d]['U'], p[d]['b'], rev, None, masks[d],
+                                    mi[d] if mi else None, *(zone[d] if zone else (None, None)),
+                                    ln=ln[d])
+        OL.lstm_backward(dhs[d], cache)
+        want[d] = dict(hs=hs, cache=cache)
+    um = gate_major_to_unit_major
+    wx = np.zeros((T, n_pad, 2, 4 * H), np.float32)
+    U = np.zeros((2, H, 4 * H), np.float32)
+    cellp = np.zeros((2, 34 * H), np.float32)
+    mk = np.ones((2, n_pad, H), np.float32)
+    for di, d in enumerate(('fwd', 'bwd')):
+        wx[:, :N, di] = um(x @ p[d]['W'], H)
+        U[di] = um(p[d]['U'], H)
+        blocks = ([um(v, H) for v in mi[d]] if use_mi else [np.zeros(4 * H)] * 3) + \
+            [um(p[d]['b'], H), um(ln[d]['Uh'][0], H), um(ln[d]['Uh'][1], H),
+             um(ln[d]['Wx'][0], H), um(ln[d]['Wx'][1], H), ln[d]['new_c'][0], ln[d]['new_c'][1]]
+        cellp[di] = np.concatenate(blocks)
+        if use_mask:
+            mk[di, :N] = masks[d]
+    mk_d = to_dev(mk) if use_mask else None
+    zc_d = zh_d = None
+    if use_zone:
+        zc_d = to_dev(np.stack([zone['fwd'][0], zone['bwd'][0]], axis=1).astype(np.float32))
+        zh_d = to_dev(np.stack([zone['fwd'][1], zone['bwd'][1]], axis=1).astype(np.float32))
+    wx_d, U_d, cp_d = to_dev(wx), to_dev(U), to_dev(cellp)
+    z4 = lambda: torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    uh, gates, duh, dwx = z4(), z4(), z4(), z4()
+    y = torch.zeros(T, n_pad, 2 * H, device=dev)
+    cell = torch.zeros(T, n_pad, 2, H, device=dev)
+    ops.lstm_ln_seq_fwd(wx_d, U_d, cp_d, uh, y, cell, gates, T, n_pad, H, has_mi=use_mi,
+                        mask_u=mk_d, zone_c=zc_d, zone_h=zh_d)
+    yh, ch = y.cpu().numpy(), cell.cpu().numpy()
+    tag = 'LN T%d N%d H%d mi%d z%d' % (T, N, H, use_mi, use_zone)
+    for di, d in enumerate(('fwd', 'bwd')):
+        assert report('h %s %s' % (d, tag), yh[:, :N, di * H:(di + 1) * H], want[d]['hs']) < 1e-4
+        assert report('c %s %s' % (d, tag), ch[:, :N, di], want[d]['cache']['cs']) < 1e-4
+    dy = np.zeros((T, n_pad, 2 * H), np.float32)
+    dy[:, :N, :H], dy[:, :N, H:] = dhs['fwd'], dhs['bwd']
+    dparams = torch.zeros(n_pad, 2, 34 * H, device=dev)
+    ops.lstm_ln_seq_bwd(to_dev(dy), wx_d, U_d, cp_d, uh, y, cell, gates, duh, dwx, dparams,
+                        T, n_pad, H, has_mi=use_mi, mask_u=mk_d, zone_c=zc_d, zone_h=zh_d)
+    got_p = dparams.cpu().numpy()[:N].sum(axis=0)
+    # LN of the all-zero h@U row of the first step has 1/sqrt(eps) = 316 as its scale: the
+    # gradients through it are amplified by that factor, and so is float32 round-off
+    # (the oracle runs in float64) -- wide rows get a tolerance of 1e-3 of the maximum
+    gtol = 1e-4 if H <= 128 else 1e-3
+    for di, d in enumerate(('fwd', 'bwd')):
+        c = want[d]['cache']
+        for name, got, ref in (('duh', duh.cpu().numpy()[:, :N, di], um(c['das'], H)),
+                               ('dwx', dwx.cpu().numpy()[:, :N, di], um(c['dwxs'], H))):
+            assert report('%s %s %s' % (name, d, tag), got, ref) < gtol * max(1.0, np.abs(ref).max())
+        refs = ([um(g, H) for g in c['dmi']] if use_mi else [np.zeros(4 * H)] * 3) + \
+            [um(c['dzs'].sum(axis=(0, 1)), H), um(c['dln']['Uh'][0], H), um(c['dln']['Uh'][1], H),
+             um(c['dln']['Wx'][0], H), um(c['dln']['Wx'][1], H), c['dln']['new_c'][0],
+             c['dln']['new_c'][1]]
+        ref = np.concatenate(refs)
+        assert report('dparams %s %s' % (d, tag), got_p[di], ref) < gtol * max(1.0, np.abs(ref).max())
