@@ -175,7 +175,16 @@ class Model(object):
                 s.oU = take(2 * s.Hp * 4 * s.Hp)
                 segs += [(s.oW, _pad4(f_pad * 8 * s.Hp), s.l2_W),
                          (s.oU, _pad4(2 * s.Hp * 4 * s.Hp), s.l2_U)]
-                if s.mi is None:
+                s.ln = st.get('layer_norm')             # [gain_init, bias_init] or None
+                if s.ln is not None:
+                    if s.Hp != s.H:
+                        raise NotImplementedError('layer_norm needs num_hiddens % 4 == 0')
+                    # (2, 34H): alpha, beta1, beta2, bias, LN(h@U) gain/bias, LN(x@W)
+                    # gain/bias (4H each), LN(c) gain/bias (H each)  -- csrc/lstm_ln.hip
+                    s.ocell = take(68 * s.Hp)
+                    s.ob = None
+                    segs.append((s.ocell, _pad4(68 * s.Hp), 0.0))
+                elif s.mi is None:
                     s.ob = take(8 * s.Hp)
                     segs.append((s.ob, _pad4(8 * s.Hp), 0.0))
                 else:       # (2, 4, 4Hp): alpha, beta1, beta2, bias per direction
@@ -194,6 +203,10 @@ class Model(object):
                     ws += [W.astype(np.float32), U.astype(np.float32), b.astype(np.float32)]
                     if s.mi is not None:            # k_init: constant vectors (core/initializers.py)
                         ws += [np.full(4 * s.H, float(k), np.float32) for k in s.mi]
+                    if s.ln is not None:            # gain, bias of LN(h@U), LN(x@W), LN(c)
+                        for width in (4 * s.H, 4 * s.H, s.H):
+                            ws += [np.full(width, float(s.ln[0]), np.float32),
+                                   np.full(width, float(s.ln[1]), np.float32)]
                 init.append((s, 'bilstm', ws))
                 f_real, f_pad = 2 * s.H, 2 * s.Hp
             elif s.kind == 'merge':
@@ -260,9 +273,23 @@ class Model(object):
                         for k in range(3):
                             mip[d, k] = _gm2um(np.asarray(next(it), np.float32), s.H, s.Hp)
                         mip[d, 3] = bp[d]
+                    if s.ln is not None:            # ... then the LN pairs (Uh, Wx, new_c)
+                        H = s.H
+                        blk = np.zeros(34 * H, np.float32)
+                        if s.mi is not None:
+                            blk[:12 * H] = mip[d, :3].ravel()
+                        blk[12 * H:16 * H] = bp[d]
+                        for k in range(4):          # gain_u, bias_u, gain_w, bias_w
+                            blk[(16 + 4 * k) * H:(20 + 4 * k) * H] = \
+                                _gm2um(np.asarray(next(it), np.float32), H, H)
+                        blk[32 * H:33 * H] = np.asarray(next(it), np.float32)
+                        blk[33 * H:34 * H] = np.asarray(next(it), np.float32)
+                        host[s.ocell + d * 34 * H:s.ocell + (d + 1) * 34 * H] = blk
                 host[s.oW:s.oW + Wp.size] = Wp.ravel()
                 host[s.oU:s.oU + Up.size] = Up.ravel()
-                if s.mi is None:
+                if s.ln is not None:
+                    pass
+                elif s.mi is None:
                     host[s.ob:s.ob + bp.size] = bp.ravel()
                 else:
                     host[s.omi:s.omi + mip.size] = mip.ravel()
@@ -279,7 +306,11 @@ class Model(object):
                 rows = self._real_rows(s)
                 Wp = flat[s.oW:s.oW + s.f_in_pad * 8 * s.Hp].reshape(s.f_in_pad, 2, 4 * s.Hp)
                 Up = flat[s.oU:s.oU + 2 * s.Hp * 4 * s.Hp].reshape(2, s.Hp, 4 * s.Hp)
-                if s.mi is None:
+                if s.ln is not None:
+                    cp = flat[s.ocell:s.ocell + 68 * s.Hp].reshape(2, 34 * s.Hp)
+                    mip = cp[:, :16 * s.Hp].reshape(2, 4, 4 * s.Hp)
+                    bp = mip[:, 3]
+                elif s.mi is None:
                     bp = flat[s.ob:s.ob + 8 * s.Hp].reshape(2, 4 * s.Hp)
                 else:
                     mip = flat[s.omi:s.omi + 32 * s.Hp].reshape(2, 4, 4 * s.Hp)
@@ -289,6 +320,11 @@ class Model(object):
                             _um2gm(bp[d], s.H, s.Hp)]
                     if s.mi is not None:
                         out += [_um2gm(mip[d, k], s.H, s.Hp) for k in range(3)]
+                    if s.ln is not None:
+                        H = s.H
+                        out += [_um2gm(cp[d, (16 + 4 * k) * H:(20 + 4 * k) * H], H, H)
+                                for k in range(4)]
+                        out += [cp[d, 32 * H:33 * H].copy(), cp[d, 33 * H:34 * H].copy()]
         return out
 
     def get_weights(self):
@@ -396,7 +432,7 @@ class Model(object):
                 rec['BW'], rec['BU'] = BW, BU
                 var = self._variant_args(s, si, T, n_pad, training, masks)
                 rec['var'] = var
-                if s.mi is None:
+                if s.mi is None and s.ln is None:
                     zx = self._buf('zx%d_%d' % (nb % 2, Hp), (T, n_pad, 2, 4 * Hp))
                 else:       # x@W is needed again by BPTT: one buffer per layer
                     zx = self._buf('zxmi%d' % si, (T, n_pad, 2, 4 * Hp))
@@ -415,8 +451,14 @@ class Model(object):
                 gates = self._buf('gates%d' % si, (T, n_pad, 2, 4 * Hp))
                 U = self._view(s.oU, 2 * Hp * 4 * Hp)
                 nxt = self.stages[si + 1] if si + 1 < len(self.stages) else None
-                if pipe and nxt is not None and nxt.kind == 'bilstm' and not var \
-                        and nxt.mi is None:
+                if s.ln is not None:        # generic row-per-workgroup cell (csrc/lstm_ln.hip)
+                    uh = self._buf('uh%d' % si, (T, n_pad, 2, 4 * Hp))
+                    rec['uh'] = uh
+                    ops.lstm_ln_seq_fwd(zx, U, self._view(s.ocell, 68 * Hp), uh, y, cell, gates, T,
+                                        n_pad, Hp, has_mi=s.mi is not None, mask_u=BU,
+                                        zone_c=var.get('zone_c'), zone_h=var.get('zone_h'))
+                elif pipe and nxt is not None and nxt.kind == 'bilstm' and not var \
+                        and nxt.mi is None and nxt.ln is None:
                     # after S = 3T/4 steps the frames [T-S, S) of y are final in BOTH
                     # directions: the next layer's input projection of those frames runs
                     # on the pipe stream while this recurrence finishes its last quarter
@@ -457,7 +499,7 @@ class Model(object):
         """Keyword arguments of the optional cell variants for ops.lstm_seq_fwd (and, with
         the backward extras added later, lstm_seq_bwd): {} for the plain cell."""
         var = {}
-        if s.mi is not None:
+        if s.mi is not None and s.ln is None:
             var['mi'] = self._view(s.omi, 32 * s.Hp)
             var['uh'] = self._buf('uh%d' % si, (T, n_pad, 2, 4 * s.Hp))
         if s.zoneout_c > 0 or s.zoneout_h > 0:
@@ -488,7 +530,7 @@ class Model(object):
             return
         # with multiplicative integration the bias enters inside the cell (z = alpha Wx Uh
         # + beta1 Uh + beta2 Wx + b), so the projection is the bare product
-        bias = self._view(s.ob, 8 * Hp) if s.mi is None else None
+        bias = self._view(s.ob, 8 * Hp) if (s.mi is None and s.ln is None) else None
         if BW is None:
             ops.gemm(a, self.params, zx, m, 8 * Hp, s.f_in_pad, a_off=r0 * s.f_in_pad,
                      b_off=s.oW, c_off=r0 * 8 * Hp, bias=bias)
@@ -625,12 +667,19 @@ class Model(object):
                 zmx = self._buf('dzmax%d' % par, (1,))
                 var = dict(rec.get('var') or {})
                 gsrc = dz                  # slab the dW / dX GEMMs read
-                if s.mi is not None:
+                pgrad = None               # (per-row parameter-gradient sums, rows, cols, offset)
+                if s.ln is not None:
+                    gsrc = self._buf('dwx%d' % par, (T, n_pad, 2, 4 * Hp))
+                    dpar = self._buf('dcellp%d' % si, (n_pad, 2, 34 * Hp))
+                    pgrad = (dpar, n_pad, 68 * Hp, s.ocell)
+                elif s.mi is not None:
                     gsrc = self._buf('dwx%d' % par, (T, n_pad, 2, 4 * Hp))
                     dmi = self._buf('dmi%d' % si, (n_pad // 16, 2, 4, 4 * Hp))
                     var.update(wx=rec['zx'], dwx=gsrc, dmi=dmi)
+                    pgrad = (dmi, n_pad // 16, 32 * Hp, s.omi)
                 pipe_b = (getattr(self, '_pipe_now', False) and self._pipe is not None
-                          and not first and self.lstm_mode == 0 and T >= 16 and not var)
+                          and not first and self.lstm_mode == 0 and T >= 16 and not var
+                          and s.ln is None)
                 S = (self._pipe_split16 * T) // 16
                 dx = None
                 if pipe_b:
@@ -650,6 +699,16 @@ class Model(object):
                     rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad,
                                                    Hp, mask_u=BU, mode=self.lstm_mode,
                                                    dz_absmax=zmx, steps=(S, T - S))
+                elif s.ln is not None:
+                    ops.lstm_ln_seq_bwd(da, rec['zx'], U, self._view(s.ocell, 68 * Hp), rec['uh'],
+                                        rec['y'], rec['cell'], rec['gates'], dz, gsrc, pgrad[0], T,
+                                        n_pad, Hp, has_mi=s.mi is not None, mask_u=BU,
+                                        zone_c=var.get('zone_c'), zone_h=var.get('zone_h'))
+                    # one pre-scale for the gradient GEMMs: max over both gradient slabs
+                    ops.absmax(dz, zmx)
+                    tmp = ops.absmax(gsrc, self._buf('dzmax_t', (1,)))
+                    torch.maximum(zmx, tmp, out=zmx)
+                    flush_side()
                 else:
                     rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad,
                                                    Hp, mask_u=BU, mode=self.lstm_mode,
@@ -673,8 +732,7 @@ class Model(object):
                         else:
                             self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
 
-                def grads_W(wsn, s=s, dz=gsrc, a_in=a_in, BW=BW, Hp=Hp, zmx=zmx,
-                            dmi=var.get('dmi')):
+                def grads_W(wsn, s=s, dz=gsrc, a_in=a_in, BW=BW, Hp=Hp, zmx=zmx, pgrad=pgrad):
                     # dW = (x (.) B_W)^T d(x@W), db = colsum(dz)
                     if BW is None:
                         ops.gemm(a_in, dz, self.grads, s.f_in_pad, 8 * Hp, rows, trans_a=True,
@@ -685,12 +743,13 @@ class Model(object):
                                      ldb=8 * Hp, ldc=8 * Hp, b_off=d * 4 * Hp,
                                      c_off=s.oW + d * 4 * Hp, split_k=split, a_scale=BW[d],
                                      a_scale_period=n_pad, ws_name=wsn, b_absmax=zmx)
-                    if dmi is None:
+                    if pgrad is None:
                         ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp),
                                    ws_name=wsn + '_cs')
-                    else:   # d alpha, d beta1, d beta2, d b: per-batch-tile sums from BPTT
-                        ops.colsum(dmi, n_pad // 16, 32 * Hp, 32 * Hp,
-                                   self._gview(s.omi, 32 * Hp), ws_name=wsn + '_cs')
+                    else:   # bias / MI / LN parameter gradients: partial sums from BPTT
+                        buf, nrow, ncol, goff = pgrad
+                        ops.colsum(buf, nrow, ncol, ncol, self._gview(goff, ncol),
+                                   ws_name=wsn + '_cs')
 
                 def weight_grads(wsn, gu=grads_U, gw=grads_W):
                     gu(wsn)

@@ -8,7 +8,7 @@ N x Bidirectional(LSTM) -> TimeDistributed(Dense)) and hands its two ends to
 HIP engine (core/engine.py) executes.  ``LSTM`` keeps the reference override's
 signature (core/layers.py:366-386: zoneout_h/zoneout_c/layer_norm/mi on top of the
 Keras LSTM arguments); of the optional variants the residual ``merge``, multiplicative
-integration and zoneout are implemented, layer_norm is not.
+integration, zoneout and layer normalisation are implemented.
 """
 
 
@@ -88,17 +88,17 @@ class LSTM(object):
 
     Implemented: consume_less='gpu' fused layout, hard_sigmoid inner activation,
     tanh activation, variational dropout_W / dropout_U, W/U l2 regularisers,
-    multiplicative integration (mi=[alpha, beta1, beta2] inits) and zoneout_c / zoneout_h.
+    multiplicative integration (mi=[alpha, beta1, beta2] inits), zoneout_c / zoneout_h and
+    layer_norm=[gain_init, bias_init] (LN of h@U, x@W and the output cell state).
     """
 
     def __init__(self, output_dim, zoneout_h=0., zoneout_c=0., layer_norm=None, mi=None,
                  return_sequences=True, consume_less='gpu', W_regularizer=None,
                  U_regularizer=None, dropout_W=0., dropout_U=0., activation='tanh',
                  inner_activation='hard_sigmoid', **kwargs):
-        if layer_norm is not None:
-            raise NotImplementedError(
-                'layer_norm is not built yet (SURVEY.md row N4): it needs three extra '
-                'cross-workgroup reductions per recurrent step')
+        if layer_norm is not None and len(layer_norm) != 2:
+            raise ValueError('layer_norm = [gain_init, bias_init]')
+        self.layer_norm = None if layer_norm is None else [float(v) for v in layer_norm]
         if mi is not None and len(mi) != 3:
             raise ValueError('mi = [alpha_init, beta1_init, beta2_init]')
         self.mi = None if mi is None else [float(v) for v in mi]

@@ -263,7 +263,8 @@ def model_forward(params, x, masks=None, zone=None):
             kc = kh = None
             if zone is not None and zone[li] is not None:
                 kc, kh = zone[li][dname]
-            hs, cache = lstm_forward(o, p['W'], p['U'], p['b'], rev, BW, BU, p.get('mi'), kc, kh)
+            hs, cache = lstm_forward(o, p['W'], p['U'], p['b'], rev, BW, BU, p.get('mi'), kc, kh,
+                                     ln=p.get('ln'))
             outs.append(hs); lc[dname] = cache
         caches['layers'].append(lc)
         new_o = np.concatenate(outs, axis=-1)
@@ -306,6 +307,8 @@ def model_backward(params, caches, dlogits):
             g[dname] = {'W': dW, 'U': dU, 'b': db}
             if caches['layers'][li][dname].get('dmi') is not None:
                 g[dname]['mi'] = caches['layers'][li][dname]['dmi']
+            if caches['layers'][li][dname].get('dln') is not None:
+                g[dname]['ln'] = caches['layers'][li][dname]['dln']
             dx_total = dx if dx_total is None else dx_total + dx
         grads['layers'][li] = g
         do = dx_total if d_skip is None else dx_total + d_skip
@@ -365,5 +368,11 @@ def flatten(tree):
             if layer[d].get('mi') is not None:       # Keras add_weight order (layers.py:389-404)
                 for k, a in zip(('mi_alpha', 'mi_beta1', 'mi_beta2'), layer[d]['mi']):
                     out.append(('layer%d/%s/%s' % (li, d, k), a))
+            if layer[d].get('ln') is not None:
+                # the reference iterates a dict literal {'Uh', 'Wx', 'new_c'} (layers.py:409),
+                # whose Python-2 order is unspecified: this order is a convention of the build
+                for k in ('Uh', 'Wx', 'new_c'):
+                    out.append(('layer%d/%s/ln_gain_%s' % (li, d, k), layer[d]['ln'][k][0]))
+                    out.append(('layer%d/%s/ln_bias_%s' % (li, d, k), layer[d]['ln'][k][1]))
     out += [('dense/W', tree['dense']['W']), ('dense/b', tree['dense']['b'])]
     return out

@@ -129,6 +129,8 @@ int main(void) {
   printf("lstm %zu %zu %zu %zu\\n", sizeof(asr_lstm_args), offsetof(asr_lstm_args, dz_absmax),
          offsetof(asr_lstm_args, step_begin), offsetof(asr_lstm_args, dmi));
   printf("segment %zu %zu\\n", sizeof(asr_segment), offsetof(asr_segment, l2));
+  printf("lstmln %zu %zu %zu\\n", sizeof(asr_lstm_ln_args), offsetof(asr_lstm_ln_args, cellp),
+         offsetof(asr_lstm_ln_args, dparams));
   return 0;
 }
 ''')
@@ -141,3 +143,5 @@ int main(void) {
     assert out['gemm'] == [C.sizeof(G), G.bias.offset, G.b_absmax.offset]
     assert out['lstm'] == [C.sizeof(Ls), Ls.dz_absmax.offset, Ls.step_begin.offset, Ls.dmi.offset]
     assert out['segment'] == [C.sizeof(S), S.l2.offset]
+    LN = _lib.LstmLnArgs
+    assert out['lstmln'] == [C.sizeof(LN), LN.cellp.offset, LN.dparams.offset]

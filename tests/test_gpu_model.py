@@ -256,3 +256,59 @@ def test_brsmv1_multiplicative_integration_and_zoneout():
     want_t = OL.model_forward(params, xt, zone=zone_t)[0]
     logits_t = model.forward(slab, training=False).cpu().numpy()[:, :N]
     assert report('mi+zoneout test-phase logits', logits_t, want_t) < 1e-4
+
+
+@pytest.mark.parametrize('with_mi', [False, True])
+def test_brsmv1_layer_normalisation(with_mi):
+    """brsmv1(layer_norm=[gain, bias]) (+ mi, zoneout): weights in the order [W, U, b,
+    (alpha, beta1, beta2), gain/bias of LN(h@U), LN(x@W), LN(c)] per direction; logits, loss
+    and every gradient vs the oracle."""
+    from asr_study_amd.core import models
+    rs = np.random.RandomState(13)
+    N, T, F, C, H, L = 5, 15, 9, 7, 12, 2
+    kw = dict(mi=[1.0, 0.5, 0.5], zoneout=0.2) if with_mi else {}
+    model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
+                          dropout=0.0, weight_decay=0.0, layer_norm=[1.0, 0.0], seed=5, **kw)
+    w = [a + rs.randn(*a.shape).astype(np.float32) * 0.15 for a in model.get_weights()]
+    per_dir = 3 + (3 if with_mi else 0) + 6
+    assert len(w) == L * 2 * per_dir + 2
+    model.set_weights(w)
+    for a, b in zip(model.get_weights(), w):
+        assert np.array_equal(a, b)
+    it = iter([a.astype(np.float64) for a in w])
+    params = {'layers': []}
+    for _ in range(L):
+        layer = {}
+        for d in ('fwd', 'bwd'):
+            layer[d] = {'W': next(it), 'U': next(it), 'b': next(it)}
+            if with_mi:
+                layer[d]['mi'] = [next(it), next(it), next(it)]
+            layer[d]['ln'] = {k: [next(it), next(it)] for k in ('Uh', 'Wx', 'new_c')}
+        params['layers'].append(layer)
+    params['dense'] = {'W': next(it), 'b': next(it)}
+    x, labels, lens = _batch(rs, N, T, F, C)
+    xt = np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float64)
+    zone, masks_g = None, None
+    if with_mi:
+        zone, masks_g = [], {}
+        for li in range(L):
+            z, KC, KH = {}, np.ones((T, 2, H), np.float32), np.ones((T, 2, H), np.float32)
+            for di, d in enumerate(('fwd', 'bwd')):
+                kc = (rs.rand(T, H) > 0.2).astype(np.float64)
+                kh = (rs.rand(T, H) > 0.2).astype(np.float64)
+                z[d] = (kc, kh)
+                KC[:, di], KH[:, di] = kc, kh
+            zone.append(z)
+            masks_g[1 + li] = (None, None, torch.from_numpy(KC).cuda(), torch.from_numpy(KH).cuda())
+    want = OL.loss_and_grads(params, xt, labels, lens, zone=zone)
+    slab = model.to_slab(x)
+    ctc, logits, _ = model.loss_and_grads(slab, labels, lens, training=True, masks=masks_g)
+    torch.cuda.synchronize()
+    assert report('LN logits', logits.cpu().numpy()[:, :N], want['logits']) < 1e-4
+    np.testing.assert_allclose(ctc.cpu().numpy(), want['ctc'], rtol=1e-4)
+    got = model.get_gradients()
+    flat = OL.flatten(want['grads'])
+    assert len(flat) == len(got)
+    for (name, g), gg in zip(flat, got):
+        scale = max(1e-3, np.abs(g).max())
+        assert report('LN grad ' + name, gg, g) < 2e-4 * scale + 1e-6, name
