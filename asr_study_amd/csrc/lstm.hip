@@ -9,22 +9,36 @@
 // i.e. a (16 x H)x(H x 4H) product per batch tile that cannot start before the
 // previous step has finished: a latency problem, not a throughput one.
 //
-// Design (CDNA4), third iteration (measured history in DESIGN.md: v1 per-wave
-// 8-byte granules 11.4 us/step; v2 1024-thread WGs 5.2/2.8 us/step fwd/bwd):
+// Design (CDNA4; measured history in DESIGN.md, from 11.4 / 19.5 us per step in the first
+// version to 2.2 / 2.5 now at H = 256):
 //  * A layer is a set of independent CHAINS (direction, 16-row batch tile).  A
 //    chain is split over 256-thread workgroups by hidden units (16 per WG); the
 //    four waves of a WG sit one per SIMD (one MFMA pipe each) and keep their slice
-//    of U stationary in VGPRs as the MFMA A-operand for the whole sequence
-//    (v_mfma_f32_16x16x4_f32: exact fp32; C/D layout row = 4*(lane>>4)+reg, col =
-//    lane&15, so with gate columns ordered unit*4+gate a lane ends up with the four
-//    gates of ONE (unit, sample): gate math is lane-local, no cross-wave reduce).
-//  * Forward: workgroups exchange h_t (H x 16 words per chain and step).  The WG
-//    gathers the chain's h ONCE into a double-buffered LDS tile (16-byte loads),
-//    every wave reads its MFMA B-operand from LDS; one barrier per step.
+//    of U stationary in VGPRs as the MFMA A-operand for the whole sequence.  C/D
+//    layout row = 4*(lane>>4)+reg, col = lane&15: with gate columns ordered
+//    unit*4+gate a lane ends up with the four gates of ONE (unit, sample), so the
+//    gate math is lane-local.
+//  * Arithmetic (default, ASR_LSTM_PREC=1): every fp32 operand is split into fp16
+//    hi + lo (22 mantissa bits) and a product is three v_mfma_f32_16x16x32_f16 with
+//    fp32 accumulation (error ~2^-22) instead of eight exact fp32 MFMAs; BPTT scales
+//    each batch column by its own power of two first.  ASR_LSTM_PREC=0 keeps the
+//    exact v_mfma_f32_16x16x4_f32 kernels (fwd_body / bwd_body).
+//  * Forward: workgroups exchange h_t, split and packed by the PRODUCER (one word =
+//    fp16 hi << 16 | fp16 lo).  From H = 256 up (fwd_body_k) K is split over the four
+//    waves: a wave multiplies all 64 gate columns of the WG with the quarter of h it
+//    gathered itself (registers -> MFMA B operand, no LDS staging), and the partial
+//    gate tiles meet in LDS; narrower layers (fwd_body_h) stage h in LDS once and
+//    every wave reads its B operand from there.  One barrier per step either way.
 //  * Backward: a workgroup owns 16 units = 64 gate columns j.  It multiplies its
 //    own dz_J (local) with U[:, J] for ALL H outputs and publishes the partial dh
-//    tiles; each consumer sums the partials addressed to its units.  Exchange
-//    volume is H x 16 words per producer -- the same as forward, not the 4H-wide dz.
+//    tiles; a consumer lane gathers the 16-byte group of its (sample, unit quad) from
+//    every producer, adds them in registers and across four lanes with DPP quad
+//    permutes.  Exchange volume is H x 16 words per producer, not the 4H-wide dz.
+//  * A step's first poll is preceded by a short nap (ASR_LSTM_PREPOLL_F/_B): a poll
+//    that reaches the L2 before the producers' stores costs a whole extra round trip.
+//  * The optional cell variants (multiplicative integration, zoneout) are the VAR
+//    template paths, compiled into their own kernels (lstm_*_kernel_hv); layer
+//    normalisation lives in lstm_ln.hip.
 //  * Hand-off protocol: every exchanged fp32 word carries the step tag in its
 //    mantissa LSB (value perturbed by <= 1 ulp; the consumer clears the bit); a
 //    16-byte group is its own flag -- no fences, no flags, placement independent
