@@ -108,6 +108,10 @@ SIGNATURES = {
     'asr_sgd_step': (C.c_int, [void_p, void_p, void_p, C.c_int64, void_p, C.c_int, void_p,
                                C.c_float, C.c_float, C.c_float, void_p]),
     'asr_axpby': (C.c_int, [C.c_int64, C.c_float, void_p, C.c_float, void_p, void_p, void_p]),
+    'asr_comm_unique_id': (C.c_int, [void_p]),
+    'asr_comm_init': (C.c_int, [void_p, C.c_int, C.c_int, C.POINTER(void_p)]),
+    'asr_comm_allreduce_sum': (C.c_int, [void_p, void_p, C.c_int64, void_p]),
+    'asr_comm_destroy': (C.c_int, [void_p]),
     'asr_lstm_ln_workspace_bytes': (C.c_size_t, [C.POINTER(LstmLnArgs)]),
     'asr_lstm_ln_seq_fwd': (C.c_int, [C.POINTER(LstmLnArgs), void_p]),
     'asr_lstm_ln_seq_bwd': (C.c_int, [C.POINTER(LstmLnArgs), void_p, C.c_size_t, void_p]),

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libasr_hip.so')
 SOURCES = ['capi.cpp', 'ctc.hip', 'frontend.hip', 'gemm.hip', 'lstm.hip', 'lstm_ln.hip',
-           'optim.hip', 'decode_host.cpp']
+           'optim.hip', 'decode_host.cpp', 'comm.cpp']
 ARCH = 'gfx950'
 
 
@@ -78,7 +78,7 @@ def _compile(verbose):
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (src, out))
     tmp = LIB + '.tmp.%d' % os.getpid()
-    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs + ['-lpthread']
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs + ['-lpthread', '-ldl']
     subprocess.check_call(cmd)
     os.replace(tmp, LIB)                     # atomic: a loader never sees a partial file
     with open(STAMP, 'w') as f:

@@ -601,7 +601,8 @@ class Model(object):
         if not hasattr(self, '_dz_free'):
             self._dz_free = [None, None]
 
-        reduce_now = self._dist_active() and os.environ.get('ASR_AR_OVERLAP', '1') != '0'
+        reduce_now = (self._dist_active() and os.environ.get('ASR_AR_OVERLAP', '1') != '0'
+                      and os.environ.get('ASR_COMM', 'torch') != 'capi')
         self._ar_handles, self._ar_covered = [], []
 
         def flush_side():
@@ -872,6 +873,11 @@ class Model(object):
         import torch.distributed as dist
         if not self._dist_active():
             return 1
+        if os.environ.get('ASR_COMM', 'torch') == 'capi':
+            # the library's own RCCL entry points (asr_comm_*), on the current stream
+            from ..parallel import CapiComm
+            CapiComm.get().allreduce_sum_(self.grads)
+            return dist.get_world_size()
         handles, covered = getattr(self, '_ar_handles', []), sorted(getattr(self, '_ar_covered', []))
         for h in handles:
             h.wait()                        # the current stream waits for the collective

@@ -107,3 +107,50 @@ class ShardedFlow(object):
         return ([x, lab, np.asarray(lens).reshape(-1)[keep]], [zeros[keep], lab])
 
     next = __next__
+
+
+class CapiComm(object):
+    """The gradient all-reduce through the library's own RCCL entry points
+    (include/asr_hip.h C1, ``ASR_COMM=capi``) instead of torch.distributed's: rank 0 draws
+    the RCCL unique id, the existing process group only ferries those 128 bytes, and the
+    collective is then enqueued on torch's CURRENT stream by ``asr_comm_allreduce_sum``."""
+
+    _instance = None
+
+    @classmethod
+    def get(cls):
+        if cls._instance is None:
+            cls._instance = cls()
+        return cls._instance
+
+    def __init__(self):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib.load()
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        box = [None]
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            _lib.check(self._lib.asr_comm_unique_id(buf), 'asr_comm_unique_id')
+            box[0] = bytes(buf)
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        self._comm = C.c_void_p()
+        _lib.check(self._lib.asr_comm_init(box[0], rank, world, C.byref(self._comm)),
+                   'asr_comm_init')
+        self.world = world
+
+    def allreduce_sum_(self, flat):
+        from . import _lib
+        stream = torch.cuda.current_stream(flat.device).cuda_stream
+        _lib.check(self._lib.asr_comm_allreduce_sum(self._comm, self._C.c_void_p(flat.data_ptr()),
+                                                    flat.numel(), self._C.c_void_p(stream)),
+                   'asr_comm_allreduce_sum')
+        return flat
+
+    def close(self):
+        if self._comm:
+            self._lib.asr_comm_destroy(self._comm)
+            self._comm = self._C.c_void_p()
+        CapiComm._instance = None

@@ -315,6 +315,23 @@ int asr_lstm_ln_seq_fwd(const asr_lstm_ln_args* a, asr_stream_t stream);
 int asr_lstm_ln_seq_bwd(const asr_lstm_ln_args* a, void* workspace, size_t ws_bytes,
                         asr_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* C1  Gradient all-reduce (RCCL over xGMI) for hosts without torch.           */
+/* One communicator per process / GPU: rank 0 calls asr_comm_unique_id and     */
+/* ships the ASR_COMM_ID_BYTES to the other ranks by any side channel; every   */
+/* rank then calls asr_comm_init with the HIP device already selected.         */
+/* asr_comm_allreduce_sum sums n floats over the ranks in place, enqueued on    */
+/* the given stream.  librccl is resolved with dlopen at first use.  (The      */
+/* shipped Python host issues the same collective through torch.distributed,   */
+/* backend "nccl" = RCCL, unless ASR_COMM=capi.)                               */
+/* ------------------------------------------------------------------------ */
+#define ASR_COMM_ID_BYTES 128
+typedef void* asr_comm_t;
+int asr_comm_unique_id(void* id_out);
+int asr_comm_init(const void* id, int rank, int world, asr_comm_t* comm_out);
+int asr_comm_allreduce_sum(asr_comm_t comm, float* buf, int64_t n, asr_stream_t stream);
+int asr_comm_destroy(asr_comm_t comm);
+
 /* out[i] = a * x[i] + b * y[i] (out may alias x or y).  The residual connection of    */
 /* brsmv1(residual=...): keras merge([new_o, o], mode='sum' | 'ave'),                 */
 /* core/models.py:273-276, and its gradient accumulation.                            */

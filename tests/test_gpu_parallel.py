@@ -49,8 +49,9 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from asr_study_amd.core import models, optimizers
 out = {}
-for mode in ("1", "0"):
-    os.environ["ASR_AR_OVERLAP"] = mode
+for mode in ("1", "0", "capi"):
+    os.environ["ASR_AR_OVERLAP"] = "0" if mode == "capi" else mode
+    os.environ["ASR_COMM"] = "capi" if mode == "capi" else "torch"
     model = models.brsmv1(num_features=9, num_classes=7, num_hiddens=16, num_layers=3,
                           dropout=0.0, weight_decay=1e-4, seed=1)
     model.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=1.0))
@@ -81,5 +82,5 @@ def test_layerwise_allreduce_overlap_equals_single_allreduce():
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('RESULT ')][0]
     res = json.loads(line[7:])
-    assert res['1'] == res['0']
+    assert res['1'] == res['0'] == res['capi']      # capi: asr_comm_* instead of torch
     assert res['layers_reduced_during_bptt_1'] == 2 and res['layers_reduced_during_bptt_0'] == 0
