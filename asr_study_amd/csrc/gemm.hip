@@ -787,8 +787,15 @@ absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out)
   for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
     m = fmaxf(m, fabsf(x[i]));
+  // one atomic per workgroup (atomics to one address serialise in the L2)
+  __shared__ float wmax[4];
   m = asr_wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (m > 0.f) atomicMax(out, __float_as_uint(m));
+  }
 }
 
 // Column sums (bias gradients): out[n] = beta*out[n] + sum_m X[m][n].  HBM-bound:
@@ -1005,7 +1012,7 @@ extern "C" int asr_absmax(const float* x, int64_t n, float* out, asr_stream_t st
   ASR_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0, "absmax: x must be 16-byte aligned");
   ASR_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), stream));
   int64_t blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, (size_t)n,
                      reinterpret_cast<unsigned*>(out));
