@@ -865,6 +865,18 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 }  // namespace
 
+// Dynamic-LDS "ballast" for the small helper kernels that run on the weight-gradient
+// stream beside a BPTT kernel: a recurrent workgroup reserves 96 KB of its CU's 160 KB,
+// so a helper asking for 80 KB can never be placed on the same CU and steal issue slots
+// from its one-wave-per-SIMD critical path (ASR_LDS_BALLAST=0 disables).
+static size_t lds_ballast(const void* kernel) {
+  static const int on = [] { const char* v = getenv("ASR_LDS_BALLAST"); return v ? atoi(v) : 1; }();
+  if (!on) return 0;
+  const size_t bytes = 80 * 1024;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
+
 extern "C" size_t asr_gemm_workspace_bytes(const asr_gemm_args* a) {
   if (!a || a->split_k <= 1) return 0;
   return asr_align_up((size_t)a->split_k * a->M * a->N * sizeof(float), 256);
@@ -999,7 +1011,8 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
     const size_t total = (size_t)a->M * a->N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream,
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256),
+                       lds_ballast((const void*)gemm_splitk_reduce_kernel), stream,
                        reinterpret_cast<const float*>(workspace), splits, a->M, a->N, ep2);
     ASR_CHECK_LAUNCH();
   }
@@ -1035,10 +1048,12 @@ extern "C" int asr_colsum(const float* X, int M, int N, int ldx, float* out, flo
   const int rs = colsum_slices(M);
   const int rows_per_slice = (M + rs - 1) / rs;
   double* partial = reinterpret_cast<double*>(workspace);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, stream, X, M, N,
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, rs), dim3(256),
+                     lds_ballast((const void*)colsum_partial_kernel), stream, X, M, N,
                      ldx, rows_per_slice, partial);
   ASR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, partial,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256),
+                     lds_ballast((const void*)colsum_final_kernel), stream, partial,
                      rs, N, out, beta);
   ASR_CHECK_LAUNCH();
   return ASR_OK;
