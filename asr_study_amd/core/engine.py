@@ -1034,11 +1034,16 @@ class Model(object):
 
     def evaluate_generator(self, generator, val_samples, max_q_size=10, nb_worker=1, **kwargs):
         """Returns [loss, ctc_loss, decoder_loss, <decoder>_ler] averaged with batch-size
-        weights (train.py:223-227, eval.py:76-80)."""
+        weights (train.py:223-227, eval.py:76-80).  Batches are drawn on a producer thread
+        (Keras' generator queue), so host reads overlap the forward pass and the decoder."""
         seen, sums = 0, np.zeros(4)
-        while seen < val_samples:
-            inputs, outputs = next(generator)
-            n = len(np.asarray(inputs[2]).reshape(-1))
-            sums += np.array(self.test_on_batch(inputs, outputs)) * n
-            seen += n
+        feeder = _Feeder(generator, max_q_size, self.device)
+        try:
+            while seen < val_samples:
+                inputs, outputs = feeder.get()
+                n = len(np.asarray(inputs[2]).reshape(-1))
+                sums += np.array(self.test_on_batch(inputs, outputs)) * n
+                seen += n
+        finally:
+            feeder.close()
         return (sums / max(seen, 1)).tolist()
