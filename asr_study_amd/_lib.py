@@ -57,6 +57,19 @@ class LstmLnArgs(C.Structure):
                 ('dparams', void_p)]
 
 
+class GateGemmArgs(C.Structure):
+    _fields_ = [('rows', C.c_int), ('n_pad', C.c_int), ('in_dim', C.c_int),
+                ('gate_dim', C.c_int),
+                ('x', void_p), ('ldx', C.c_int),
+                ('W', void_p), ('ldw', C.c_int),
+                ('bias', void_p), ('mask_w', void_p),
+                ('zx', void_p), ('ldz', C.c_int),
+                ('dz', void_p), ('dz_absmax', void_p),
+                ('dx', void_p), ('dx_beta', C.c_float),
+                ('dW', void_p), ('db', void_p),
+                ('split_k', C.c_int), ('precision', C.c_int)]
+
+
 class Segment(C.Structure):
     _fields_ = [('offset', C.c_int64), ('len', C.c_int64), ('l2', C.c_float),
                 ('reserved', C.c_float)]
@@ -115,6 +128,31 @@ SIGNATURES = {
     'asr_lstm_ln_workspace_bytes': (C.c_size_t, [C.POINTER(LstmLnArgs)]),
     'asr_lstm_ln_seq_fwd': (C.c_int, [C.POINTER(LstmLnArgs), void_p]),
     'asr_lstm_ln_seq_bwd': (C.c_int, [C.POINTER(LstmLnArgs), void_p, C.c_size_t, void_p]),
+    # operation-level entry points (csrc/roles.cpp)
+    'asr_frontend_mfcc_batch': (C.c_int, [C.POINTER(FrontendCfg), void_p, void_p, void_p,
+                                          c_int_p, C.c_int, C.c_int, void_p, void_p, void_p,
+                                          void_p, void_p, C.c_int, void_p, void_p, C.c_size_t,
+                                          void_p]),
+    'asr_frontend_logfbank_batch': (C.c_int, [C.POINTER(FrontendCfg), void_p, void_p, void_p,
+                                              c_int_p, C.c_int, C.c_int, void_p, void_p,
+                                              void_p, void_p, C.c_int, void_p, void_p,
+                                              C.c_size_t, void_p]),
+    'asr_gemm_gate_workspace_bytes': (C.c_size_t, [C.POINTER(GateGemmArgs), C.c_int]),
+    'asr_gemm_gate_fwd': (C.c_int, [C.POINTER(GateGemmArgs), void_p, C.c_size_t, void_p]),
+    'asr_gemm_gate_dgrad': (C.c_int, [C.POINTER(GateGemmArgs), void_p, C.c_size_t, void_p]),
+    'asr_gemm_gate_wgrad': (C.c_int, [C.POINTER(GateGemmArgs), void_p, C.c_size_t, void_p]),
+    'asr_ctc_beam': (C.c_int, [void_p, void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, void_p, void_p, void_p]),
+    'asr_edit_distance': (C.c_int, [void_p, void_p, C.c_int, void_p, void_p, C.c_int,
+                                    C.c_int, void_p]),
+    'asr_clip_adam_step': (C.c_int, [void_p, void_p, void_p, void_p, C.c_int64, void_p,
+                                     C.c_int, void_p, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, C.c_int, void_p, C.c_size_t,
+                                     void_p]),
+    'asr_clip_sgd_step': (C.c_int, [void_p, void_p, void_p, C.c_int64, void_p, C.c_int,
+                                    void_p, C.c_float, C.c_float, C.c_float, void_p,
+                                    C.c_size_t, void_p]),
+    'asr_comm_allreduce': (C.c_int, [void_p, void_p, C.c_int64, void_p]),
 }
 
 _lib = None

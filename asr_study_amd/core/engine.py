@@ -532,15 +532,14 @@ class Model(object):
         # + beta1 Uh + beta2 Wx + b), so the projection is the bare product
         bias = self._view(s.ob, 8 * Hp) if (s.mi is None and s.ln is None) else None
         if BW is None:
-            ops.gemm(a, self.params, zx, m, 8 * Hp, s.f_in_pad, a_off=r0 * s.f_in_pad,
-                     b_off=s.oW, c_off=r0 * 8 * Hp, bias=bias)
+            ops.gate_gemm('fwd', m, n_pad, s.f_in_pad, 8 * Hp, self.params, s.oW, 8 * Hp, 8 * Hp,
+                          x=a, x_off=r0 * s.f_in_pad, bias=bias, zx=zx, z_off=r0 * 8 * Hp)
             return
         for d in range(2):      # each direction has its own input mask (two Keras layers)
-            ops.gemm(a, self.params, zx, m, 4 * Hp, s.f_in_pad, ldb=8 * Hp, ldc=8 * Hp,
-                     a_off=r0 * s.f_in_pad, b_off=s.oW + d * 4 * Hp,
-                     c_off=r0 * 8 * Hp + d * 4 * Hp,
-                     bias=None if bias is None else bias[d * 4 * Hp:(d + 1) * 4 * Hp],
-                     a_scale=BW[d], a_scale_period=n_pad)
+            ops.gate_gemm('fwd', m, n_pad, s.f_in_pad, 4 * Hp, self.params, s.oW + d * 4 * Hp,
+                          8 * Hp, 8 * Hp, x=a, x_off=r0 * s.f_in_pad,
+                          bias=None if bias is None else bias[d * 4 * Hp:(d + 1) * 4 * Hp],
+                          mask_w=BW[d], zx=zx, z_off=r0 * 8 * Hp + d * 4 * Hp)
 
     def _dx_gemm(self, dz, s, dx, BW, r0, r1, n_pad, zmx):
         """dx[r0:r1] = sum_d B_W[d] (.) (dz_d[r0:r1] @ W_d^T) over slab rows [r0, r1)."""
@@ -548,14 +547,15 @@ class Model(object):
         if m <= 0:
             return
         if BW is None:
-            ops.gemm(dz, self.params, dx, m, s.f_in_pad, 8 * Hp, trans_b=True,
-                     a_off=r0 * 8 * Hp, b_off=s.oW, c_off=r0 * s.f_in_pad, a_absmax=zmx)
+            ops.gate_gemm('dgrad', m, n_pad, s.f_in_pad, 8 * Hp, self.params, s.oW, 8 * Hp,
+                          8 * Hp, dz=dz, z_off=r0 * 8 * Hp, dz_absmax=zmx, dx=dx,
+                          dx_off=r0 * s.f_in_pad)
             return
         for d in range(2):
-            ops.gemm(dz, self.params, dx, m, s.f_in_pad, 4 * Hp, trans_b=True, lda=8 * Hp,
-                     ldb=8 * Hp, a_off=r0 * 8 * Hp + d * 4 * Hp, b_off=s.oW + d * 4 * Hp,
-                     c_off=r0 * s.f_in_pad, beta=0.0 if d == 0 else 1.0, c_scale=BW[d],
-                     c_scale_period=n_pad, a_absmax=zmx)
+            ops.gate_gemm('dgrad', m, n_pad, s.f_in_pad, 4 * Hp, self.params, s.oW + d * 4 * Hp,
+                          8 * Hp, 8 * Hp, mask_w=BW[d], dz=dz, z_off=r0 * 8 * Hp + d * 4 * Hp,
+                          dz_absmax=zmx, dx=dx, dx_off=r0 * s.f_in_pad,
+                          dx_beta=0.0 if d == 0 else 1.0)
 
     def _draw_all_masks(self, n_pad):
         """Variational-dropout masks of every BiLSTM stage for one batch, drawn with ONE
@@ -735,19 +735,23 @@ class Model(object):
 
                 def grads_W(wsn, s=s, dz=gsrc, a_in=a_in, BW=BW, Hp=Hp, zmx=zmx, pgrad=pgrad):
                     # dW = (x (.) B_W)^T d(x@W), db = colsum(dz)
+                    own_bias = pgrad is None
                     if BW is None:
-                        ops.gemm(a_in, dz, self.grads, s.f_in_pad, 8 * Hp, rows, trans_a=True,
-                                 c_off=s.oW, split_k=split, ws_name=wsn, b_absmax=zmx)
+                        ops.gate_gemm('wgrad', rows, n_pad, s.f_in_pad, 8 * Hp, self.params, s.oW,
+                                      8 * Hp, 8 * Hp, x=a_in, dz=dz, dz_absmax=zmx,
+                                      dW=self.grads, dw_off=s.oW, split_k=split, ws_name=wsn,
+                                      db=self._gview(s.ob, 8 * Hp) if own_bias else None)
                     else:
                         for d in range(2):
-                            ops.gemm(a_in, dz, self.grads, s.f_in_pad, 4 * Hp, rows, trans_a=True,
-                                     ldb=8 * Hp, ldc=8 * Hp, b_off=d * 4 * Hp,
-                                     c_off=s.oW + d * 4 * Hp, split_k=split, a_scale=BW[d],
-                                     a_scale_period=n_pad, ws_name=wsn, b_absmax=zmx)
-                    if pgrad is None:
-                        ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp),
-                                   ws_name=wsn + '_cs')
-                    else:   # bias / MI / LN parameter gradients: partial sums from BPTT
+                            ops.gate_gemm('wgrad', rows, n_pad, s.f_in_pad, 4 * Hp, self.params,
+                                          s.oW + d * 4 * Hp, 8 * Hp, 8 * Hp, x=a_in,
+                                          mask_w=BW[d], dz=dz, z_off=d * 4 * Hp, dz_absmax=zmx,
+                                          dW=self.grads, dw_off=s.oW + d * 4 * Hp, split_k=split,
+                                          ws_name=wsn)
+                        if own_bias:    # one pass over dz for both directions' bias gradients
+                            ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp),
+                                       ws_name=wsn + '_cs')
+                    if not own_bias:    # bias / MI / LN parameter gradients: partial sums from BPTT
                         buf, nrow, ncol, goff = pgrad
                         ops.colsum(buf, nrow, ncol, ncol, self._gview(goff, ncol),
                                    ws_name=wsn + '_cs')

@@ -39,10 +39,9 @@ class Adam(Optimizer):
 
     def step(self, model):
         self.iterations += 1
-        ops.grad_norm(model.params, model.grads, model._segs_dev, model._nseg, model._norm)
-        ops.adam_step(model.params, model.grads, self.state[0], self.state[1],
-                      model._segs_dev, model._nseg, model._norm, self.clipnorm, self.lr,
-                      self.iterations, self.beta_1, self.beta_2, self.epsilon)
+        ops.clip_adam_step(model.params, model.grads, self.state[0], self.state[1],
+                           model._segs_dev, model._nseg, model._norm, self.clipnorm, self.lr,
+                           self.iterations, self.beta_1, self.beta_2, self.epsilon)
 
 
 class SGD(Optimizer):
@@ -57,9 +56,8 @@ class SGD(Optimizer):
 
     def step(self, model):
         self.iterations += 1
-        ops.grad_norm(model.params, model.grads, model._segs_dev, model._nseg, model._norm)
-        ops.sgd_step(model.params, model.grads, self.state[0], model._segs_dev, model._nseg,
-                     model._norm, self.clipnorm, self.lr, self.momentum)
+        ops.clip_sgd_step(model.params, model.grads, self.state[0], model._segs_dev,
+                          model._nseg, model._norm, self.clipnorm, self.lr, self.momentum)
 
 
 def get(name):

@@ -50,6 +50,14 @@ def pad16(n):
 
 
 # --------------------------------------------------------------------------- GEMM
+def _resolve_split(split_k, M, N, K):
+    if split_k == 'auto':
+        # long-K / small-output GEMMs (dW, dU): split K until ~1024 workgroups exist
+        tiles = ((int(M) + 127) // 128) * ((int(N) + 127) // 128)
+        split_k = max(1, min(64, (1024 + tiles - 1) // tiles, int(K) // 256))
+    return int(split_k)
+
+
 def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None,
          alpha=1.0, beta=0.0, bias=None, a_scale=None, a_scale_period=0, c_scale=None,
          c_scale_period=0, split_k=0, a_off=0, b_off=0, c_off=0, ws_name='gemm',
@@ -76,17 +84,48 @@ def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ld
     a.c_scale = c_scale.data_ptr() if c_scale is not None else None
     a.c_scale_period = int(c_scale_period)
     a.c_scale_ld = int(c_scale.shape[-1]) if c_scale is not None else 0
-    if split_k == 'auto':
-        # long-K / small-output GEMMs (dW, dU): split K until ~1024 workgroups exist
-        tiles = ((int(M) + 127) // 128) * ((int(N) + 127) // 128)
-        split_k = max(1, min(64, (1024 + tiles - 1) // tiles, int(K) // 256))
-    a.split_k = int(split_k)
+    a.split_k = _resolve_split(split_k, M, N, K)
     a.precision = int(precision)
     a.a_absmax = a_absmax.data_ptr() if a_absmax is not None else None
     a.b_absmax = b_absmax.data_ptr() if b_absmax is not None else None
     nbytes = lib.asr_gemm_workspace_bytes(C.byref(a))
     ws = WS.get(ws_name, nbytes, Cm.device) if nbytes else None
     L.check(lib.asr_gemm(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_gemm')
+
+
+_GATE_ROLES = {'fwd': 0, 'dgrad': 1, 'wgrad': 2}
+
+
+def gate_gemm(role, rows, n_pad, in_dim, gate_dim, W, w_off, ldw, ldz, x=None, x_off=0,
+              ldx=None, bias=None, mask_w=None, zx=None, dz=None, z_off=0, dz_absmax=None,
+              dx=None, dx_off=0, dx_beta=0.0, dW=None, dw_off=0, db=None, split_k=0,
+              precision=-1, ws_name='gemm'):
+    """One of the three GEMMs of an LSTM layer's input projection (asr_gemm_gate_fwd /
+    _dgrad / _wgrad, include/asr_hip.h): tensors are raw float32 storage, *_off element
+    offsets into them (x_off into x, z_off into zx or dz, w_off into W, dw_off into dW)."""
+    lib = L.load()
+    g = L.GateGemmArgs()
+    g.rows, g.n_pad, g.in_dim, g.gate_dim = int(rows), int(n_pad), int(in_dim), int(gate_dim)
+    g.x = None if x is None else x.data_ptr() + 4 * int(x_off)
+    g.ldx = int(ldx if ldx is not None else in_dim)
+    g.W = W.data_ptr() + 4 * int(w_off)
+    g.ldw, g.ldz = int(ldw), int(ldz)
+    g.bias = None if bias is None else bias.data_ptr()
+    g.mask_w = None if mask_w is None else mask_w.data_ptr()
+    g.zx = None if zx is None else zx.data_ptr() + 4 * int(z_off)
+    g.dz = None if dz is None else dz.data_ptr() + 4 * int(z_off)
+    g.dz_absmax = None if dz_absmax is None else dz_absmax.data_ptr()
+    g.dx = None if dx is None else dx.data_ptr() + 4 * int(dx_off)
+    g.dx_beta = float(dx_beta)
+    g.dW = None if dW is None else dW.data_ptr() + 4 * int(dw_off)
+    g.db = None if db is None else db.data_ptr()
+    g.split_k = _resolve_split(split_k, in_dim, gate_dim, rows)
+    g.precision = int(precision)
+    kind = _GATE_ROLES[role]
+    nbytes = lib.asr_gemm_gate_workspace_bytes(C.byref(g), kind)
+    ws = WS.get(ws_name, nbytes, W.device) if nbytes else None
+    fn = (lib.asr_gemm_gate_fwd, lib.asr_gemm_gate_dgrad, lib.asr_gemm_gate_wgrad)[kind]
+    L.check(fn(C.byref(g), _ptr(ws), nbytes, _stream()), 'asr_gemm_gate_' + role)
 
 
 def absmax(x, out=None):
@@ -217,11 +256,11 @@ def ctc_beam_search_host(logits_host, seq_len_host, N, beam_width=100, merge_rep
     dec = np.empty((int(N), T), dtype=np.int32)
     dlen = np.empty(int(N), dtype=np.int32)
     score = np.empty(int(N), dtype=np.float32)
-    L.check(lib.asr_ctc_beam_search_host(
+    L.check(lib.asr_ctc_beam(
         logits_host.ctypes.data_as(C.c_void_p), seq.ctypes.data_as(C.c_void_p), T, int(N),
         n_pad, Cc, int(beam_width), int(bool(merge_repeated)),
         dec.ctypes.data_as(C.c_void_p), dlen.ctypes.data_as(C.c_void_p),
-        score.ctypes.data_as(C.c_void_p)), 'asr_ctc_beam_search_host')
+        score.ctypes.data_as(C.c_void_p)), 'asr_ctc_beam')
     return [dec[n, :dlen[n]].tolist() for n in range(int(N))], score
 
 
@@ -242,10 +281,10 @@ def edit_distance_host(hyps, truths):
     h, hl, hld = pack(hyps)
     t, tl, tld = pack(truths)
     out = np.empty(N, np.float32)
-    L.check(lib.asr_edit_distance_host(
+    L.check(lib.asr_edit_distance(
         h.ctypes.data_as(C.c_void_p), hl.ctypes.data_as(C.c_void_p), hld,
         t.ctypes.data_as(C.c_void_p), tl.ctypes.data_as(C.c_void_p), tld, N,
-        out.ctypes.data_as(C.c_void_p)), 'asr_edit_distance_host')
+        out.ctypes.data_as(C.c_void_p)), 'asr_edit_distance')
     return out
 
 
@@ -276,6 +315,29 @@ def adam_step(params, grads, m, v, segs, n_seg, norm, clipnorm, lr, step, beta1=
                                    _stream()), 'asr_adam_step')
 
 
+def clip_adam_step(params, grads, m, v, segs, n_seg, norm_out, clipnorm, lr, step, beta1=0.9,
+                   beta2=0.999, eps=1e-8):
+    """Global norm (-> norm_out, two float64) + clipped Adam update in one library call."""
+    lib = L.load()
+    n = params.numel()
+    nbytes = lib.asr_optim_workspace_bytes(n)
+    ws = WS.get('optim', nbytes, params.device)
+    L.check(lib.asr_clip_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), n, _ptr(segs),
+                                   n_seg, _ptr(norm_out), float(clipnorm), float(lr),
+                                   float(beta1), float(beta2), float(eps), int(step), _ptr(ws),
+                                   nbytes, _stream()), 'asr_clip_adam_step')
+
+
+def clip_sgd_step(params, grads, vel, segs, n_seg, norm_out, clipnorm, lr, momentum=0.9):
+    lib = L.load()
+    n = params.numel()
+    nbytes = lib.asr_optim_workspace_bytes(n)
+    ws = WS.get('optim', nbytes, params.device)
+    L.check(lib.asr_clip_sgd_step(_ptr(params), _ptr(grads), _ptr(vel), n, _ptr(segs), n_seg,
+                                  _ptr(norm_out), float(clipnorm), float(lr), float(momentum),
+                                  _ptr(ws), nbytes, _stream()), 'asr_clip_sgd_step')
+
+
 def sgd_step(params, grads, vel, segs, n_seg, norm, clipnorm, lr, momentum=0.9):
     L.check(L.load().asr_sgd_step(_ptr(params), _ptr(grads), _ptr(vel), params.numel(),
                                   _ptr(segs), n_seg, _ptr(norm), float(clipnorm), float(lr),
@@ -298,11 +360,14 @@ def frontend_features(cfg, audio, offsets, lengths, host_lengths, n_pad, tables,
     ws = WS.get('frontend', nbytes, audio.device)
     out = torch.empty((int(t_out), int(n_pad), f_out), dtype=torch.float32, device=audio.device)
     frames = torch.empty(n_utt, dtype=torch.int32, device=audio.device)
-    L.check(lib.asr_frontend_features(
-        C.byref(cfg), _ptr(audio), _ptr(offsets), _ptr(lengths), hl, n_utt, int(n_pad),
-        _ptr(tables['window']), _ptr(tables['mel']), _ptr(tables['mel_range']),
-        _ptr(tables.get('dct')), _ptr(out), int(t_out), _ptr(frames), _ptr(ws), nbytes,
-        _stream()), 'asr_frontend_features')
+    head = (C.byref(cfg), _ptr(audio), _ptr(offsets), _ptr(lengths), hl, n_utt, int(n_pad),
+            _ptr(tables['window']), _ptr(tables['mel']), _ptr(tables['mel_range']))
+    tail = (_ptr(out), int(t_out), _ptr(frames), _ptr(ws), nbytes, _stream())
+    if cfg.kind == 0:
+        L.check(lib.asr_frontend_mfcc_batch(*(head + (_ptr(tables['dct']),) + tail)),
+                'asr_frontend_mfcc_batch')
+    else:
+        L.check(lib.asr_frontend_logfbank_batch(*(head + tail)), 'asr_frontend_logfbank_batch')
     return out, frames
 
 

@@ -338,6 +338,88 @@ int asr_comm_destroy(asr_comm_t comm);
 int asr_axpby(int64_t n, float a, const float* x, float b, const float* y, float* out,
               asr_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* Operation-level entry points: one per role on the training path, expressed */
+/* on the general entry points above (csrc/roles.cpp; no further kernels).    */
+/* ------------------------------------------------------------------------ */
+/* K1-K3 by feature class: preprocessing/audio.py:309-367 (MFCC; cfg->kind    */
+/* must be 0) and :394-442 (LogFbank; cfg->kind must be 1, no DCT table).     */
+/* Arguments as asr_frontend_features.                                        */
+int asr_frontend_mfcc_batch(const asr_frontend_cfg* cfg, const float* audio,
+                            const int* offsets, const int* lengths,
+                            const int* host_lengths, int n_utt, int n_pad,
+                            const float* window, const float* mel,
+                            const int* mel_range, const float* dct, float* out,
+                            int t_out, int* out_frames, void* workspace,
+                            size_t ws_bytes, asr_stream_t stream);
+int asr_frontend_logfbank_batch(const asr_frontend_cfg* cfg, const float* audio,
+                                const int* offsets, const int* lengths,
+                                const int* host_lengths, int n_utt, int n_pad,
+                                const float* window, const float* mel,
+                                const int* mel_range, float* out, int t_out,
+                                int* out_frames, void* workspace, size_t ws_bytes,
+                                asr_stream_t stream);
+
+/* K4/K6 the three GEMMs of one LSTM layer's input projection                 */
+/* (core/layers.py:439, K.dot(x * B_W[0], self.W), hoisted out of the time    */
+/* loop) over `rows` slab rows (whole frames of n_pad samples when a mask is  */
+/* given; mask row = slab row % n_pad):                                       */
+/*   fwd  : zx = (x (.) B_W) @ W + bias                                       */
+/*   dgrad: dx = dx_beta * dx + (dz @ W^T) (.) B_W                            */
+/*   wgrad: dW = (x (.) B_W)^T @ dz ;  db = column sums of dz (if db != NULL) */
+/* gate_dim is the number of gate columns this call covers (4H for one        */
+/* direction -- each direction of a Bidirectional layer has its own B_W --    */
+/* or 8H for both when mask_w is NULL); ldw / ldz are the row strides of W /  */
+/* dW and of zx / dz (8H in the engine's fused two-direction layout).         */
+typedef struct asr_gate_gemm_args {
+  int rows, n_pad, in_dim, gate_dim;
+  const float* x;  int ldx;   /* (rows, in_dim)                               */
+  const float* W;  int ldw;   /* (in_dim, gate_dim)                           */
+  const float* bias;          /* (gate_dim) or NULL (fwd)                     */
+  const float* mask_w;        /* (n_pad, in_dim) variational mask or NULL     */
+  float* zx;       int ldz;   /* fwd out (rows, gate_dim)                     */
+  const float* dz;            /* dgrad / wgrad in, row stride ldz             */
+  const float* dz_absmax;     /* device max|dz| (split-fp16 pre-scale) / NULL */
+  float* dx;                  /* dgrad out (rows, in_dim), row stride ldx     */
+  float dx_beta;              /* 0, or 1 to add the second direction's term   */
+  float* dW;                  /* wgrad out (in_dim, gate_dim), row stride ldw */
+  float* db;                  /* wgrad out (gate_dim) or NULL                 */
+  int split_k;                /* wgrad: split the long `rows` reduction       */
+  int precision;              /* as asr_gemm_args.precision (-1 = default)    */
+} asr_gate_gemm_args;
+/* role: 0 = fwd, 1 = dgrad, 2 = wgrad. */
+size_t asr_gemm_gate_workspace_bytes(const asr_gate_gemm_args* g, int role);
+int asr_gemm_gate_fwd(const asr_gate_gemm_args* g, void* workspace, size_t ws_bytes,
+                      asr_stream_t stream);
+int asr_gemm_gate_dgrad(const asr_gate_gemm_args* g, void* workspace, size_t ws_bytes,
+                        asr_stream_t stream);
+int asr_gemm_gate_wgrad(const asr_gate_gemm_args* g, void* workspace, size_t ws_bytes,
+                        asr_stream_t stream);
+
+/* K9 / K10 under their operation names (same arguments as the *_host forms).  */
+int asr_ctc_beam(const float* logits_host, const int* seq_len_host, int T, int N,
+                 int n_pad, int C, int beam_width, int merge_repeated, int* decoded,
+                 int* decoded_len, float* log_score);
+int asr_edit_distance(const int* hyp, const int* hyp_len, int hyp_ld,
+                      const int* truth, const int* truth_len, int truth_ld, int N,
+                      float* out_normalized);
+
+/* K11 one call per optimiser step: global gradient norm (written to norm_out  */
+/* as asr_grad_norm does) followed by the clipped Adam / SGD update, both      */
+/* enqueued on `stream`; workspace from asr_optim_workspace_bytes(n).          */
+int asr_clip_adam_step(float* params, const float* grads, float* m, float* v,
+                       int64_t n, const asr_segment* segments_dev, int n_seg,
+                       double* norm_out, float clipnorm, float lr, float beta1,
+                       float beta2, float eps, int step, void* workspace,
+                       size_t ws_bytes, asr_stream_t stream);
+int asr_clip_sgd_step(float* params, const float* grads, float* vel, int64_t n,
+                      const asr_segment* segments_dev, int n_seg, double* norm_out,
+                      float clipnorm, float lr, float momentum, void* workspace,
+                      size_t ws_bytes, asr_stream_t stream);
+
+/* C1 asr_comm_allreduce_sum under the name the scope table uses.             */
+int asr_comm_allreduce(asr_comm_t comm, float* buf, int64_t n, asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

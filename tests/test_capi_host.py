@@ -131,6 +131,8 @@ int main(void) {
   printf("segment %zu %zu\\n", sizeof(asr_segment), offsetof(asr_segment, l2));
   printf("lstmln %zu %zu %zu\\n", sizeof(asr_lstm_ln_args), offsetof(asr_lstm_ln_args, cellp),
          offsetof(asr_lstm_ln_args, dparams));
+  printf("gate %zu %zu %zu %zu\\n", sizeof(asr_gate_gemm_args), offsetof(asr_gate_gemm_args, zx),
+         offsetof(asr_gate_gemm_args, dx_beta), offsetof(asr_gate_gemm_args, precision));
   return 0;
 }
 ''')
@@ -145,3 +147,5 @@ int main(void) {
     assert out['segment'] == [C.sizeof(S), S.l2.offset]
     LN = _lib.LstmLnArgs
     assert out['lstmln'] == [C.sizeof(LN), LN.cellp.offset, LN.dparams.offset]
+    GG = _lib.GateGemmArgs
+    assert out['gate'] == [C.sizeof(GG), GG.zx.offset, GG.dx_beta.offset, GG.precision.offset]

@@ -116,3 +116,43 @@ def test_absmax():
     x = torch.randn(1000003, device='cuda:0') * 1e-4
     x[77777] = -0.5
     assert abs(float(ops.absmax(x[:1000000].contiguous())) - 0.5) < 1e-7
+
+
+@pytest.mark.parametrize('masked', [False, True])
+def test_gate_projection_roles(masked):
+    """asr_gemm_gate_fwd / _dgrad / _wgrad (one direction's block of a fused two-direction
+    layout: ldw = ldz = 2 * gate_dim) against float64 NumPy."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(7 + masked)
+    T, n_pad, F, G = 11, 16, 40, 48          # gate_dim G = 4H of one direction
+    rows = T * n_pad
+    x = rs.randn(rows, F)
+    W = rs.randn(F, 2 * G) * 0.3
+    b = rs.randn(2 * G)
+    dz = rs.randn(rows, 2 * G)
+    mask = (rs.rand(n_pad, F) > 0.3) / 0.7 if masked else None
+    mrows = np.tile(mask, (T, 1)) if masked else 1.0
+    xd, Wd, bd, dzd = [to_dev(a.astype(np.float32)) for a in (x, W, b, dz)]
+    md = to_dev(mask.astype(np.float32)) if masked else None
+    for d in range(2):
+        cols = slice(d * G, (d + 1) * G)
+        zx = torch.zeros((rows, 2 * G), dtype=torch.float32, device='cuda:0')
+        ops.gate_gemm('fwd', rows, n_pad, F, G, Wd, d * G, 2 * G, 2 * G, x=xd, bias=bd[cols],
+                      mask_w=md, zx=zx, z_off=d * G)
+        torch.cuda.synchronize()
+        got = zx.cpu().numpy()
+        assert np.abs(got[:, cols] - ((x * mrows) @ W[:, cols] + b[cols])).max() < 2e-4
+        assert not got[:, (1 - d) * G:(2 - d) * G].any()      # the other direction untouched
+        dx = to_dev(np.ones((rows, F), np.float32))
+        ops.gate_gemm('dgrad', rows, n_pad, F, G, Wd, d * G, 2 * G, 2 * G, mask_w=md, dz=dzd,
+                      z_off=d * G, dx=dx, dx_beta=1.0)
+        torch.cuda.synchronize()
+        want = 1.0 + (dz[:, cols] @ W[:, cols].T) * mrows
+        assert np.abs(dx.cpu().numpy() - want).max() < 2e-4
+        dW = torch.zeros((F, 2 * G), dtype=torch.float32, device='cuda:0')
+        db = torch.zeros(G, dtype=torch.float32, device='cuda:0')
+        ops.gate_gemm('wgrad', rows, n_pad, F, G, Wd, d * G, 2 * G, 2 * G, x=xd, mask_w=md,
+                      dz=dzd, z_off=d * G, dW=dW, dw_off=d * G, db=db, split_k=3)
+        torch.cuda.synchronize()
+        assert np.abs(dW.cpu().numpy()[:, cols] - (x * mrows).T @ dz[:, cols]).max() < 1e-3
+        assert np.abs(db.cpu().numpy() - dz[:, cols].sum(0)).max() < 1e-4

@@ -33,12 +33,17 @@ def test_adam_and_sgd(clip):
             want_pen = np.sum(l2vec * p_ref[0] ** 2)
             opt.step(p_ref, [g_tot])
             gd = to_dev(g)
+            # the one-call form (asr_clip_*_step) on a copy must equal norm + step exactly
+            p2, m2, v2, norm2 = p.clone(), m.clone(), v.clone(), torch.zeros_like(norm)
             ops.grad_norm(p, gd, segs, nseg, norm)
             if kind == 'adam':
                 ops.adam_step(p, gd, m, v, segs, nseg, norm, clip, 1e-2, step)
+                ops.clip_adam_step(p2, gd, m2, v2, segs, nseg, norm2, clip, 1e-2, step)
             else:
                 ops.sgd_step(p, gd, m, segs, nseg, norm, clip, 1e-2, 0.9)
+                ops.clip_sgd_step(p2, gd, m2, segs, nseg, norm2, clip, 1e-2, 0.9)
             torch.cuda.synchronize()
+            assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(norm, norm2)
             nh = norm.cpu().numpy()
             assert abs(nh[0] - want_norm) < 1e-5 * want_norm
             assert abs(nh[1] - want_pen) < 1e-5 * max(1.0, want_pen)
