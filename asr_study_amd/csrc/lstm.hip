@@ -56,6 +56,7 @@
 //  * mode 1 launches one step per kernel (same buffer, visibility from the kernel
 //    boundary, no polling): the always-safe fallback with identical arithmetic.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -821,6 +822,236 @@ lstm_fwd_kernel_k(LstmParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// forward, split-fp16, K split over the waves, TWO batch tiles per workgroup (opt-in,
+// ASR_LSTM_PAIR=1).  The two 16-sample tiles (2q, 2q+1) of a direction multiply with the
+// same U slice, so one workgroup can serve both chains with the same stationary operand
+// registers and alternate between them: while tile A's published h travels to its
+// consumers, the workgroup computes tile B, and the gather loads of a tile are issued
+// in the middle of the OTHER tile's phase (PLACE: 0 = before its MFMAs, 3 = after them,
+// 1 = after its partial-tile barrier, 2 = at its very end, i.e. no overlap -- the control).  The chain
+// protocol (tags, parity slots, one exchange buffer per chain) is that of fwd_body_k.
+template <int NKW, bool FAST, int PLACE>
+__device__ __forceinline__ void fwd_body_k2(const LstmParams& p, int pair, int wg, float* lds) {
+  // Requires H == 128 * NKW (every lane's gather groups and units exist): the steady loop
+  // below has NO branch around a vector-memory instruction, so the compiler can count the
+  // younger operations exactly and a tile's gather is awaited with s_waitcnt vmcnt(N > 0)
+  // while the other tile's slab stores are still in flight.
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, nl = lane & 15;
+  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
+  const int UG = H >> 2;
+  const int NBH = p.NB >> 1;
+  const int dir = pair / NBH, q = pair % NBH;
+  const int ug = wg * 4 + w;                       // the unit group this wave FINISHES
+  const int u = 4 * ug + g;
+  const int kbase = 32 * NKW * w;                  // first unit of this wave's K slice
+  f32x4* part = reinterpret_cast<f32x4*>(lds);     // [2 tiles][4 waves][4 gate tiles][64 lanes]
+
+  h8 ufh[4][NKW], ufl[4][NKW];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ugj = wg * 4 + j;
+#pragma unroll
+    for (int kk = 0; kk < NKW; ++kk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = kbase + 32 * kk + 8 * g + e;
+        const float x = p.U[((size_t)(dir * H + k)) * H4 + 16 * ugj + nl];
+        _Float16 hi, lo;
+        split_f16(x, hi, lo);
+        ufh[j][kk][e] = hi; ufl[j][kk][e] = lo;
+      }
+    }
+  }
+  const int slot_words = UG * (p.xstride / 4);
+  const int s_end = p.s_begin + p.s_count;
+  int n[2];
+  float mask[2], c[2];
+  unsigned* xch[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int bt = 2 * q + x;
+    n[x] = bt * 16 + nl;
+    mask[x] = p.mask_u ? p.mask_u[((size_t)dir * p.n_pad + n[x]) * H + u] : 1.f;
+    c[x] = 0.f;
+    xch[x] = p.xbuf + (size_t)(dir * p.NB + bt) * p.xchain_words;
+    if (p.s_begin > 0) {
+      const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
+      c[x] = p.cell[(((size_t)tpp * p.n_pad + n[x]) * 2 + dir) * H + u];
+    }
+  }
+  auto load_zx = [&](int x, int ss) -> float4 {
+    const int sc = ss < s_end ? ss : s_end - 1;    // past the end: a valid, unused row
+    const int tt = dir == 0 ? sc : p.T - 1 - sc;
+    return *reinterpret_cast<const float4*>(
+        p.zx + (((size_t)tt * p.n_pad + n[x]) * 2 + dir) * H4 + 4 * u);
+  };
+  float4 zx_next[2] = {load_zx(0, p.s_begin), load_zx(1, p.s_begin)};
+  constexpr int NL = 2 * NKW;
+  unsigned off[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+    off[i] = (unsigned)(((kbase + 32 * (i >> 1) + 8 * g) / 4 + (i & 1)) * p.xstride + nl * 16);
+  bool dead = false;
+  u32x4 v[2][NL];
+  // the exchange slot holding h of step `ss` of tile x
+  auto slot = [&](int x, int ss) -> __amdgpu_buffer_rsrc_t {
+    return __builtin_amdgcn_make_buffer_rsrc(xch[x] + (size_t)(ss & 1) * slot_words, 0,
+                                             slot_words * 4, 0x00020000);
+  };
+  auto issue = [&](int x, int ss) {
+    for (int i = 0; i < p.prepoll; ++i) __builtin_amdgcn_s_sleep(1);
+    const __amdgpu_buffer_rsrc_t rsrc = slot(x, ss);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) v[x][i] = xload<FAST>(rsrc, off[i]);
+  };
+  auto all_fresh = [&](int x, unsigned tag) -> bool {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) ok = ok && tags_ok(v[x][i], tag);
+    return ok;
+  };
+  // rare path: some word of the gather was stale -- poll until every word carries the tag
+  auto repoll = [&](int x, int ss, unsigned tag) {
+    const __amdgpu_buffer_rsrc_t rsrc = slot(x, ss);
+    const long long t0 = wall_clock64();
+    while (!dead) {
+      for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        if (!tags_ok(v[x][i], tag)) v[x][i] = xload<FAST>(rsrc, off[i]);
+      if (all_fresh(x, tag)) return;
+      if (wall_clock64() - t0 > kSpinTicks) {
+        dead = true;
+        atomicExch(p.status, 1);
+      }
+    }
+  };
+  // cell update of tile x at step s from the recurrent contribution `a`; publishes h
+  auto finish_step = [&](int x, int s, const f32x4& a, const float4& zx4) {
+    const int t = dir == 0 ? s : p.T - 1 - s;
+    const float gi = hard_sigmoid(a[0] + zx4.x);
+    const float gf = hard_sigmoid(a[1] + zx4.y);
+    const float gg = fast_tanh(a[2] + zx4.z);
+    const float go = hard_sigmoid(a[3] + zx4.w);
+    c[x] = gf * c[x] + gi * gg;
+    const float h = go * fast_tanh(c[x]);
+    const unsigned wtag = (unsigned)(s >> 1) & 1u;
+    _Float16 ph, pl;
+    split_f16(h * mask[x], ph, pl);
+    const unsigned w0 = ((((unsigned)__builtin_bit_cast(unsigned short, ph) << 16) |
+                          (unsigned)__builtin_bit_cast(unsigned short, pl)) & ~1u) | wtag;
+    // (the last step's word is published too: nobody reads it, and no branch is needed)
+    __builtin_amdgcn_raw_buffer_store_b32(w0, slot(x, s),
+                                          (unsigned)(ug * p.xstride + nl * 16 + g * 4), 0,
+                                          FAST ? 0 : kSc1);
+    const size_t row = (size_t)t * p.n_pad + n[x];
+    p.y[row * H2 + dir * H + u] = h;
+    p.cell[(row * 2 + dir) * H + u] = c[x];
+    *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
+        make_float4(gi, gf, gg, go);
+  };
+
+  int s = p.s_begin;
+  if (s == 0) {
+    // step 0 of both tiles: h_prev = 0, nothing to gather
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const float4 zx4 = zx_next[x];
+      zx_next[x] = load_zx(x, 1);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      finish_step(x, 0, zero, zx4);
+    }
+    s = 1;
+  }
+  // one phase = one step of tile X.  The gather issued during the phase is the OTHER
+  // tile's next input: phase 0 -> tile 1, h of step s-1 (consumed later in this iteration);
+  // phase 1 -> tile 0, h of step s (consumed by the next iteration; after the last one it
+  // is a harmless unused read).
+  auto phase = [&](auto xc, int s) {
+    constexpr int x = decltype(xc)::value;
+    constexpr int ox = 1 - x;
+    const int os = x == 0 ? s - 1 : s;
+    const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
+    const float4 zx4 = zx_next[x];
+    if (!all_fresh(x, tag)) repoll(x, s - 1, tag);
+    zx_next[x] = load_zx(x, s + 1);
+    h8 bh[NKW], bl[NKW];
+#pragma unroll
+    for (int kk = 0; kk < NKW; ++kk) {
+      u32x4 q0 = v[x][2 * kk], q1 = v[x][2 * kk + 1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        q0[e] &= ~1u;
+        q1[e] &= ~1u;
+      }
+      u32x4 hi, lo;
+      hi[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x07060302u);
+      hi[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x07060302u);
+      hi[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x07060302u);
+      hi[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x07060302u);
+      lo[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x05040100u);
+      lo[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x05040100u);
+      lo[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x05040100u);
+      lo[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x05040100u);
+      bh[kk] = __builtin_bit_cast(h8, hi);
+      bl[kk] = __builtin_bit_cast(h8, lo);
+    }
+    if (PLACE == 0) issue(ox, os);
+    // one LDS buffer per tile: a wave that writes tile x again has passed the other
+    // tile's barrier, which every wave reaches only after its reads of this buffer
+    f32x4* mine = part + ((size_t)x * 4 + w) * 4 * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac0 = am, ac1 = am;
+#pragma unroll
+      for (int kk = 0; kk < NKW; ++kk) {
+        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[j][kk], bh[kk], am, 0, 0, 0);
+        ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[j][kk], bl[kk], ac0, 0, 0, 0);
+        ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[j][kk], bh[kk], ac1, 0, 0, 0);
+      }
+      mine[j * 64 + lane] = am + (ac0 + ac1) * (1.f / kLoScale);
+    }
+    if (PLACE == 3) issue(ox, os);
+    __syncthreads();
+    const f32x4* all = part + (size_t)x * 4 * 4 * 64 + (size_t)w * 64 + lane;
+    const f32x4 a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
+    if (PLACE == 1) issue(ox, os);
+    finish_step(x, s, a, zx4);
+    if (PLACE == 2) issue(ox, os);
+  };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  // The first phase is peeled so that EVERY gather the loop waits for was issued by the
+  // same code sequence (followed by the same four stores): the compiler then awaits it
+  // with an exact s_waitcnt vmcnt(N) instead of a conservative vmcnt(0) that would also
+  // wait for the other tile's stores to be acknowledged.
+  if (s < s_end) {
+    issue(0, s - 1);
+    phase(T0{}, s);
+    for (;;) {
+      phase(T1{}, s);
+      if (++s >= s_end) break;
+      phase(T0{}, s);
+    }
+  }
+}
+
+template <int NKW, int PLACE>
+__global__ void __launch_bounds__(kThreads)
+lstm_fwd_kernel_k2(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int pair_local, wg;
+  if (!map_block(p, pair_local, wg)) return;
+  const int pair = p.chain_begin + pair_local;
+  const bool fast = chain_on_one_xcd(p, pair, wg, reinterpret_cast<int*>(lds));
+  if (fast) fwd_body_k2<NKW, true, PLACE>(p, pair, wg, lds);
+  else fwd_body_k2<NKW, false, PLACE>(p, pair, wg, lds);
+}
+
+// ---------------------------------------------------------------------------
 // backward (BPTT).  WG `cw` of a chain owns units [16 cw, 16 cw + 16) = gate
 // columns j in [64 cw, 64 cw + 64).  TPW = output tiles (16 units) per wave.
 template <int TPW, bool FAST>
@@ -1321,6 +1552,7 @@ lstm_bwd_kernel_hv(LstmParams p) {
 // ---------------------------------------------------------------------------
 struct Plan {
   int R, P, TPW, MAXR, NKK, prec;
+  int pair;                // 1: a workgroup serves two batch tiles (lstm_fwd_kernel_k2)
   size_t shm;
   size_t xchain_words;
   int chains_per_launch;
@@ -1366,6 +1598,14 @@ kern_t pick_fwd_k(int nkk) {
     default: return lstm_fwd_kernel_k<4>;
   }
 }
+kern_t pick_fwd_k2(int nkk, int place) {
+  if (nkk <= 8) return place == 0 ? lstm_fwd_kernel_k2<2, 0>
+                     : place == 1 ? lstm_fwd_kernel_k2<2, 1>
+                     : place == 3 ? lstm_fwd_kernel_k2<2, 3> : lstm_fwd_kernel_k2<2, 2>;
+  return place == 0 ? lstm_fwd_kernel_k2<4, 0>
+       : place == 1 ? lstm_fwd_kernel_k2<4, 1>
+       : place == 3 ? lstm_fwd_kernel_k2<4, 3> : lstm_fwd_kernel_k2<4, 2>;
+}
 kern_t pick_bwd_h(int tpw) {
   switch (tpw) {
     case 1: return lstm_bwd_kernel_h<1>;
@@ -1409,6 +1649,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   // 0 = exact fp32 MFMA
   pl.prec = env_int("ASR_LSTM_PREC", 1) ? 1 : 0;
   pl.NKK = 0;
+  pl.pair = 0;
   if (!bwd) {
     pl.R = up4((H + 3) / 4);
     if (pl.R > 128) {
@@ -1432,6 +1673,12 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       if (!variants && env_int("ASR_LSTM_KSPLIT", pl.NKK >= 8 ? 1 : 0)) {
         pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
         k = pick_fwd_k(pl.NKK);
+        // two batch tiles per workgroup (opt-in): persistent mode, an even number of tiles
+        if (env_int("ASR_LSTM_PAIR", 0) && a->mode == 0 && (a->n_pad / 16) % 2 == 0 &&
+            (H == 256 || H == 512)) {
+          pl.pair = 1;
+          k = pick_fwd_k2(pl.NKK, env_int("ASR_LSTM_PAIR_PLACE", 1));
+        }
       }
     }
   } else {
@@ -1480,7 +1727,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     return ASR_ERR_RESIDENCY;
   }
   long cpl = cap / pl.P;
-  if (cpl > chains) cpl = chains;
+  if (cpl > chains) cpl = chains;      // (in pair mode: counted in pairs by run())
   pl.chains_per_launch = (int)cpl;
   *out = pl;
   if (kout) *kout = k;
@@ -1559,7 +1806,8 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
     ASR_CHECK_HIP(hipMemsetAsync(ws, 0, kStatusBytes + cb_, stream));
     ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes + cb_, 0xFF, xb, stream));
   }
-  const int chains = 2 * p.NB;
+  // launch units: chains, or pairs of chains when a workgroup serves two batch tiles
+  const int chains = pl.pair ? p.NB : 2 * p.NB;
   const bool stepwise = a->mode == 1;
   p.poll = stepwise ? 0 : 1;
   p.allow_fast = env_int("ASR_LSTM_FAST", 1);
@@ -1567,7 +1815,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   // measured optimum on MI355X (tools/sweep_poll.sh): forward 14-16 naps (~0.4 us),
   // BPTT 8 for chains of <= 16 workgroups and none for wider ones
   p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.P <= 16 ? 8 : 0)
-                  : env_int("ASR_LSTM_PREPOLL_F", pl.P <= 16 ? 12 : 16);
+                  : env_int("ASR_LSTM_PREPOLL_F", pl.pair ? 0 : pl.P <= 16 ? 12 : 16);
   p.repoll = bwd ? env_int("ASR_LSTM_REPOLL_B", 1) : env_int("ASR_LSTM_REPOLL_F", 1);
   p.xstride = fwd_xstride();
   const int steps_per_launch = stepwise ? 1 : (r_end - r_begin);

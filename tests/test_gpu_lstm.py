@@ -132,6 +132,43 @@ def test_step_ranges_continue_one_sequence(T, N, H, cuts):
     assert np.abs(whole[3]).max() == whole[4][0]
 
 
+@pytest.mark.parametrize('N,H,place', [(32, 256, 0), (32, 256, 1), (32, 256, 2), (32, 256, 3), (64, 512, 1),
+                                       (20, 256, 1)])
+def test_paired_forward_kernel_matches_the_default_one(N, H, place, monkeypatch):
+    """ASR_LSTM_PAIR=1 (lstm_fwd_kernel_k2: one workgroup alternates between the two batch
+    tiles of a direction, gathers prefetched during the other tile's phase) performs the same
+    arithmetic as the default forward kernel (same products and summation order; the
+    compiler contracts the cell update differently, so 1 ulp per step may differ): equal to
+    1e-5, and sliced == whole bit for bit; with a recurrent-dropout mask."""
+    from asr_study_amd import ops
+    T = 61
+    rs = np.random.RandomState(H + N + place)
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
+    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
+
+    def run(ranges):
+        y = torch.zeros(T, n_pad, 2 * H, device=dev)
+        cell = torch.zeros(T, n_pad, 2, H, device=dev)
+        gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+        for r in ranges:
+            ws = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask, steps=r)
+        ops.lstm_status(ws)
+        return [t.cpu().numpy() for t in (y, cell, gates)]
+    monkeypatch.setenv('ASR_LSTM_PAIR', '0')
+    want = run([None])
+    monkeypatch.setenv('ASR_LSTM_PAIR', '1')
+    monkeypatch.setenv('ASR_LSTM_PAIR_PLACE', str(place))
+    whole = run([None])
+    for name, a, b in zip(('y', 'cell', 'gates'), want, whole):
+        assert np.abs(a - b).max() < 1e-5, name
+    sliced = run([(0, 17), (17, 30), (47, 14)])
+    for name, a, b in zip(('y', 'cell', 'gates'), whole, sliced):
+        assert np.array_equal(a, b), name
+
+
 @pytest.mark.parametrize('T,N,H,use_mi,use_zone', [
     (23, 5, 16, True, False),
     (23, 5, 16, False, True),
