@@ -646,6 +646,52 @@ lstm_fwd_kernel_hv(LstmParams p) {
   else fwd_body_h<NKK, false, true>(p, chain, wg, lds);
 }
 
+// ---- arithmetic shared by the K-split forward kernels (fwd_body_k / fwd_body_k2), written
+// with contraction off and explicit FMAs so that both round identically: which of the two
+// processed a batch row is then invisible in the result, bit for bit.
+__device__ __forceinline__ f32x4 combine_split(const f32x4& am, const f32x4& ac0,
+                                               const f32x4& ac1) {
+#pragma clang fp contract(off)
+  const f32x4 t = ac0 + ac1;
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(t[e], 1.f / kLoScale, am[e]);
+  return r;
+}
+__device__ __forceinline__ float hard_sigmoid_nc(float x) {
+#pragma clang fp contract(off)
+  return fminf(fmaxf(__builtin_fmaf(0.2f, x, 0.5f), 0.f), 1.f);
+}
+__device__ __forceinline__ float tanh_nc(float x) {
+#pragma clang fp contract(off)
+  const float xc = fminf(fmaxf(x, -15.f), 15.f);
+  const float e = __expf(2.f * xc);
+  return __fdividef(e - 1.f, e + 1.f);
+}
+struct CellFwd { float gi, gf, gg, go, c, h, hm; };
+// a: recurrent contribution h_prev @ U of the four gates; zx4: x @ W + b; hm = h * mask is
+// what the next step multiplies with U
+__device__ __forceinline__ CellFwd cell_forward(const f32x4& a, const float4& zx4, float c_prev,
+                                                float mask) {
+#pragma clang fp contract(off)
+  CellFwd o;
+  o.gi = hard_sigmoid_nc(a[0] + zx4.x);
+  o.gf = hard_sigmoid_nc(a[1] + zx4.y);
+  o.gg = tanh_nc(a[2] + zx4.z);
+  o.go = hard_sigmoid_nc(a[3] + zx4.w);
+  o.c = __builtin_fmaf(o.gf, c_prev, o.gi * o.gg);
+  o.h = o.go * tanh_nc(o.c);
+  o.hm = o.h * mask;
+  return o;
+}
+// exchanged word: fp16 hi << 16 | fp16 lo with the step tag in the LSB
+__device__ __forceinline__ unsigned packed_word(float hm, unsigned tag) {
+  _Float16 ph, pl;
+  split_f16(hm, ph, pl);
+  return ((((unsigned)__builtin_bit_cast(unsigned short, ph) << 16) |
+           (unsigned)__builtin_bit_cast(unsigned short, pl)) & ~1u) | tag;
+}
+
 // forward, split-fp16, K split over the waves.  Wave w multiplies ALL 64 gate columns
 // of the workgroup (4 tiles of 16) with ITS quarter of h (32*NKW units): its MFMA
 // B-operand comes straight from its own gather (registers; no LDS staging of h, and a
@@ -762,7 +808,7 @@ __device__ __forceinline__ void fwd_body_k(const LstmParams& p, int chain, int w
           ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[j][kk], bl[kk], ac0, 0, 0, 0);
           ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[j][kk], bh[kk], ac1, 0, 0, 0);
         }
-        mine[j * 64 + lane] = am + (ac0 + ac1) * (1.f / kLoScale);
+        mine[j * 64 + lane] = combine_split(am, ac0, ac1);
       }
       __syncthreads();
       if (prof) tk2 = wall_clock64();
@@ -773,18 +819,10 @@ __device__ __forceinline__ void fwd_body_k(const LstmParams& p, int chain, int w
     }
     if (prof) { asm volatile("" :: "v"(a[0])); tk3 = wall_clock64(); }
     if (ug_ok) {
-      const float gi = hard_sigmoid(a[0] + zx4.x);
-      const float gf = hard_sigmoid(a[1] + zx4.y);
-      const float gg = fast_tanh(a[2] + zx4.z);
-      const float go = hard_sigmoid(a[3] + zx4.w);
-      c = gf * c + gi * gg;
-      const float h = go * fast_tanh(c);
+      const CellFwd o = cell_forward(a, zx4, c, mask);
+      c = o.c;
       if (s + 1 < p.T) {
-        const unsigned wtag = (unsigned)(s >> 1) & 1u;
-        _Float16 ph, pl;
-        split_f16(h * mask, ph, pl);
-        const unsigned w0 = ((((unsigned)__builtin_bit_cast(unsigned short, ph) << 16) |
-                              (unsigned)__builtin_bit_cast(unsigned short, pl)) & ~1u) | wtag;
+        const unsigned w0 = packed_word(o.hm, (unsigned)(s >> 1) & 1u);
         // every lane stores its own word: [ug][sample][unit g] -- the four words of a
         // 16-byte group carry their own tags, so no cross-row shuffle is needed
         __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
@@ -793,10 +831,10 @@ __device__ __forceinline__ void fwd_body_k(const LstmParams& p, int chain, int w
                                               0, FAST ? 0 : kSc1);
       }
       const size_t row = (size_t)t * p.n_pad + n;
-      p.y[row * H2 + dir * H + u] = h;
+      p.y[row * H2 + dir * H + u] = o.h;
       p.cell[(row * 2 + dir) * H + u] = c;
       *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
-          make_float4(gi, gf, gg, go);
+          make_float4(o.gi, o.gf, o.gg, o.go);
     }
     if (prof && s > 0) {
       const long long tk4 = wall_clock64();
@@ -822,14 +860,16 @@ lstm_fwd_kernel_k(LstmParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// forward, split-fp16, K split over the waves, TWO batch tiles per workgroup (opt-in,
-// ASR_LSTM_PAIR=1).  The two 16-sample tiles (2q, 2q+1) of a direction multiply with the
-// same U slice, so one workgroup can serve both chains with the same stationary operand
-// registers and alternate between them: while tile A's published h travels to its
-// consumers, the workgroup computes tile B, and the gather loads of a tile are issued
-// in the middle of the OTHER tile's phase (PLACE: 0 = before its MFMAs, 3 = after them,
-// 1 = after its partial-tile barrier, 2 = at its very end, i.e. no overlap -- the control).  The chain
-// protocol (tags, parity slots, one exchange buffer per chain) is that of fwd_body_k.
+// forward, split-fp16, K split over the waves, TWO batch tiles per workgroup (default for
+// H = 256 / 512 and an even number of batch tiles; ASR_LSTM_PAIR=0 disables).  The two
+// 16-sample tiles (2q, 2q+1) of a direction multiply with the same U slice, so one
+// workgroup can serve both chains with the same stationary operand registers and
+// alternate between them: while tile A's published h travels to its consumers, the
+// workgroup computes tile B, and the gather loads of a tile are issued in the middle of
+// the OTHER tile's phase (PLACE: 0 = before its MFMAs, 3 = after them, 1 = after its
+// partial-tile barrier (default, measured best), 2 = at its very end, i.e. no overlap --
+// the control).  The chain protocol (tags, parity slots, one exchange buffer per chain)
+// is that of fwd_body_k; half as many CUs are occupied.
 template <int NKW, bool FAST, int PLACE>
 __device__ __forceinline__ void fwd_body_k2(const LstmParams& p, int pair, int wg, float* lds) {
   // Requires H == 128 * NKW (every lane's gather groups and units exist): the steady loop
@@ -932,17 +972,10 @@ __device__ __forceinline__ void fwd_body_k2(const LstmParams& p, int pair, int w
   // cell update of tile x at step s from the recurrent contribution `a`; publishes h
   auto finish_step = [&](int x, int s, const f32x4& a, const float4& zx4) {
     const int t = dir == 0 ? s : p.T - 1 - s;
-    const float gi = hard_sigmoid(a[0] + zx4.x);
-    const float gf = hard_sigmoid(a[1] + zx4.y);
-    const float gg = fast_tanh(a[2] + zx4.z);
-    const float go = hard_sigmoid(a[3] + zx4.w);
-    c[x] = gf * c[x] + gi * gg;
-    const float h = go * fast_tanh(c[x]);
-    const unsigned wtag = (unsigned)(s >> 1) & 1u;
-    _Float16 ph, pl;
-    split_f16(h * mask[x], ph, pl);
-    const unsigned w0 = ((((unsigned)__builtin_bit_cast(unsigned short, ph) << 16) |
-                          (unsigned)__builtin_bit_cast(unsigned short, pl)) & ~1u) | wtag;
+    const CellFwd o = cell_forward(a, zx4, c[x], mask[x]);
+    c[x] = o.c;
+    const float gi = o.gi, gf = o.gf, gg = o.gg, go = o.go, h = o.h;
+    const unsigned w0 = packed_word(o.hm, (unsigned)(s >> 1) & 1u);
     // (the last step's word is published too: nobody reads it, and no branch is needed)
     __builtin_amdgcn_raw_buffer_store_b32(w0, slot(x, s),
                                           (unsigned)(ug * p.xstride + nl * 16 + g * 4), 0,
@@ -1012,7 +1045,7 @@ __device__ __forceinline__ void fwd_body_k2(const LstmParams& p, int pair, int w
         ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[j][kk], bl[kk], ac0, 0, 0, 0);
         ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[j][kk], bh[kk], ac1, 0, 0, 0);
       }
-      mine[j * 64 + lane] = am + (ac0 + ac1) * (1.f / kLoScale);
+      mine[j * 64 + lane] = combine_split(am, ac0, ac1);
     }
     if (PLACE == 3) issue(ox, os);
     __syncthreads();
@@ -1673,8 +1706,9 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       if (!variants && env_int("ASR_LSTM_KSPLIT", pl.NKK >= 8 ? 1 : 0)) {
         pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
         k = pick_fwd_k(pl.NKK);
-        // two batch tiles per workgroup (opt-in): persistent mode, an even number of tiles
-        if (env_int("ASR_LSTM_PAIR", 0) && a->mode == 0 && (a->n_pad / 16) % 2 == 0 &&
+        // two batch tiles per workgroup (ASR_LSTM_PAIR=0 disables): persistent mode, an
+        // even number of tiles, every lane's gather groups and units present
+        if (env_int("ASR_LSTM_PAIR", 1) && a->mode == 0 && (a->n_pad / 16) % 2 == 0 &&
             (H == 256 || H == 512)) {
           pl.pair = 1;
           k = pick_fwd_k2(pl.NKK, env_int("ASR_LSTM_PAIR_PLACE", 1));
