@@ -260,7 +260,7 @@ def main():
         alg_bytes = {'fwd': 4 * slab_b + slab_b + slab_b + 4 * slab_b,
                      'bwd': slab_b + 4 * slab_b + slab_b + 4 * slab_b}
         # HBM traffic per LAYER from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE; per-launch
-        # average x launches per layer), profiles/r1g_bench_cfg2_hbm_traffic.md; cfg2 only
+        # average x launches per layer), profiles/r1i_bench_cfg2_hbm_traffic.md; cfg2 only
         pmc = {'cfg2': {'fwd': 647.6e6, 'bwd': 654.7e6}}.get(args.config, {})
 
         def roof(kind, times, kernel):
@@ -302,7 +302,7 @@ def main():
                        'parallelism': 'dp%d' % world, 'params': model.count_params()},
             'roofline': roof('bwd', bwd_t, 'lstm_bwd_kernel_h (persistent BPTT of one BiLSTM '
                                             'layer, both directions)'),
-            'roofline_lstm_fwd': roof('fwd', fwd_t, 'lstm_fwd_kernel_k (persistent forward '
+            'roofline_lstm_fwd': roof('fwd', fwd_t, 'lstm_fwd_kernel_k2 (persistent forward '
                                                      'recurrence of one BiLSTM layer)'),
         }
         line.update(extra)
