@@ -1583,6 +1583,264 @@ lstm_bwd_kernel_hv(LstmParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// backward, split-fp16, TWO batch tiles per workgroup (plain cell, H = 256 / 512, an even
+// number of batch tiles; ASR_LSTM_PAIR_B).  Same idea as fwd_body_k2: both tiles of a
+// direction multiply with the same U^T slice, the workgroup alternates between them and
+// issues a tile's gather during the other tile's phase (PLACE: 3 = before that phase's
+// barrier, 1 = after it, 2 = at its end, i.e. no overlap).  As there, the steady loop has no
+// branch around a vector-memory instruction so that the gather is awaited with an exact
+// s_waitcnt vmcnt(N).  Chain protocol and exchange layout are those of bwd_body_h.
+template <int TPW, bool FAST, int PLACE>
+__device__ __forceinline__ void bwd_body_h2(const LstmParams& p, int pair, int cw, float* lds) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, nl = lane & 15;
+  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
+  const int P = p.P;                               // == 4 * TPW here
+  const int NBH = p.NB >> 1;
+  const int dir = pair / NBH, q = pair % NBH;
+  constexpr int DZH = 72;                         // LDS row stride of the dz tiles (halfs)
+  constexpr int kTileFloats = 16 + (2 * 16 * DZH) / 2;        // sinv + hi + lo, in floats
+  // one dz tile per batch tile: a wave that rewrites tile x's buffer has passed the other
+  // tile's barrier, which every wave reaches only after its MFMA reads of this buffer
+
+  h8 ufh[TPW][2], ufl[TPW][2];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int krow = 16 * (w + 4 * i) + nl;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 64 * cw + 32 * kk + 8 * g + e;
+        _Float16 hi, lo;
+        split_f16(p.U[((size_t)(dir * H + krow)) * H4 + j], hi, lo);
+        ufh[i][kk][e] = hi; ufl[i][kk][e] = lo;
+      }
+    }
+  }
+  const int cu = 16 * cw + (tid & 15);
+  const int s_end = p.s_begin + p.s_count;
+  const size_t slot_words = (size_t)P * P * 256;
+  int cn[2];
+  float cmask[2], dc[2];
+  unsigned* xch[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int bt = 2 * q + x;
+    cn[x] = bt * 16 + (tid >> 4);
+    cmask[x] = p.mask_u ? p.mask_u[((size_t)dir * p.n_pad + cn[x]) * H + cu] : 1.f;
+    dc[x] = p.s_begin > 0 ? p.dc_state[((size_t)dir * p.n_pad + cn[x]) * H + cu] : 0.f;
+    xch[x] = p.xbuf + (size_t)(dir * p.NB + bt) * p.xchain_words;
+  }
+  float zmax = 0.f;
+  bool dead = false;
+
+  // slab values of the NEXT step of each tile, prefetched one step ahead
+  float nx_dy[2], nx_c[2], nx_cp[2];
+  float4 nx_g[2];
+  auto load_slabs = [&](int x, int ss) {
+    const int sc = ss < s_end ? ss : s_end - 1;    // past the end: a valid, unused row
+    const int tt = dir == 0 ? p.T - 1 - sc : sc;
+    const bool has_prev = sc + 1 < p.T;            // the sequence's first frame has c_prev = 0
+    const int tcc = has_prev ? (dir == 0 ? tt - 1 : tt + 1) : tt;
+    const size_t row = (size_t)tt * p.n_pad + cn[x];
+    nx_dy[x] = p.dy[row * H2 + dir * H + cu];
+    nx_c[x] = p.cell[(row * 2 + dir) * H + cu];
+    const float cp = p.cell[(((size_t)tcc * p.n_pad + cn[x]) * 2 + dir) * H + cu];
+    nx_cp[x] = has_prev ? cp : 0.f;
+    nx_g[x] = *reinterpret_cast<const float4*>(p.gates + (row * 2 + dir) * H4 + 4 * cu);
+  };
+  load_slabs(0, p.s_begin);
+  load_slabs(1, p.s_begin);
+
+  // Lane (sample = lane>>4 of this wave's four, unit quad = (lane>>2)&3, sub = lane&3)
+  // gathers the 16-byte group (sample, quad) of the partial dh tiles of producers
+  // sub*TPW+i; summed in registers, then over the four `sub` lanes with DPP quad permutes.
+  constexpr int NL = TPW;
+  const int sub = lane & 3;
+  const int grp_in_tile = (4 * w + (lane >> 4)) * 4 + ((lane >> 2) & 3);
+  unsigned off[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) off[i] = (unsigned)(((sub * TPW + i) * 64 + grp_in_tile) * 16);
+  u32x4 v[2][NL];
+  // this workgroup's region of the slot that holds the partial tiles of step `ss`, tile x
+  auto rslot = [&](int x, int ss) -> __amdgpu_buffer_rsrc_t {
+    return __builtin_amdgcn_make_buffer_rsrc(
+        xch[x] + (size_t)(ss & 1) * slot_words + (size_t)cw * P * 256, 0, P * 256 * 4, 0x00020000);
+  };
+  auto issue = [&](int x, int ss) {
+    for (int i = 0; i < p.prepoll; ++i) __builtin_amdgcn_s_sleep(1);
+    const __amdgpu_buffer_rsrc_t rsrc = rslot(x, ss);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) v[x][i] = xload<FAST>(rsrc, off[i]);
+  };
+  auto all_fresh = [&](int x, unsigned tag) -> bool {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) ok = ok && tags_ok(v[x][i], tag);
+    return ok;
+  };
+  auto repoll = [&](int x, int ss, unsigned tag) {
+    const __amdgpu_buffer_rsrc_t rsrc = rslot(x, ss);
+    const long long t0 = wall_clock64();
+    while (!dead) {
+      for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        if (!tags_ok(v[x][i], tag)) v[x][i] = xload<FAST>(rsrc, off[i]);
+      if (all_fresh(x, tag)) return;
+      if (wall_clock64() - t0 > kSpinTicks) {
+        dead = true;
+        atomicExch(p.status, 1);
+      }
+    }
+  };
+
+  // everything of one step of tile x after its recurrent gradient dh_rec is known: cell
+  // gradient, dz slab + LDS tile, barrier, partial dh tiles = U^T-slice x dz, publish.
+  // ISSUE: whether the other tile's gather (tile ox, step os) is issued on the way.
+  auto tail = [&](auto xc, auto issue_c, int s, float dh_rec, int os) {
+    constexpr int x = decltype(xc)::value;
+    constexpr int ox = 1 - x;
+    constexpr bool ISSUE = decltype(issue_c)::value;
+    float* sinv = lds + (size_t)x * kTileFloats;              // [16] 1/scale per batch column
+    _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZH] hi
+    _Float16* dzl = dzh + 16 * DZH;                           // [16][DZH] lo
+    const int t = dir == 0 ? p.T - 1 - s : s;
+    {
+      const float4 gt = nx_g[x];
+      const float dyv = nx_dy[x], cv = nx_c[x], cpv = nx_cp[x];
+      load_slabs(x, s + 1);
+      const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
+      const float dh = dyv + cmask[x] * dh_rec;
+      const float tch = fast_tanh(cv);
+      const float d_o = dh * tch;
+      const float dcc = dc[x] + dh * go * (1.f - tch * tch);
+      const float d_i = dcc * gg, d_g = dcc * gi, d_f = dcc * cpv;
+      dc[x] = dcc * gf;
+      float4 z4;
+      z4.x = d_i * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
+      z4.y = d_f * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
+      z4.z = d_g * (1.f - gg * gg);
+      z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
+      *reinterpret_cast<float4*>(p.dz + (((size_t)t * p.n_pad + cn[x]) * 2 + dir) * H4 + 4 * cu) = z4;
+      // power-of-two scale of this batch column: max over its 16 threads (one DPP row)
+      float m = fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w)));
+      zmax = fmaxf(zmax, m);
+      m = row16_max(m);
+      int ex = 0;
+      if (m > 0.f) (void)frexpf(m, &ex); else ex = 9;
+      ex = ex < -100 ? -100 : ex;                 // keep 2^(9-ex) finite for denormal maxima
+      const float sc = ldexpf(1.f, 9 - ex);
+      if ((tid & 15) == 0) sinv[tid >> 4] = ldexpf(1.f, ex - 9);
+      h4 hi4, lo4;
+      _Float16 a, b;
+      split_f16(z4.x * sc, a, b); hi4[0] = a; lo4[0] = b;
+      split_f16(z4.y * sc, a, b); hi4[1] = a; lo4[1] = b;
+      split_f16(z4.z * sc, a, b); hi4[2] = a; lo4[2] = b;
+      split_f16(z4.w * sc, a, b); hi4[3] = a; lo4[3] = b;
+      *reinterpret_cast<h4*>(dzh + (tid >> 4) * DZH + 4 * (tid & 15)) = hi4;
+      *reinterpret_cast<h4*>(dzl + (tid >> 4) * DZH + 4 * (tid & 15)) = lo4;
+    }
+    if (ISSUE && PLACE == 3) issue(ox, os);
+    __syncthreads();
+    if (ISSUE && PLACE == 1) issue(ox, os);
+    {
+      h8 bh[2], bl[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bh[kk] = *reinterpret_cast<const h8*>(dzh + nl * DZH + 32 * kk + 8 * g);
+        bl[kk] = *reinterpret_cast<const h8*>(dzl + nl * DZH + 32 * kk + 8 * g);
+      }
+      const float us = sinv[nl];
+      const unsigned wtag = (unsigned)(s >> 1) & 1u;
+      // (the last step's tiles are published too: nobody reads them, and no branch is needed)
+      const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+          xch[x] + (size_t)(s & 1) * slot_words, 0, (unsigned)(slot_words * 4), 0x00020000);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int mt = w + 4 * i;
+        f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac0 = am, ac1 = am;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[i][kk], bh[kk], am, 0, 0, 0);
+          ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[i][kk], bl[kk], ac0, 0, 0, 0);
+          ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[i][kk], bh[kk], ac1, 0, 0, 0);
+        }
+        const f32x4 a = (am + (ac0 + ac1) * (1.f / kLoScale)) * us;
+        u32x4 o;
+        o[0] = tag_word(a[0], wtag); o[1] = tag_word(a[1], wtag);
+        o[2] = tag_word(a[2], wtag); o[3] = tag_word(a[3], wtag);
+        xstore<FAST>(o, wr, (unsigned)((((size_t)mt * P + cw) * 256 + nl * 16 + 4 * g) * 4));
+      }
+    }
+    if (ISSUE && PLACE == 2) issue(ox, os);
+  };
+  // one phase = one step (s >= 1) of tile x: finish its gather, reduce, then `tail`.  The
+  // gather issued on the way is the OTHER tile's next input: phase 0 -> tile 1, partial
+  // tiles of step s-1 (consumed later in this iteration); phase 1 -> tile 0, step s
+  // (consumed by the next iteration; after the last one a harmless unused read).
+  auto phase = [&](auto xc, int s) {
+    constexpr int x = decltype(xc)::value;
+    const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
+    if (!all_fresh(x, tag)) repoll(x, s - 1, tag);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      acc.x += __uint_as_float(v[x][i][0] & ~1u); acc.y += __uint_as_float(v[x][i][1] & ~1u);
+      acc.z += __uint_as_float(v[x][i][2] & ~1u); acc.w += __uint_as_float(v[x][i][3] & ~1u);
+    }
+    acc.x += quad_swap1(acc.x); acc.y += quad_swap1(acc.y);
+    acc.z += quad_swap1(acc.z); acc.w += quad_swap1(acc.w);
+    acc.x += quad_swap2(acc.x); acc.y += quad_swap2(acc.y);
+    acc.z += quad_swap2(acc.z); acc.w += quad_swap2(acc.w);
+    const float dh_rec = sub == 0 ? acc.x : sub == 1 ? acc.y : sub == 2 ? acc.z : acc.w;
+    tail(xc, std::true_type{}, s, dh_rec, x == 0 ? s - 1 : s);
+  };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  int s = p.s_begin;
+  if (s == 0) {
+    // step 0 of both tiles: no recurrent gradient yet, nothing to gather
+    tail(T0{}, std::false_type{}, 0, 0.f, 0);
+    tail(T1{}, std::false_type{}, 0, 0.f, 0);
+    s = 1;
+  }
+  // (first phase peeled, as in fwd_body_k2, so that every gather the loop waits for was
+  // issued by the same code sequence)
+  if (s < s_end) {
+    issue(0, s - 1);
+    phase(T0{}, s);
+    for (;;) {
+      phase(T1{}, s);
+      if (++s >= s_end) break;
+      phase(T0{}, s);
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+    p.dc_state[((size_t)dir * p.n_pad + cn[x]) * H + cu] = dc[x];
+  if (p.dz_absmax) {
+    zmax = asr_wave_max(zmax);
+    if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
+  }
+}
+
+template <int TPW, int PLACE>
+__global__ void __launch_bounds__(kThreads)
+lstm_bwd_kernel_h2(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int pair_local, cw;
+  if (!map_block(p, pair_local, cw)) return;
+  const int pair = p.chain_begin + pair_local;
+  const bool fast = chain_on_one_xcd(p, pair, cw, reinterpret_cast<int*>(lds));
+  if (fast) bwd_body_h2<TPW, true, PLACE>(p, pair, cw, lds);
+  else bwd_body_h2<TPW, false, PLACE>(p, pair, cw, lds);
+}
+
+// ---------------------------------------------------------------------------
 struct Plan {
   int R, P, TPW, MAXR, NKK, prec;
   int pair;                // 1: a workgroup serves two batch tiles (lstm_fwd_kernel_k2)
@@ -1638,6 +1896,12 @@ kern_t pick_fwd_k2(int nkk, int place) {
   return place == 0 ? lstm_fwd_kernel_k2<4, 0>
        : place == 1 ? lstm_fwd_kernel_k2<4, 1>
        : place == 3 ? lstm_fwd_kernel_k2<4, 3> : lstm_fwd_kernel_k2<4, 2>;
+}
+kern_t pick_bwd_h2(int tpw, int place) {
+  if (tpw <= 4) return place == 3 ? lstm_bwd_kernel_h2<4, 3>
+                     : place == 2 ? lstm_bwd_kernel_h2<4, 2> : lstm_bwd_kernel_h2<4, 1>;
+  return place == 3 ? lstm_bwd_kernel_h2<8, 3>
+       : place == 2 ? lstm_bwd_kernel_h2<8, 2> : lstm_bwd_kernel_h2<8, 1>;
 }
 kern_t pick_bwd_h(int tpw) {
   switch (tpw) {
@@ -1728,7 +1992,14 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     k = pick_bwd(pl.TPW);
     if (pl.prec == 1) {
       pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 72 * 2);
-      k = (a->mi || a->zone_c || a->zone_h) ? pick_bwd_hv(pl.TPW) : pick_bwd_h(pl.TPW);
+      const bool variants = a->mi || a->zone_c || a->zone_h;
+      k = variants ? pick_bwd_hv(pl.TPW) : pick_bwd_h(pl.TPW);
+      // two batch tiles per workgroup (opt-in): plain cell, persistent mode, H = 256 / 512
+      if (!variants && env_int("ASR_LSTM_PAIR_B", 0) && a->mode == 0 &&
+          (a->n_pad / 16) % 2 == 0 && (H == 256 || H == 512)) {
+        pl.pair = 1;
+        k = pick_bwd_h2(pl.TPW, env_int("ASR_LSTM_PAIR_PLACE_B", 1));
+      }
     }
   }
   if (pl.shm < (size_t)pl.P * 4 + 16) pl.shm = (size_t)pl.P * 4 + 16;
@@ -1848,7 +2119,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.dbg = env_int("ASR_LSTM_DBG", 0);
   // measured optimum on MI355X (tools/sweep_poll.sh): forward 14-16 naps (~0.4 us),
   // BPTT 8 for chains of <= 16 workgroups and none for wider ones
-  p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.P <= 16 ? 8 : 0)
+  p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.pair ? 0 : pl.P <= 16 ? 8 : 0)
                   : env_int("ASR_LSTM_PREPOLL_F", pl.pair ? 0 : pl.P <= 16 ? 12 : 16);
   p.repoll = bwd ? env_int("ASR_LSTM_REPOLL_B", 1) : env_int("ASR_LSTM_REPOLL_F", 1);
   p.xstride = fwd_xstride();

@@ -170,6 +170,46 @@ def test_paired_forward_kernel_matches_the_default_one(N, H, place, monkeypatch)
         assert np.array_equal(a, b), name
 
 
+@pytest.mark.parametrize('N,H,place', [(32, 256, 1), (32, 256, 3), (32, 256, 2), (64, 512, 1),
+                                       (20, 256, 1)])
+def test_paired_bptt_kernel_matches_the_default_one(N, H, place, monkeypatch):
+    """ASR_LSTM_PAIR_B=1 (lstm_bwd_kernel_h2: two batch tiles per workgroup in BPTT) against
+    the default BPTT kernel on the same forward activations: same products and summation
+    order, cell gradient evaluated by separately compiled code (1e-6 of the largest
+    gradient); sliced == whole bit for bit; max|dz| exact; with a recurrent-dropout mask."""
+    from asr_study_amd import ops
+    T = 61
+    rs = np.random.RandomState(H + N + place)
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.1).astype(np.float32)).to(dev)
+    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
+    y = torch.zeros(T, n_pad, 2 * H, device=dev)
+    cell = torch.zeros(T, n_pad, 2, H, device=dev)
+    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    ops.lstm_status(ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask))
+
+    def run(ranges):
+        dz = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+        amax = torch.zeros(1, device=dev)
+        for r in ranges:
+            ws = ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=mask,
+                                  dz_absmax=amax, steps=r)
+        ops.lstm_status(ws)
+        return dz.cpu().numpy(), amax.cpu().numpy()
+    monkeypatch.setenv('ASR_LSTM_PAIR_B', '0')
+    want, _ = run([None])
+    monkeypatch.setenv('ASR_LSTM_PAIR_B', '1')
+    monkeypatch.setenv('ASR_LSTM_PAIR_PLACE_B', str(place))
+    whole, amax = run([None])
+    assert np.abs(whole - want).max() < 1e-6 * np.abs(want).max()
+    assert np.abs(whole).max() == amax[0]
+    sliced, amax2 = run([(0, 17), (17, 30), (47, 14)])
+    assert np.array_equal(whole, sliced) and amax2[0] == amax[0]
+
+
 @pytest.mark.parametrize('T,N,H,use_mi,use_zone', [
     (23, 5, 16, True, False),
     (23, 5, 16, False, True),
