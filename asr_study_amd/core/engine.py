@@ -102,7 +102,7 @@ class Model(object):
         self.device = torch.device(device or 'cuda:0')
         self.spec = spec
         self.num_features = int(num_features)
-        self.lstm_mode = lstm_mode
+        self.lstm_mode = int(os.environ.get('ASR_LSTM_MODE', lstm_mode))   # 1 = stepwise kernels
         self.optimizer = None
         self.metrics_names = ['loss', 'ctc_loss', 'decoder_loss', 'decoder_ler']
         self.decoder = dict(is_greedy=True)
@@ -914,15 +914,24 @@ class Model(object):
         if not sync:
             # snapshots of this step's small result tensors (the buffers behind them are
             # reused by the next step): metrics can then be fetched one step later
-            return ctc.clone(), dec.clone(), dlen.clone(), self._norm[1:2].clone()
+            return (ctc.clone(), dec.clone(), dlen.clone(), self._norm[1:2].clone(),
+                    ops.lstm_timeout_flags(self.device))
         return self._metrics(ctc, dec, dlen, labels)
 
     def _lagged(self, pending):
-        (ctc, dec, dlen, pen), labels, _ = pending
-        return self._metrics(ctc, dec, dlen, labels, pen=pen)
+        (ctc, dec, dlen, pen, flags), labels, _ = pending
+        return self._metrics(ctc, dec, dlen, labels, pen=pen, flags=flags)
 
-    def _metrics(self, ctc, dec, dlen, labels, hyps=None, pen=None):
+    def _metrics(self, ctc, dec, dlen, labels, hyps=None, pen=None, flags=None):
         ctc_h = ctc.cpu().numpy().astype(np.float64)
+        # the persistent recurrent kernels bound every spin; one that gave up has left
+        # invalid activations behind: fail here, at the step's host synchronisation point
+        flags = ops.lstm_timeout_flags(self.device) if flags is None else flags
+        if bool(flags.any().item()):
+            from .._lib import AsrHipError
+            raise AsrHipError('a persistent LSTM kernel abandoned a bounded spin (peer workgroup '
+                              'not co-resident or device fault): the results of this step are '
+                              'invalid; ASR_LSTM_MODE=1 selects the stepwise kernels')
         if pen is not None:
             pen = float(pen.item())
         else:

@@ -107,6 +107,17 @@ struct LstmParams {
 
 constexpr long long kSpinTicks = 60LL * 1000 * 1000;   // 0.6 s of the 100 MHz wall clock
 
+// Workspace layout: [sticky block][status block][XCC table][exchange buffer][dc_state].
+// status[0] is the timeout flag of the LAST call (the library clears it at the start of
+// every sequence); the first int of the sticky block in front of it is set together with
+// it and cleared only by asr_lstm_status, so a host that checks once per training step
+// still sees a timeout of any of the step's calls.
+constexpr int kStickyInts = 64;                        // 256 bytes
+__device__ __forceinline__ void mark_timeout(int* status) {
+  atomicExch(status, 1);
+  atomicExch(status - kStickyInts, 1);
+}
+
 __device__ __forceinline__ float hard_sigmoid(float x) {
   return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f);
 }
@@ -196,7 +207,7 @@ __device__ __forceinline__ void gather_groups(__amdgpu_buffer_rsrc_t rsrc,
     if (!timing) { t0 = wall_clock64(); timing = true; }
     else if (wall_clock64() - t0 > kSpinTicks) {
       dead = true;
-      atomicExch(status, 1);
+      mark_timeout(status);
       return;
     }
     if (!nosleep) for (int i = 0; i < repoll; ++i) __builtin_amdgcn_s_sleep(1);
@@ -965,7 +976,7 @@ __device__ __forceinline__ void fwd_body_k2(const LstmParams& p, int pair, int w
       if (all_fresh(x, tag)) return;
       if (wall_clock64() - t0 > kSpinTicks) {
         dead = true;
-        atomicExch(p.status, 1);
+        mark_timeout(p.status);
       }
     }
   };
@@ -1693,7 +1704,7 @@ __device__ __forceinline__ void bwd_body_h2(const LstmParams& p, int pair, int c
       if (all_fresh(x, tag)) return;
       if (wall_clock64() - t0 > kSpinTicks) {
         dead = true;
-        atomicExch(p.status, 1);
+        mark_timeout(p.status);
       }
     }
   };
@@ -2040,6 +2051,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
 }
 
 constexpr size_t kStatusBytes = 256;
+constexpr size_t kStickyBytes = kStickyInts * sizeof(int);
 
 size_t xbuf_bytes(const asr_lstm_args* a, bool bwd) {
   const size_t chains = (size_t)2 * (a->n_pad / 16);
@@ -2071,7 +2083,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   kern_t k;
   const int rc = make_plan(a, bwd, &pl, &k);
   if (rc != ASR_OK) return rc;
-  char* ws = reinterpret_cast<char*>(workspace);
+  char* ws = reinterpret_cast<char*>(workspace) + kStickyBytes;    // sticky block first
   const size_t xb = xbuf_bytes(a, bwd);
   const size_t cb_ = xcc_bytes(a);
   LstmParams p;
@@ -2145,7 +2157,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
 
 extern "C" size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward) {
   if (!a || a->n_pad <= 0 || a->H <= 0) return 0;
-  return kStatusBytes + xcc_bytes(a) + xbuf_bytes(a, backward != 0) +
+  return kStickyBytes + kStatusBytes + xcc_bytes(a) + xbuf_bytes(a, backward != 0) +
          asr_align_up((size_t)4 * a->n_pad * a->H * sizeof(float), 256);
 }
 
@@ -2163,10 +2175,14 @@ extern "C" int asr_lstm_seq_bwd(const asr_lstm_args* a, void* workspace, size_t 
 // workspace abandoned a bounded spin.
 extern "C" int asr_lstm_status(const void* workspace, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  int st[2] = {0, 0};
+  int st[kStickyInts + 1];
   ASR_CHECK_HIP(hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, stream));
   ASR_CHECK_HIP(hipStreamSynchronize(stream));
-  if (st[0] != 0) {
+  if (st[0] != 0 || st[kStickyInts] != 0) {
+    if (st[0] != 0) {                      // sticky flag: reported once
+      ASR_CHECK_HIP(hipMemsetAsync(const_cast<void*>(workspace), 0, sizeof(int), stream));
+      ASR_CHECK_HIP(hipStreamSynchronize(stream));
+    }
     asr_set_error("lstm: persistent kernel timed out waiting for a peer workgroup");
     return ASR_ERR_TIMEOUT;
   }
@@ -2189,7 +2205,7 @@ extern "C" int asr_lstm_plan(const asr_lstm_args* a, int backward, int* ks, int*
 // 4 phases x 4 waves, accumulated over the steps of the last call.
 extern "C" int asr_lstm_profile(const void* workspace, asr_stream_t stream_, long long* out16) {
   hipStream_t stream = (hipStream_t)stream_;
-  ASR_CHECK_HIP(hipMemcpyAsync(out16, reinterpret_cast<const char*>(workspace) + 64,
+  ASR_CHECK_HIP(hipMemcpyAsync(out16, reinterpret_cast<const char*>(workspace) + kStickyBytes + 64,
                                16 * sizeof(long long), hipMemcpyDeviceToHost, stream));
   ASR_CHECK_HIP(hipStreamSynchronize(stream));
   return ASR_OK;
@@ -2200,7 +2216,8 @@ extern "C" int asr_lstm_profile(const void* workspace, asr_stream_t stream_, lon
 extern "C" int asr_lstm_fast_chains(const void* workspace, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int st[2] = {0, 0};
-  ASR_CHECK_HIP(hipMemcpyAsync(st, workspace, sizeof(st), hipMemcpyDeviceToHost, stream));
+  ASR_CHECK_HIP(hipMemcpyAsync(st, reinterpret_cast<const char*>(workspace) + kStickyBytes,
+                               sizeof(st), hipMemcpyDeviceToHost, stream));
   ASR_CHECK_HIP(hipStreamSynchronize(stream));
   return st[1];
 }

@@ -37,7 +37,9 @@ class _Workspaces(object):
         key = (name, str(device))
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            # zero-filled: the recurrent kernels keep a sticky timeout flag in the first
+            # bytes of their workspace (asr_lstm_status)
+            buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
             self.bufs[key] = buf
         return buf
 
@@ -195,6 +197,14 @@ def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check
 
 def lstm_status(ws):
     L.check(L.load().asr_lstm_status(_ptr(ws), _stream()), 'asr_lstm_status')
+
+
+def lstm_timeout_flags(device):
+    """The sticky timeout flags of the forward / BPTT workspaces as one int32 tensor of two
+    elements on the device (a snapshot enqueued on the current stream, no synchronisation);
+    non-zero = a persistent kernel abandoned a bounded spin since the flag was cleared."""
+    return torch.stack([WS.get(name, 0, device)[:4].view(torch.int32)[0]
+                        for name in ('lstm_fwd', 'lstm_bwd')])
 
 
 def lstm_fast_chains(ws):

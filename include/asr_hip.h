@@ -202,7 +202,12 @@ int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,
 int asr_lstm_seq_bwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,
                      asr_stream_t stream);
 /* Synchronises `stream`, then returns 0 or ASR_ERR_TIMEOUT if a persistent
- * kernel that used this workspace abandoned a bounded spin (results invalid). */
+ * kernel that used this workspace abandoned a bounded spin (results invalid)
+ * in ANY call since the previous asr_lstm_status on it: the first int of the
+ * workspace is a sticky flag that only this function clears (the workspace's
+ * first 256 bytes must therefore be zero before its first use).  A host that
+ * never wants to synchronise may instead copy that int back with its own
+ * asynchronous readback once per training step.                             */
 int asr_lstm_status(const void* workspace, asr_stream_t stream);
 /* Launch plan the library would use (diagnostics / DESIGN.md numbers).       */
 int asr_lstm_plan(const asr_lstm_args* a, int backward, int* k_split,

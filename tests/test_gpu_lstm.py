@@ -132,6 +132,32 @@ def test_step_ranges_continue_one_sequence(T, N, H, cuts):
     assert np.abs(whole[3]).max() == whole[4][0]
 
 
+def test_sticky_timeout_flag_survives_later_calls_and_is_reported_once():
+    """The first int of the recurrent workspace is a sticky timeout flag: set together with
+    the per-call flag, untouched by later calls on the same workspace, cleared only by
+    asr_lstm_status -- so one check per training step sees a timeout of any layer."""
+    from asr_study_amd import ops
+    from asr_study_amd._lib import AsrHipError
+    T, n_pad, H = 5, 16, 16
+    dev = torch.device('cuda:0')
+    rs = np.random.RandomState(0)
+    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(2, H, 4 * H) / 4).astype(np.float32)).to(dev)
+    y = torch.zeros(T, n_pad, 2 * H, device=dev)
+    cell = torch.zeros(T, n_pad, 2, H, device=dev)
+    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    ws = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H)
+    ops.lstm_status(ws)
+    assert not ops.lstm_timeout_flags(dev).any().item()
+    ws[:4].view(torch.int32)[0] = 1              # what mark_timeout() does on the device
+    ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H)       # a later, healthy call
+    assert ops.lstm_timeout_flags(dev)[0].item() == 1
+    with pytest.raises(AsrHipError):
+        ops.lstm_status(ws)
+    ops.lstm_status(ws)                          # reported once, then clear
+    assert not ops.lstm_timeout_flags(dev).any().item()
+
+
 @pytest.mark.parametrize('N,H,place', [(32, 256, 0), (32, 256, 1), (32, 256, 2), (32, 256, 3), (64, 512, 1),
                                        (20, 256, 1)])
 def test_paired_forward_kernel_matches_the_default_one(N, H, place, monkeypatch):
