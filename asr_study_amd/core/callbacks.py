@@ -35,9 +35,28 @@ class Callback(object):
         pass
 
 
+LSTM_PARTS = ('W', 'U', 'b')
+MI_PARTS = ('mi_alpha', 'mi_beta1', 'mi_beta2')
+# the reference iterates a dict literal {'Uh', 'Wx', 'new_c'} (core/layers.py:409): its
+# Python-2 order is unspecified, so files are written in this order and READ BY NAME
+LN_PARTS = ('ln_gain_Uh', 'ln_bias_Uh', 'ln_gain_Wx', 'ln_bias_Wx', 'ln_gain_new_c',
+            'ln_bias_new_c')
+
+
+def lstm_weight_parts(stage):
+    """Per-direction weight suffixes of a BiLSTM stage in get_weights() order: Keras' W, U, b
+    (base LSTM.build), then the reference's add_weight names (core/layers.py:388-422)."""
+    parts = list(LSTM_PARTS)
+    if getattr(stage, 'mi', None) is not None:
+        parts += list(MI_PARTS)
+    if getattr(stage, 'ln', None) is not None:
+        parts += list(LN_PARTS)
+    return parts
+
+
 def keras_layers(model, weights):
     """[(layer name, [(weight name, array), ...])] in Keras-1.2.2 naming for the model's
-    weight-bearing stages (get_weights() order)."""
+    weight-bearing stages (get_weights() order); every array of ``weights`` is consumed."""
     it = iter(weights)
     out, nb, nd = [], 0, 0
     for s in model.stages:
@@ -45,14 +64,35 @@ def keras_layers(model, weights):
             nb += 1
             ws = []
             for d in ('forward', 'backward'):
-                for part in ('W', 'U', 'b'):
+                for part in lstm_weight_parts(s):
                     ws.append(('%s_lstm_%d_%s:0' % (d, nb, part), next(it)))
             out.append(('bidirectional_%d' % nb, ws))
         elif s.kind == 'dense':
             nd += 1
             out.append(('timedistributed_%d' % nd, [('dense_%d_W:0' % nd, next(it)),
                                                     ('dense_%d_b:0' % nd, next(it))]))
+    rest = sum(1 for _ in it)
+    if rest:
+        raise ValueError('keras_layers: %d weight arrays left over (get_weights() and the '
+                         'stage list disagree)' % rest)
     return out
+
+
+def order_layer_weights(names, arrays):
+    """Arrays of one Keras layer group re-ordered into this package's get_weights() order,
+    by NAME: tolerant of the TF backend's ':0' suffix and of any order of the reference's
+    mi / layer-norm weights inside the group.  Unknown names keep their file order."""
+    def key(name):
+        n = name[:-2] if name.endswith(':0') else name
+        d = 0 if n.startswith('forward_') else 1 if n.startswith('backward_') else 0
+        for rank, part in enumerate(LSTM_PARTS + MI_PARTS + LN_PARTS + ('W', 'b')):
+            if n.endswith('_' + part):
+                return (d, rank)
+        return None
+    keys = [key(n) for n in names]
+    if any(k is None for k in keys) or len(set(keys)) != len(keys):
+        return list(arrays)
+    return [a for _, a in sorted(zip(keys, arrays), key=lambda ka: ka[0])]
 
 
 def save_model(model, filepath, meta=None, model_config=None):

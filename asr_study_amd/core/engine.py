@@ -46,6 +46,11 @@ def _um2gm(a, H, Hp):
     return np.ascontiguousarray(np.swapaxes(u, -1, -2)).reshape(sh + (4 * H,))
 
 
+# where a Model lives when the factory is given no ``device`` (host-only tests build on 'cpu':
+# weights I/O works there, every compute call still needs the HIP library and a GPU)
+DEFAULT_DEVICE = os.environ.get('ASR_DEVICE', 'cuda:0')
+
+
 class Stage(object):
     pass
 
@@ -99,7 +104,7 @@ class Model(object):
     """The object ``ctc_model(inputs, output)`` returns (core/models.py:31-52)."""
 
     def __init__(self, spec, num_features, device=None, seed=0, lstm_mode=0):
-        self.device = torch.device(device or 'cuda:0')
+        self.device = torch.device(device or DEFAULT_DEVICE)
         self.spec = spec
         self.num_features = int(num_features)
         self.lstm_mode = int(os.environ.get('ASR_LSTM_MODE', lstm_mode))   # 1 = stepwise kernels
@@ -847,8 +852,9 @@ class Model(object):
         """Same with labels (N, l_max) / label_len / seq_len already on the device."""
         logits = self.forward(slab, training=training, masks=masks)
         dlog = self._buf('dlogits', logits.shape)
+        # n_global = 0: a zero-weight dummy shard (parallel.ShardedBatch.n_local == 0)
         ctc = ops.ctc_loss_grad(logits, lab, lab_len, sl, N, grad=dlog,
-                                grad_scale=1.0 / float(n_global or N))
+                                grad_scale=0.0 if n_global == 0 else 1.0 / float(n_global or N))
         self.backward(dlog)
         return ctc, logits, sl
 
@@ -905,8 +911,13 @@ class Model(object):
         N = len(labels)
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # a rank's shard of a global batch says how many samples the GLOBAL batch had (shards
+        # are unequal when the batch is not divisible by the world; parallel.ShardedBatch)
+        n_global = getattr(inputs, 'n_global', N * world)
+        if getattr(inputs, 'n_local', N) == 0:
+            n_global = 0
         ctc, logits, sl = self.loss_and_grads(slab, labels, lens, training=True, masks=masks,
-                                              n_global=N * world)
+                                              n_global=n_global)
         self._allreduce()
         self._step += 1
         self.optimizer.step(self)
@@ -1010,20 +1021,26 @@ class Model(object):
         try:
             for epoch in range(initial_epoch, nb_epoch):
                 t0 = time.time()
-                seen, sums = 0, np.zeros(4)
+                seen, seen_local, sums = 0, 0, np.zeros(4)
                 pending = None              # (device results, labels, n) of the previous step
                 while seen < samples_per_epoch:
                     inputs, outputs = feeder.get()
                     slab, labels, lens = self._unpack_inputs(inputs)
-                    n = len(labels)
-                    res = self.train_on_batch([('slab', slab), labels, lens], outputs, sync=False)
+                    # an epoch counts GLOBAL samples; this rank's metrics weigh its own
+                    n = getattr(inputs, 'n_local', len(labels))
+                    batch = [('slab', slab), labels, lens]
+                    if hasattr(inputs, 'n_global'):
+                        from ..parallel import ShardedBatch
+                        batch = ShardedBatch(batch, inputs.n_global, inputs.n_local)
+                    res = self.train_on_batch(batch, outputs, sync=False)
                     if pending is not None:
                         sums += np.array(self._lagged(pending)) * pending[2]
                     pending = (res, labels, n)
-                    seen += n
+                    seen += getattr(inputs, 'n_global', len(labels))
+                    seen_local += n
                 if pending is not None:
                     sums += np.array(self._lagged(pending)) * pending[2]
-                logs = dict(zip(self.metrics_names, (sums / max(seen, 1)).tolist()))
+                logs = dict(zip(self.metrics_names, (sums / max(seen_local, 1)).tolist()))
                 if validation_data is not None:
                     val = self.evaluate_generator(validation_data, nb_val_samples)
                     for k, v in zip(self.metrics_names, val):

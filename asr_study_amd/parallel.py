@@ -79,6 +79,19 @@ def reduce_metrics(sums, count):
     return (t[:-1] / max(float(t[-1]), 1.0)).tolist()
 
 
+class ShardedBatch(list):
+    """``[x, labels, lens]`` of one rank's shard plus what the step needs to know about the
+    GLOBAL batch it came from: ``n_global`` (samples in the global batch: the gradient is
+    scaled by 1/n_global on every rank so that the all-reduced sum is the gradient of the
+    global batch mean, and an epoch counts global samples) and ``n_local`` (this rank's real
+    samples; 0 when the global batch was smaller than the world and this rank only carries a
+    zero-weight dummy so that it still takes part in the collectives)."""
+
+    def __init__(self, items, n_global, n_local):
+        super(ShardedBatch, self).__init__(items)
+        self.n_global, self.n_local = int(n_global), int(n_local)
+
+
 class ShardedFlow(object):
     """Wraps a DatasetIterator: every rank advances the same index stream and keeps
     its ``rank::world`` shard; inputs are padded to the global batch's T_max."""
@@ -97,14 +110,16 @@ class ShardedFlow(object):
         (x, labels, lens), (zeros, _) = next(self.flow)
         n = len(np.asarray(lens).reshape(-1))
         keep = np.arange(n)[self.rank::self.world]
-        if len(keep) == 0:
+        n_local = len(keep)
+        if n_local == 0:                    # zero-weight dummy: sample 0 with gradient scale 0
             keep = np.arange(n)[:1]
         csr = labels.tocsr()
         lab = [csr.data[csr.indptr[i]:csr.indptr[i + 1]] for i in keep]
         if isinstance(x, tuple) and x[0] == 'slab':
             raise NotImplementedError('on-device features + sharding: shard before extraction')
         x = np.asarray(x)[keep]                  # still padded to the GLOBAL T_max
-        return ([x, lab, np.asarray(lens).reshape(-1)[keep]], [zeros[keep], lab])
+        return (ShardedBatch([x, lab, np.asarray(lens).reshape(-1)[keep]], n, n_local),
+                [zeros[keep], lab])
 
     next = __next__
 

@@ -10,6 +10,7 @@ import os
 import numpy as np
 import yaml
 
+from ..core.callbacks import order_layer_weights
 from ..datasets import h5lite
 from . import generic_utils as utils
 from .hparams import HParams
@@ -45,7 +46,7 @@ def load_model(model_fname, return_meta=False, mode='train', **kwargs):
             for lname in g.attrs.get_strings('layer_names'):
                 lg = g[lname]
                 names = lg.attrs.get_strings('weight_names') if 'weight_names' in lg.attrs else []
-                weights += [lg[w].read_array() for w in names]
+                weights += order_layer_weights(names, [lg[w].read_array() for w in names])
         else:                              # round-1 development format
             shapes = yaml.safe_load(g.attrs['shapes'])
             weights = [np.asarray(a, np.float32).reshape(s)
@@ -59,10 +60,11 @@ def load_model(model_fname, return_meta=False, mode='train', **kwargs):
             # a file written by the reference: the topology is named in meta/training_args
             # (train.py:127-129), input / output widths are read off the weights
             targs = yaml.safe_load(f['meta'].attrs['training_args'])
-            kwargs = HParams().parse(list(targs.get('model_params') or [])).values()
-            kwargs.setdefault('num_features', int(weights[0].shape[0]))
-            kwargs.setdefault('num_classes', int(weights[-1].shape[0]))
-            cfg = {'name': targs['model'], 'kwargs': kwargs}
+            # (own name: ``kwargs`` are the caller's decoder options, read again below)
+            mkw = HParams().parse(list(targs.get('model_params') or [])).values()
+            mkw.setdefault('num_features', int(weights[0].shape[0]))
+            mkw.setdefault('num_classes', int(weights[-1].shape[0]))
+            cfg = {'name': targs['model'], 'kwargs': mkw}
     factory = utils.get_from_module('core.models', cfg['name'])
     model = factory(**cfg.get('kwargs', {}))
     model.config = cfg

@@ -67,15 +67,18 @@ def test_beam_search_host_matches_oracle(lib, beam_width):
         assert plain[n] == want[0]
 
 
-def test_beam_search_host_28_classes_width_100(lib):
+@pytest.mark.parametrize('width,T', [(100, 60), (400, 36)])
+def test_beam_search_host_28_classes_width_100_and_400(lib, width, T):
+    """28 classes at the README's width (100) and at the width eval.py really uses (400,
+    utils/core_utils.py:70-71): the beam is full from the third frame on."""
     from asr_study_amd import ops
-    rs = np.random.RandomState(7)
-    T, N, n_pad, C = 60, 2, 16, 28
+    rs = np.random.RandomState(7 + width)
+    N, n_pad, C = 2, 16, 28
     logits = (rs.randn(T, n_pad, C) * 2).astype(np.float32)
-    seq = np.array([60, 45], np.int32)
-    paths, _ = ops.ctc_beam_search_host(logits, seq, N, 100, True)
+    seq = np.array([T, 3 * T // 4], np.int32)
+    paths, _ = ops.ctc_beam_search_host(logits, seq, N, width, True)
     for n in range(N):
-        want, _ = OD.beam_search_decode_one(logits[:seq[n], n], 100, merge_repeated=True,
+        want, _ = OD.beam_search_decode_one(logits[:seq[n], n], width, merge_repeated=True,
                                             dtype=np.float64)
         assert paths[n] == want[0]
 

@@ -80,3 +80,49 @@ def test_shard_indices_monotonic_and_disjoint():
     assert sorted(np.concatenate(parts).tolist()) == sorted(idx.tolist())
     for p in parts:
         assert np.all(np.diff(p) > 0)
+
+
+def test_sharded_flow_counts_global_samples_and_weights_uneven_shards():
+    """ShardedFlow (host logic, no process group): every rank sees the same number of steps
+    per epoch = ceil(len / batch); the shards of a batch add up to the global batch;
+    n_global is the GLOBAL batch size on every rank (the 1/N_global gradient scale), also
+    for the short last batch; a rank left without a sample carries a zero-weight dummy."""
+    import scipy.sparse as sp
+    from asr_study_amd import parallel
+
+    class Flow(object):
+        def __init__(self, total, batch):
+            self.len, self.batch, self.pos = total, batch, 0
+
+        def __next__(self):
+            n = min(self.batch, self.len - self.pos)
+            self.pos = (self.pos + n) % self.len
+            x = np.zeros((n, 4, 3), np.float32) + np.arange(n)[:, None, None]
+            rows = np.repeat(np.arange(n), 2)
+            cols = np.tile(np.arange(2), n)
+            lab = sp.coo_matrix((np.arange(2 * n, dtype=np.int32) % 5, (rows, cols)))
+            return [x, lab, np.full(n, 4)], [np.zeros(n), lab]
+        next = __next__
+
+    world, total, batch = 3, 9, 4            # batches of 4, 4, 1 -> the last one < world
+    per_rank = []
+    for rank in range(world):
+        flow = parallel.ShardedFlow(Flow(total, batch), rank, world)
+        seen, steps, shards = 0, 0, []
+        while seen < flow.len:               # engine.fit_generator's epoch loop
+            inputs, _ = next(flow)
+            assert isinstance(inputs, parallel.ShardedBatch)
+            seen += inputs.n_global
+            steps += 1
+            shards.append((inputs.n_global, inputs.n_local, np.asarray(inputs[0])[:, 0, 0].tolist()))
+        per_rank.append((steps, shards))
+    assert [s for s, _ in per_rank] == [3, 3, 3]
+    for step in range(3):
+        ng = {per_rank[r][1][step][0] for r in range(world)}
+        assert ng == {(4, 4, 1)[step]}
+        assert sum(per_rank[r][1][step][1] for r in range(world)) == ng.pop()
+    # the 1-sample batch: rank 0 owns it, ranks 1 and 2 hold a zero-weight dummy (sample 0)
+    assert [per_rank[r][1][2][1] for r in range(world)] == [1, 0, 0]
+    assert per_rank[1][1][2][2] == [0.0]
+    # an uneven 4-sample batch over 3 ranks: 2 + 1 + 1 samples, all scaled by 1/4
+    assert [per_rank[r][1][0][1] for r in range(world)] == [2, 1, 1]
