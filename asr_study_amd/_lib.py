@@ -45,7 +45,7 @@ class LstmArgs(C.Structure):
                 ('dy', void_p), ('dz', void_p), ('dz_absmax', void_p),
                 ('step_begin', C.c_int), ('step_count', C.c_int),
                 ('mi', void_p), ('uh', void_p), ('zone_c', void_p), ('zone_h', void_p),
-                ('wx', void_p), ('dwx', void_p), ('dmi', void_p)]
+                ('wx', void_p), ('dwx', void_p), ('dmi', void_p), ('db_part', void_p)]
 
 
 class LstmLnArgs(C.Structure):

@@ -683,6 +683,12 @@ class Model(object):
                     dmi = self._buf('dmi%d' % si, (n_pad // 16, 2, 4, 4 * Hp))
                     var.update(wx=rec['zx'], dwx=gsrc, dmi=dmi)
                     pgrad = (dmi, n_pad // 16, 32 * Hp, s.omi)
+                else:
+                    # plain cell: BPTT leaves the bias gradient as per-batch-tile sums of dz
+                    # (accumulated in registers over the steps), so nothing re-reads the dz
+                    # slab for it; the tiles are added up on the side stream
+                    dbp = self._buf('dbpart%d' % si, (n_pad // 16, 2, 4 * Hp))
+                    pgrad = (dbp, n_pad // 16, 8 * Hp, s.ob)
                 pipe_b = (getattr(self, '_pipe_now', False) and self._pipe is not None
                           and not first and self.lstm_mode == 0 and T >= 16 and not var
                           and s.ln is None)
@@ -693,7 +699,8 @@ class Model(object):
                     # in both directions: their dX GEMMs overlap the last quarter
                     dx = self._buf('da_s%d' % si, (T, n_pad, s.f_in_pad))
                     ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp,
-                                     mask_u=BU, mode=self.lstm_mode, dz_absmax=zmx, steps=(0, S))
+                                     mask_u=BU, mode=self.lstm_mode, dz_absmax=zmx, steps=(0, S),
+                                     db_part=pgrad[0])
                     ev = torch.cuda.Event()
                     ev.record(main)
                     flush_side()    # previous layer's dW/dU/db now overlap this BPTT
@@ -704,7 +711,8 @@ class Model(object):
                         dx_inner.record(self._pipe)
                     rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad,
                                                    Hp, mask_u=BU, mode=self.lstm_mode,
-                                                   dz_absmax=zmx, steps=(S, T - S))
+                                                   dz_absmax=zmx, steps=(S, T - S),
+                                                   db_part=pgrad[0])
                 elif s.ln is not None:
                     ops.lstm_ln_seq_bwd(da, rec['zx'], U, self._view(s.ocell, 68 * Hp), rec['uh'],
                                         rec['y'], rec['cell'], rec['gates'], dz, gsrc, pgrad[0], T,
@@ -716,6 +724,8 @@ class Model(object):
                     torch.maximum(zmx, tmp, out=zmx)
                     flush_side()
                 else:
+                    if s.mi is None:
+                        var['db_part'] = pgrad[0]
                     rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad,
                                                    Hp, mask_u=BU, mode=self.lstm_mode,
                                                    dz_absmax=zmx, **var)
@@ -739,13 +749,12 @@ class Model(object):
                             self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
 
                 def grads_W(wsn, s=s, dz=gsrc, a_in=a_in, BW=BW, Hp=Hp, zmx=zmx, pgrad=pgrad):
-                    # dW = (x (.) B_W)^T d(x@W), db = colsum(dz)
-                    own_bias = pgrad is None
+                    # dW = (x (.) B_W)^T d(x@W); the bias (or MI / LN parameter) gradients come
+                    # from BPTT's per-tile partial sums, never from a pass over the dz slab
                     if BW is None:
                         ops.gate_gemm('wgrad', rows, n_pad, s.f_in_pad, 8 * Hp, self.params, s.oW,
                                       8 * Hp, 8 * Hp, x=a_in, dz=dz, dz_absmax=zmx,
-                                      dW=self.grads, dw_off=s.oW, split_k=split, ws_name=wsn,
-                                      db=self._gview(s.ob, 8 * Hp) if own_bias else None)
+                                      dW=self.grads, dw_off=s.oW, split_k=split, ws_name=wsn)
                     else:
                         for d in range(2):
                             ops.gate_gemm('wgrad', rows, n_pad, s.f_in_pad, 4 * Hp, self.params,
@@ -753,13 +762,8 @@ class Model(object):
                                           mask_w=BW[d], dz=dz, z_off=d * 4 * Hp, dz_absmax=zmx,
                                           dW=self.grads, dw_off=s.oW + d * 4 * Hp, split_k=split,
                                           ws_name=wsn)
-                        if own_bias:    # one pass over dz for both directions' bias gradients
-                            ops.colsum(dz, rows, 8 * Hp, 8 * Hp, self._gview(s.ob, 8 * Hp),
-                                       ws_name=wsn + '_cs')
-                    if not own_bias:    # bias / MI / LN parameter gradients: partial sums from BPTT
-                        buf, nrow, ncol, goff = pgrad
-                        ops.colsum(buf, nrow, ncol, ncol, self._gview(goff, ncol),
-                                   ws_name=wsn + '_cs')
+                    buf, nrow, ncol, goff = pgrad
+                    ops.colsum(buf, nrow, ncol, ncol, self._gview(goff, ncol), ws_name=wsn + '_cs')
 
                 def weight_grads(wsn, gu=grads_U, gw=grads_W):
                     gu(wsn)

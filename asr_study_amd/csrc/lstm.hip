@@ -99,6 +99,8 @@ struct LstmParams {
   float* dwx;              // BPTT + mi: d / d (x @ W); dz then holds d / d (h_prev @ U)
   float* dmi;              // BPTT + mi: (NB, 2, 4, 4H) per-batch-tile sums of the parameter
                            //            gradients d alpha, d beta1, d beta2, d bias
+  float* db_part;          // BPTT, optional: (NB, 2, 4H) per-batch-tile sums of dz over the
+                           //            tile's samples and all steps (bias-gradient partials)
   unsigned* xbuf;          // exchange buffer (words)
   long long xchain_words;  // words per chain (2 slots)
   int* xcc;                // [chains][P] XCC id + 1 of every workgroup
@@ -1096,6 +1098,58 @@ lstm_fwd_kernel_k2(LstmParams p) {
 }
 
 // ---------------------------------------------------------------------------
+template <int NL>
+__device__ __forceinline__ bool all_tagged(const u32x4 (&v)[NL], unsigned flip) {
+  unsigned x = 0u;
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+    x |= ((v[i][0] ^ flip) | (v[i][1] ^ flip)) | ((v[i][2] ^ flip) | (v[i][3] ^ flip));
+  return (x & 1u) == 0u;
+}
+
+// am = Uh0*Bh0 + Uh1*Bh1 ; ac = Uh0*Bl0 + Ul0*Bh0 + Uh1*Bl1 + Ul1*Bh1 (K = 2 x 32), i.e.
+// U^T-slice x dz tile = am + ac / 2048.  U fragments "a" (AGPR), B fragments and results "v".
+// s_nop 1: a VALU-written B operand needs 2 wait states before an MFMA reads it; trailing
+// s_nop: an MFMA's D needs its pass count + 4 states before a VALU reads it (hipcc pads one).
+__device__ __forceinline__ void mfma_hl_tile(f32x4& am, f32x4& ac, const f32x4& uh0,
+                                             const f32x4& ul0, const f32x4& uh1,
+                                             const f32x4& ul1, const h8& bh0, const h8& bl0,
+                                             const h8& bh1, const h8& bl1) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %2, %6, 0\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %2, %7, 0\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %3, %6, %1\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %4, %9, %1\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %5, %8, %1\n\t"
+      "s_nop 11"
+      : "=&v"(am), "=&v"(ac)
+      : "a"(uh0), "a"(ul0), "a"(uh1), "a"(ul1), "v"(bh0), "v"(bl0), "v"(bh1), "v"(bl1));
+}
+
+// Sum over the 16 samples of a batch tile of every thread's float4 (thread = (sample tid>>4,
+// unit tid&15)) -> dst[64 gate columns of this workgroup], in a fixed order (deterministic).
+__device__ __forceinline__ void tile_gate_sums(float4 gsum, float* lds, float* dst,
+                                               bool accumulate, int ncols = 64) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float v[4] = {gsum.x, gsum.y, gsum.z, gsum.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {           // over the wave's four samples (lane >> 4)
+    v[k] += __shfl_xor(v[k], 16);
+    v[k] += __shfl_xor(v[k], 32);
+  }
+  __syncthreads();
+  if (lane < 16) *reinterpret_cast<float4*>(lds + (w * 16 + lane) * 4) =
+      make_float4(v[0], v[1], v[2], v[3]);
+  __syncthreads();
+  if (tid < ncols) {                      // column tid = unit (tid >> 2), gate (tid & 3)
+    const float t = ((lds[tid] + lds[64 + tid]) + lds[128 + tid]) + lds[192 + tid];
+    dst[tid] = (accumulate ? dst[tid] : 0.f) + t;
+  }
+  __syncthreads();
+}
+
 // backward (BPTT).  WG `cw` of a chain owns units [16 cw, 16 cw + 16) = gate
 // columns j in [64 cw, 64 cw + 64).  TPW = output tiles (16 units) per wave.
 template <int TPW, bool FAST>
@@ -1131,6 +1185,7 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
   if (cvalid && p.mask_u) cmask = p.mask_u[((size_t)dir * p.n_pad + cn) * H + cu];
   float dc = 0.f;
   float zmax = 0.f;
+  float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);   // sum over steps of this (sample, unit)'s dz
   if (cvalid && p.s_begin > 0) dc = p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu];
   bool dead = false;
   unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;   // [2][P cons][P prod][256]
@@ -1216,6 +1271,7 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
         z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
         *reinterpret_cast<float4*>(p.dz + (((size_t)t * p.n_pad + cn) * 2 + dir) * H4 + 4 * cu) = z4;
         zmax = fmaxf(zmax, fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w))));
+        gsum.x += z4.x; gsum.y += z4.y; gsum.z += z4.z; gsum.w += z4.w;
       }
       *reinterpret_cast<float4*>(dzl + (tid >> 4) * DZS + 4 * (tid & 15)) = z4;
     }
@@ -1271,6 +1327,11 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
     for (int i = 0; i < 4; ++i) out[i] = pt[i];
   }
   if (cvalid && p.dc_state) p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu] = dc;
+  if (p.db_part) {
+    const int left = H4 - 64 * cw;
+    tile_gate_sums(gsum, lds, p.db_part + ((size_t)bt * 2 + dir) * H4 + 64 * cw, p.s_begin > 0,
+                   left < 64 ? left : 64);
+  }
   if (p.dz_absmax) {
     zmax = asr_wave_max(zmax);
     if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
@@ -1336,6 +1397,7 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
   float dc = 0.f;
   float dhz = 0.f;                                 // VAR: (1 - k_h) dh carried to the next step
   float zmax = 0.f;
+  float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);   // sum over steps of this (sample, unit)'s dz
   const bool has_mi = VAR && p.mi != nullptr;
   float4 mi_a = make_float4(0.f, 0.f, 0.f, 0.f), mi_b1 = mi_a, mi_b2 = mi_a;
   float4 g_a = mi_a, g_b1 = mi_a, g_b2 = mi_a, g_b = mi_a;     // parameter-gradient sums
@@ -1456,6 +1518,7 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
         z4.y = d_f * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
         z4.z = d_g * (1.f - gg * gg);
         z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
+        gsum.x += z4.x; gsum.y += z4.y; gsum.z += z4.z; gsum.w += z4.w;
         const size_t zoff = (((size_t)t * p.n_pad + cn) * 2 + dir) * H4 + 4 * cu;
         if (has_mi) {
           // z = alpha Wx Uh + beta1 Uh + beta2 Wx + b: the recurrent product sees
@@ -1563,6 +1626,11 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
       *dst = (p.s_begin > 0 ? *dst : 0.f) + accum[tid];
     }
   }
+  if (p.db_part) {
+    const int left = H4 - 64 * cw;
+    tile_gate_sums(gsum, lds, p.db_part + ((size_t)bt * 2 + dir) * H4 + 64 * cw, p.s_begin > 0,
+                   left < 64 ? left : 64);
+  }
   if (p.dz_absmax) {
     zmax = asr_wave_max(zmax);
     if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
@@ -1645,6 +1713,7 @@ __device__ __forceinline__ void bwd_body_h2(const LstmParams& p, int pair, int c
     dc[x] = p.s_begin > 0 ? p.dc_state[((size_t)dir * p.n_pad + cn[x]) * H + cu] : 0.f;
     xch[x] = p.xbuf + (size_t)(dir * p.NB + bt) * p.xchain_words;
   }
+  float4 gsum[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   float zmax = 0.f;
   bool dead = false;
 
@@ -1737,6 +1806,7 @@ __device__ __forceinline__ void bwd_body_h2(const LstmParams& p, int pair, int c
       z4.z = d_g * (1.f - gg * gg);
       z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
       *reinterpret_cast<float4*>(p.dz + (((size_t)t * p.n_pad + cn[x]) * 2 + dir) * H4 + 4 * cu) = z4;
+      gsum[x].x += z4.x; gsum[x].y += z4.y; gsum[x].z += z4.z; gsum[x].w += z4.w;
       // power-of-two scale of this batch column: max over its 16 threads (one DPP row)
       float m = fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w)));
       zmax = fmaxf(zmax, m);
@@ -1833,6 +1903,12 @@ __device__ __forceinline__ void bwd_body_h2(const LstmParams& p, int pair, int c
 #pragma unroll
   for (int x = 0; x < 2; ++x)
     p.dc_state[((size_t)dir * p.n_pad + cn[x]) * H + cu] = dc[x];
+  if (p.db_part) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+      tile_gate_sums(gsum[x], lds, p.db_part + ((size_t)(2 * q + x) * 2 + dir) * H4 + 64 * cw,
+                     p.s_begin > 0);
+  }
   if (p.dz_absmax) {
     zmax = asr_wave_max(zmax);
     if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
@@ -1849,6 +1925,295 @@ lstm_bwd_kernel_h2(LstmParams p) {
   const bool fast = chain_on_one_xcd(p, pair, cw, reinterpret_cast<int*>(lds));
   if (fast) bwd_body_h2<TPW, true, PLACE>(p, pair, cw, lds);
   else bwd_body_h2<TPW, false, PLACE>(p, pair, cw, lds);
+}
+
+// ---------------------------------------------------------------------------
+// backward, split-fp16, third generation (plain cell, H = 256 / 512, persistent mode): the
+// default BPTT kernel.  NT = 2: two batch tiles per workgroup as bwd_body_h2 (a tile's gather
+// is in flight during the other tile's phase); NT = 1: one tile, gather issued right after the
+// publish.  What changed against bwd_body_h / _h2 (static count of one step at H = 512: about
+// 1900 instructions -> about 700):
+//  * the MFMAs are inline asm with the U^T fragments as AGPR operands and the results in
+//    VGPRs.  With the builtin hipcc keeps the 128 stationary fragment registers of TPW = 8 in
+//    VGPRs, accumulates into AGPRs and, short of VGPRs, parks the gathered words in AGPRs too:
+//    ~640 v_accvgpr_read/write per step, every one on the critical path of a wave that is
+//    alone on its SIMD.  (Wait states the compiler cannot pad are inside the asm string.)
+//  * tag test = OR-reduction of (word ^ -tag) and ONE compare per lane, one ballot per wave,
+//    instead of a compare per word whose lane masks met in ~75 dependent scalar operations;
+//  * the gathered words are added WITH their tag bit (<= 1 ulp, as clearing it was);
+//  * no branch around any vector-memory instruction in the steady loop, gather offsets as
+//    immediates of one base register;
+//  * the bias gradient (sum over samples and steps of dz) is accumulated in registers and
+//    leaves as per-tile partial sums (LstmParams::db_part): no pass over the dz slab after it.
+// Arithmetic: products and summation order of a (sample, unit) are the same for NT = 1 and 2,
+// for sliced and whole sequences and for both transports.
+template <int TPW, bool FAST, int NT, int PLACE>
+__device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw, float* lds) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, nl = lane & 15;
+  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
+  const int P = p.P;                               // == 4 * TPW here
+  const int per_dir = NT == 2 ? (p.NB >> 1) : p.NB;
+  const int dir = unit / per_dir, bt0 = NT * (unit % per_dir);
+  constexpr int DZH = 72;                         // LDS row stride of the dz tiles (halfs)
+  constexpr int kTileFloats = 16 + (2 * 16 * DZH) / 2;        // sinv + hi + lo, in floats
+  // NT = 2: one dz tile buffer per batch tile (a wave that rewrites tile x's buffer has passed
+  // the other tile's barrier, which every wave reaches only after its MFMA reads of this
+  // buffer); NT = 1: two buffers by step parity (the one barrier per step keeps the waves at
+  // most one step apart)
+
+  f32x4 ufh[TPW][2], ufl[TPW][2];                  // bit patterns of 8 halfs each (AGPRs)
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int krow = 16 * (w + 4 * i) + nl;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      h8 hv, lv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 64 * cw + 32 * kk + 8 * g + e;
+        _Float16 hi, lo;
+        split_f16(p.U[((size_t)(dir * H + krow)) * H4 + j], hi, lo);
+        hv[e] = hi; lv[e] = lo;
+      }
+      ufh[i][kk] = __builtin_bit_cast(f32x4, hv);
+      ufl[i][kk] = __builtin_bit_cast(f32x4, lv);
+      // from here on the fragments are AGPR-class values (defined by an asm "a" operand),
+      // so the MFMA statements read them in place instead of copying them in per use
+      asm volatile("" : "+a"(ufh[i][kk]), "+a"(ufl[i][kk]));
+    }
+  }
+  const int cu = 16 * cw + (tid & 15);
+  const int s_end = p.s_begin + p.s_count;
+  const size_t slot_words = (size_t)P * P * 256;
+  int cn[NT];
+  float cmask[NT], dc[NT];
+  float4 gsum[NT];
+  unsigned* xch[NT];
+#pragma unroll
+  for (int x = 0; x < NT; ++x) {
+    const int bt = bt0 + x;
+    cn[x] = bt * 16 + (tid >> 4);
+    cmask[x] = p.mask_u ? p.mask_u[((size_t)dir * p.n_pad + cn[x]) * H + cu] : 1.f;
+    dc[x] = p.s_begin > 0 ? p.dc_state[((size_t)dir * p.n_pad + cn[x]) * H + cu] : 0.f;
+    xch[x] = p.xbuf + (size_t)(dir * p.NB + bt) * p.xchain_words;
+    gsum[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float zmax = 0.f;
+  bool dead = false;
+
+  // slab values of the NEXT step of each tile, prefetched one step ahead
+  float nx_dy[NT], nx_c[NT], nx_cp[NT];
+  float4 nx_g[NT];
+  auto load_slabs = [&](int x, int ss) {
+    const int sc = ss < s_end ? ss : s_end - 1;    // past the end: a valid, unused row
+    const int tt = dir == 0 ? p.T - 1 - sc : sc;
+    const bool has_prev = sc + 1 < p.T;            // the sequence's first frame has c_prev = 0
+    const int tcc = has_prev ? (dir == 0 ? tt - 1 : tt + 1) : tt;
+    const size_t row = (size_t)tt * p.n_pad + cn[x];
+    nx_dy[x] = p.dy[row * H2 + dir * H + cu];
+    nx_c[x] = p.cell[(row * 2 + dir) * H + cu];
+    const float cp = p.cell[(((size_t)tcc * p.n_pad + cn[x]) * 2 + dir) * H + cu];
+    nx_cp[x] = has_prev ? cp : 0.f;
+    nx_g[x] = *reinterpret_cast<const float4*>(p.gates + (row * 2 + dir) * H4 + 4 * cu);
+  };
+#pragma unroll
+  for (int x = 0; x < NT; ++x) load_slabs(x, p.s_begin);
+
+  // Lane (sample = lane>>4 of this wave's four, unit quad = (lane>>2)&3, sub = lane&3)
+  // gathers the 16-byte group (sample, quad) of the partial dh tiles of producers
+  // sub*TPW+i (1 KB apart: immediates of one offset register); summed in registers, then
+  // over the four `sub` lanes with DPP quad permutes.
+  constexpr int NL = TPW;
+  const int sub = lane & 3;
+  const unsigned goff = (unsigned)(((sub * TPW) * 64 + (4 * w + (lane >> 4)) * 4 +
+                                    ((lane >> 2) & 3)) * 16);
+  u32x4 v[NT][NL];
+  // this workgroup's region of the slot that holds the partial tiles of step `ss`, tile x
+  auto rslot = [&](int x, int ss) -> __amdgpu_buffer_rsrc_t {
+    return __builtin_amdgcn_make_buffer_rsrc(
+        xch[x] + (size_t)(ss & 1) * slot_words + (size_t)cw * P * 256, 0, P * 256 * 4, 0x00020000);
+  };
+  auto load_groups = [&](int x, const __amdgpu_buffer_rsrc_t& rsrc) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      v[x][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff, i * 1024, FAST ? kNt : kSc1);
+  };
+  auto issue = [&](int x, int ss) {
+    for (int i = 0; i < p.prepoll; ++i) __builtin_amdgcn_s_sleep(1);
+    load_groups(x, rslot(x, ss));
+  };
+  // waits until every gathered word of tile x carries `tag` (re-reading the stale lanes' groups)
+  auto await = [&](int x, int ss, unsigned tag) {
+    const unsigned flip = 0u - tag;
+    bool stale = !all_tagged<NL>(v[x], flip);
+    if (__builtin_amdgcn_ballot_w64(stale) == 0ull) return;
+    if (!p.poll || dead) return;
+    const __amdgpu_buffer_rsrc_t rsrc = rslot(x, ss);
+    const long long t0 = wall_clock64();
+    bool gave_up = false;
+    while (stale) {
+      for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
+      load_groups(x, rsrc);
+      stale = !all_tagged<NL>(v[x], flip);
+      if (stale && wall_clock64() - t0 > kSpinTicks) { gave_up = true; break; }
+    }
+    if (__builtin_amdgcn_ballot_w64(gave_up) != 0ull) {
+      dead = true;
+      if (gave_up) mark_timeout(p.status);
+    }
+  };
+
+  // everything of one step of tile x after its recurrent gradient dh_rec is known: cell
+  // gradient, dz slab + LDS tile, barrier, partial dh tiles = U^T-slice x dz, publish.
+  // ISSUE: whether a gather (tile ox, tiles of step os) is issued on the way.
+  auto tail = [&](auto xc, auto issue_c, int s, float dh_rec, int os) {
+    constexpr int x = decltype(xc)::value;
+    constexpr int ox = NT == 2 ? 1 - x : x;
+    constexpr bool ISSUE = decltype(issue_c)::value;
+    float* sinv = lds + (size_t)(NT == 2 ? x : (s & 1)) * kTileFloats;   // [16] 1/scale
+    _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZH] hi
+    _Float16* dzl = dzh + 16 * DZH;                           // [16][DZH] lo
+    const int t = dir == 0 ? p.T - 1 - s : s;
+    {
+      const float4 gt = nx_g[x];
+      const float dyv = nx_dy[x], cv = nx_c[x], cpv = nx_cp[x];
+      load_slabs(x, s + 1);
+      const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
+      const float dh = dyv + cmask[x] * dh_rec;
+      const float tch = fast_tanh(cv);
+      const float d_o = dh * tch;
+      const float dcc = dc[x] + dh * go * (1.f - tch * tch);
+      const float d_i = dcc * gg, d_g = dcc * gi, d_f = dcc * cpv;
+      dc[x] = dcc * gf;
+      float4 z4;
+      z4.x = d_i * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
+      z4.y = d_f * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
+      z4.z = d_g * (1.f - gg * gg);
+      z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
+      *reinterpret_cast<float4*>(p.dz + (((size_t)t * p.n_pad + cn[x]) * 2 + dir) * H4 + 4 * cu) = z4;
+      gsum[x].x += z4.x; gsum[x].y += z4.y; gsum[x].z += z4.z; gsum[x].w += z4.w;
+      // power-of-two scale of this batch column: max over its 16 threads (one DPP row)
+      float m = fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w)));
+      zmax = fmaxf(zmax, m);
+      m = row16_max(m);
+      int ex = 0;
+      if (m > 0.f) (void)frexpf(m, &ex); else ex = 9;
+      ex = ex < -100 ? -100 : ex;                 // keep 2^(9-ex) finite for denormal maxima
+      const float sc = ldexpf(1.f, 9 - ex);
+      if ((tid & 15) == 0) sinv[tid >> 4] = ldexpf(1.f, ex - 9);
+      h4 hi4, lo4;
+      _Float16 a, b;
+      split_f16(z4.x * sc, a, b); hi4[0] = a; lo4[0] = b;
+      split_f16(z4.y * sc, a, b); hi4[1] = a; lo4[1] = b;
+      split_f16(z4.z * sc, a, b); hi4[2] = a; lo4[2] = b;
+      split_f16(z4.w * sc, a, b); hi4[3] = a; lo4[3] = b;
+      *reinterpret_cast<h4*>(dzh + (tid >> 4) * DZH + 4 * (tid & 15)) = hi4;
+      *reinterpret_cast<h4*>(dzl + (tid >> 4) * DZH + 4 * (tid & 15)) = lo4;
+    }
+    if (ISSUE && NT == 2 && PLACE == 3) issue(ox, os);
+    __syncthreads();
+    if (ISSUE && NT == 2 && PLACE == 1) issue(ox, os);
+    {
+      h8 bh[2], bl[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bh[kk] = *reinterpret_cast<const h8*>(dzh + nl * DZH + 32 * kk + 8 * g);
+        bl[kk] = *reinterpret_cast<const h8*>(dzl + nl * DZH + 32 * kk + 8 * g);
+      }
+      const float us = sinv[nl];
+      const float usl = us * (1.f / kLoScale);
+      const unsigned wtag = (unsigned)(s >> 1) & 1u;
+      // (the last step's tiles are published too: nobody reads them, and no branch is needed)
+      const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+          xch[x] + (size_t)(s & 1) * slot_words, 0, (unsigned)(slot_words * 4), 0x00020000);
+      const unsigned soff = (unsigned)((((size_t)w * P + cw) * 256 + nl * 16 + 4 * g) * 4);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        f32x4 am, ac;
+        mfma_hl_tile(am, ac, ufh[i][0], ufl[i][0], ufh[i][1], ufl[i][1], bh[0], bl[0], bh[1],
+                     bl[1]);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = tag_word(__builtin_fmaf(ac[e], usl, am[e] * us), wtag);
+        // partial tile of the output units 16 (w + 4 i) ..: 4 P KB apart
+        __builtin_amdgcn_raw_buffer_store_b128(o, wr, soff, i * (4 * P * 1024), FAST ? 0 : kSc1);
+      }
+    }
+    if (ISSUE && (NT == 1 || PLACE == 2)) issue(ox, os);
+  };
+  // one phase = one step (s >= 1) of tile x: finish its gather, reduce, then `tail`.
+  auto phase = [&](auto xc, int s) {
+    constexpr int x = decltype(xc)::value;
+    await(x, s - 1, (unsigned)((s - 1) >> 1) & 1u);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      acc.x += __uint_as_float(v[x][i][0]); acc.y += __uint_as_float(v[x][i][1]);
+      acc.z += __uint_as_float(v[x][i][2]); acc.w += __uint_as_float(v[x][i][3]);
+    }
+    acc.x += quad_swap1(acc.x); acc.y += quad_swap1(acc.y);
+    acc.z += quad_swap1(acc.z); acc.w += quad_swap1(acc.w);
+    acc.x += quad_swap2(acc.x); acc.y += quad_swap2(acc.y);
+    acc.z += quad_swap2(acc.z); acc.w += quad_swap2(acc.w);
+    const float dh_rec = sub == 0 ? acc.x : sub == 1 ? acc.y : sub == 2 ? acc.z : acc.w;
+    // the gather issued on the way: NT = 2: phase of tile 0 -> tile 1's tiles of step s-1
+    // (consumed later in this iteration), phase of tile 1 -> tile 0's of step s; NT = 1: this
+    // tile's of step s (after the last step a harmless unused read)
+    tail(xc, std::true_type{}, s, dh_rec, (NT == 2 && x == 0) ? s - 1 : s);
+  };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  int s = p.s_begin;
+  if (s == 0) {
+    // step 0: no recurrent gradient yet, nothing to gather
+    tail(T0{}, std::false_type{}, 0, 0.f, 0);
+    if constexpr (NT == 2) tail(T1{}, std::false_type{}, 0, 0.f, 0);
+    s = 1;
+  }
+  // (first phase peeled so that every gather the loop waits for was issued by the same
+  // code sequence)
+  if (s < s_end) {
+    issue(0, s - 1);
+    if constexpr (NT == 2) {
+      phase(T0{}, s);
+      for (;;) {
+        phase(T1{}, s);
+        if (++s >= s_end) break;
+        phase(T0{}, s);
+      }
+    } else {
+      for (; s < s_end; ++s) phase(T0{}, s);
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < NT; ++x)
+    p.dc_state[((size_t)dir * p.n_pad + cn[x]) * H + cu] = dc[x];
+  if (p.db_part) {
+#pragma unroll
+    for (int x = 0; x < NT; ++x)
+      tile_gate_sums(gsum[x], lds, p.db_part + ((size_t)(bt0 + x) * 2 + dir) * H4 + 64 * cw,
+                     p.s_begin > 0);
+  }
+  if (p.dz_absmax) {
+    zmax = asr_wave_max(zmax);
+    if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
+  }
+}
+
+template <int TPW, int NT, int PLACE>
+__global__ void __launch_bounds__(kThreads)
+lstm_bwd_kernel_x(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int unit_local, cw;
+  if (!map_block(p, unit_local, cw)) return;
+  const int unit = p.chain_begin + unit_local;
+  const bool fast = chain_on_one_xcd(p, unit, cw, reinterpret_cast<int*>(lds));
+  if (fast) bwd_body_x<TPW, true, NT, PLACE>(p, unit, cw, lds);
+  else bwd_body_x<TPW, false, NT, PLACE>(p, unit, cw, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -1913,6 +2278,12 @@ kern_t pick_bwd_h2(int tpw, int place) {
                      : place == 2 ? lstm_bwd_kernel_h2<4, 2> : lstm_bwd_kernel_h2<4, 1>;
   return place == 3 ? lstm_bwd_kernel_h2<8, 3>
        : place == 2 ? lstm_bwd_kernel_h2<8, 2> : lstm_bwd_kernel_h2<8, 1>;
+}
+kern_t pick_bwd_x(int tpw, int nt, int place) {
+  if (tpw <= 4) return nt == 1 ? lstm_bwd_kernel_x<4, 1, 1>
+                     : place == 3 ? lstm_bwd_kernel_x<4, 2, 3> : lstm_bwd_kernel_x<4, 2, 1>;
+  return nt == 1 ? lstm_bwd_kernel_x<8, 1, 1>
+       : place == 3 ? lstm_bwd_kernel_x<8, 2, 3> : lstm_bwd_kernel_x<8, 2, 1>;
 }
 kern_t pick_bwd_h(int tpw) {
   switch (tpw) {
@@ -2005,11 +2376,21 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 72 * 2);
       const bool variants = a->mi || a->zone_c || a->zone_h;
       k = variants ? pick_bwd_hv(pl.TPW) : pick_bwd_h(pl.TPW);
-      // two batch tiles per workgroup (opt-in): plain cell, persistent mode, H = 256 / 512
-      if (!variants && env_int("ASR_LSTM_PAIR_B", 0) && a->mode == 0 &&
-          (a->n_pad / 16) % 2 == 0 && (H == 256 || H == 512)) {
+      // plain cell, persistent mode, H = 256 / 512: the third-generation kernel
+      // (ASR_LSTM_BWD_GEN: 3 = bwd_body_x (default), 2 = bwd_body_h2 when paired, 1 = bwd_body_h),
+      // with two batch tiles per workgroup when the tile count is even (ASR_LSTM_PAIR_B=0:
+      // one tile per workgroup)
+      const int gen = env_int("ASR_LSTM_BWD_GEN", 3);
+      const bool wide = !variants && a->mode == 0 && (H == 256 || H == 512);
+      const bool even = (a->n_pad / 16) % 2 == 0;
+      const int pair_b = env_int("ASR_LSTM_PAIR_B", gen >= 3 ? 1 : 0);
+      const int place_b = env_int("ASR_LSTM_PAIR_PLACE_B", 1);
+      if (wide && gen >= 3) {
+        pl.pair = (pair_b && even) ? 1 : 0;
+        k = pick_bwd_x(pl.TPW, pl.pair ? 2 : 1, place_b);
+      } else if (wide && gen == 2 && pair_b && even) {
         pl.pair = 1;
-        k = pick_bwd_h2(pl.TPW, env_int("ASR_LSTM_PAIR_PLACE_B", 1));
+        k = pick_bwd_h2(pl.TPW, place_b);
       }
     }
   }
@@ -2094,6 +2475,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.dz_absmax = bwd ? reinterpret_cast<unsigned*>(a->dz_absmax) : nullptr;
   p.mi = a->mi; p.uh = a->uh; p.zone_c = a->zone_c; p.zone_h = a->zone_h;
   p.wx = a->wx; p.dwx = a->dwx; p.dmi = a->dmi;
+  p.db_part = bwd ? a->db_part : nullptr;
   if (a->mi) {
     ASR_CHECK_ARG(a->uh, "lstm: mi needs the uh slab");
     if (bwd) ASR_CHECK_ARG(a->wx && a->dwx && a->dmi, "lstm bwd: mi needs wx, dwx and dmi");

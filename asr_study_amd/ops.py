@@ -150,7 +150,7 @@ def colsum(X, M, N, ldx, out, beta=0.0, x_off=0, ws_name='colsum'):
 # --------------------------------------------------------------------------- LSTM
 def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=None,
                dy=None, dz=None, mode=0, dz_absmax=None, steps=None, mi=None, uh=None,
-               zone_c=None, zone_h=None, wx=None, dwx=None, dmi=None):
+               zone_c=None, zone_h=None, wx=None, dwx=None, dmi=None, db_part=None):
     a = L.LstmArgs()
     a.T, a.n_pad, a.H, a.mode = int(T), int(n_pad), int(H), int(mode)
     a.step_begin, a.step_count = (0, 0) if steps is None else (int(steps[0]), int(steps[1]))
@@ -158,7 +158,7 @@ def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=No
     for name, t in (('mask_u', mask_u), ('zx', zx), ('y', y), ('cell', cell),
                     ('gates', gates), ('dy', dy), ('dz', dz), ('dz_absmax', dz_absmax),
                     ('mi', mi), ('uh', uh), ('zone_c', zone_c), ('zone_h', zone_h),
-                    ('wx', wx), ('dwx', dwx), ('dmi', dmi)):
+                    ('wx', wx), ('dwx', dwx), ('dmi', dmi), ('db_part', db_part)):
         setattr(a, name, t.data_ptr() if t is not None else None)
     return a
 
@@ -181,12 +181,14 @@ def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=
 
 def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check=False,
                  dz_absmax=None, steps=None, mi=None, uh=None, zone_c=None, zone_h=None,
-                 wx=None, dwx=None, dmi=None):
+                 wx=None, dwx=None, dmi=None, db_part=None):
+    """db_part: optional (n_pad/16, 2, 4H) buffer receiving the per-batch-tile sums of dz over
+    samples and steps (bias-gradient partials; accumulated across the slices of a sequence)."""
     lib = L.load()
     _check_f32(dy, U, cell, gates, dz, mask_u)
     a = _lstm_args(T, n_pad, H, U, mask_u, cell=cell, gates=gates, dy=dy, dz=dz, mode=mode,
                    dz_absmax=dz_absmax, steps=steps, mi=mi, uh=uh, zone_c=zone_c,
-                   zone_h=zone_h, wx=wx, dwx=dwx, dmi=dmi)
+                   zone_h=zone_h, wx=wx, dwx=dwx, dmi=dmi, db_part=db_part)
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 1)
     ws = WS.get('lstm_bwd', nbytes, dy.device)
     L.check(lib.asr_lstm_seq_bwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_bwd')

@@ -195,6 +195,11 @@ typedef struct asr_lstm_args {
   const float* wx;
   float* dwx;
   float* dmi;
+  /* backward, optional: db_part (n_pad/16, 2, 4H) receives, per batch tile, the sum of dz    */
+  /* over the tile's samples and over all steps (+= across the slices of a sequence): the     */
+  /* bias gradient is its sum over axis 0, so no pass over the dz slab is needed for it.      */
+  /* With mi set the same sums are dmi[:, :, 3].                                              */
+  float* db_part;
 } asr_lstm_args;
 size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
 int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,

@@ -401,3 +401,62 @@ def test_layer_normalised_cell(T, N, H, use_mi, use_zone, use_mask):
              c['dln']['new_c'][1]]
         ref = np.concatenate(refs)
         assert report('dparams %s %s' % (d, tag), got_p[di], ref) < gtol * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('N,H', [(32, 256), (64, 512), (16, 512), (48, 256)])
+def test_bptt_kernel_generations_agree_and_emit_bias_gradient(N, H, monkeypatch):
+    """The default BPTT kernel (lstm_bwd_kernel_x: MFMA operands in AGPRs, integer tag test,
+    bias gradient accumulated in registers) against the first-generation one
+    (ASR_LSTM_BWD_GEN=1) on the same activations: gate gradients to 1e-6 of the largest;
+    one tile per workgroup == two tiles per workgroup, sliced == whole, bit for bit;
+    db_part (per-batch-tile sums of dz over samples and steps) == the sums of the dz slab it
+    wrote, from every generation, also when the sequence is processed in slices."""
+    from asr_study_amd import ops
+    T = 45
+    rs = np.random.RandomState(H + N)
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.1).astype(np.float32)).to(dev)
+    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
+    y = torch.zeros(T, n_pad, 2 * H, device=dev)
+    cell = torch.zeros(T, n_pad, 2, H, device=dev)
+    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    ops.lstm_status(ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask))
+
+    def run(ranges):
+        dz = torch.full((T, n_pad, 2, 4 * H), 7.0, device=dev)
+        dbp = torch.full((n_pad // 16, 2, 4 * H), 9.0, device=dev)
+        amax = torch.zeros(1, device=dev)
+        for r in ranges:
+            ws = ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=mask,
+                                  dz_absmax=amax, steps=r, db_part=dbp)
+        ops.lstm_status(ws)
+        want = dz.double().reshape(T, n_pad // 16, 16, 2, 4 * H).sum(dim=(0, 2))
+        err = (dbp.double() - want).abs().max().item()
+        assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+        return dz.cpu().numpy(), amax.cpu().numpy()
+    monkeypatch.setenv('ASR_LSTM_BWD_GEN', '1')
+    want, _ = run([None])
+    run([(0, 20), (20, 25)])
+    if (n_pad // 16) % 2 == 0:
+        monkeypatch.setenv('ASR_LSTM_BWD_GEN', '2')
+        monkeypatch.setenv('ASR_LSTM_PAIR_B', '1')
+        run([(0, 20), (20, 25)])
+    monkeypatch.setenv('ASR_LSTM_BWD_GEN', '3')
+    monkeypatch.setenv('ASR_LSTM_PAIR_B', '0')
+    single, amax = run([None])
+    assert np.abs(single - want).max() < 1e-6 * np.abs(want).max()
+    assert np.abs(single).max() == amax[0]
+    sliced, amax2 = run([(0, 1), (1, 16), (17, 28)])
+    assert np.array_equal(single, sliced) and amax2[0] == amax[0]
+    monkeypatch.setenv('ASR_LSTM_PAIR_B', '1')
+    paired, amax3 = run([None])
+    assert np.array_equal(single, paired) and amax3[0] == amax[0]
+    sliced2, _ = run([(0, 30), (30, 15)])
+    assert np.array_equal(paired, sliced2)
+    for transport in ('0', '1'):
+        monkeypatch.setenv('ASR_LSTM_FAST', transport)
+        again, _ = run([None])
+        assert np.array_equal(paired, again)
