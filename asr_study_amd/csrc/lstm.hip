@@ -659,6 +659,15 @@ lstm_fwd_kernel_hv(LstmParams p) {
   else fwd_body_h<NKK, false, true>(p, chain, wg, lds);
 }
 
+template <int NL>
+__device__ __forceinline__ bool all_tagged(const u32x4 (&v)[NL], unsigned flip) {
+  unsigned x = 0u;
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+    x |= ((v[i][0] ^ flip) | (v[i][1] ^ flip)) | ((v[i][2] ^ flip) | (v[i][3] ^ flip));
+  return (x & 1u) == 0u;
+}
+
 // ---- arithmetic shared by the K-split forward kernels (fwd_body_k / fwd_body_k2), written
 // with contraction off and explicit FMAs so that both round identically: which of the two
 // processed a batch row is then invisible in the result, bit for bit.
@@ -1098,13 +1107,267 @@ lstm_fwd_kernel_k2(LstmParams p) {
 }
 
 // ---------------------------------------------------------------------------
-template <int NL>
-__device__ __forceinline__ bool all_tagged(const u32x4 (&v)[NL], unsigned flip) {
-  unsigned x = 0u;
+// ---------------------------------------------------------------------------
+// forward, split-fp16, K split over the waves, third generation (plain cell, H = 256 / 512,
+// persistent mode): the default forward kernel.  NT = 2: two batch tiles per workgroup as
+// fwd_body_k2; NT = 1: one tile, gather issued right after the publish.  Same changes as in
+// bwd_body_x: MFMAs as inline asm with the stationary U fragments in AGPRs and the results in
+// VGPRs (no v_accvgpr traffic), one OR-reduction + compare per lane as tag test, gathered
+// words used with their tag bit (the LSB of the fp16 `lo` half: 2^-22 relative), no branch
+// around a vector-memory instruction, gather offsets as immediates of one base register.
+// Arithmetic of a (sample, unit) is the same for NT = 1 and 2, sliced or whole, either
+// transport.
+template <int NKW> struct FwdMfma;
+template <> struct FwdMfma<2> {
+  // am = sum_kk Uh[kk] Bh[kk] ; ac = sum_kk (Uh[kk] Bl[kk] + Ul[kk] Bh[kk])
+  static __device__ __forceinline__ void run(f32x4& am, f32x4& ac, const f32x4 (&uh)[2],
+                                             const f32x4 (&ul)[2], const h8 (&bh)[2],
+                                             const h8 (&bl)[2]) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %2, %6, 0\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %2, %8, 0\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %3, %7, %0\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %4, %6, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %3, %9, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %5, %7, %1\n\t"
+        "s_nop 11"
+        : "=&v"(am), "=&v"(ac)
+        : "a"(uh[0]), "a"(uh[1]), "a"(ul[0]), "a"(ul[1]), "v"(bh[0]), "v"(bh[1]), "v"(bl[0]),
+          "v"(bl[1]));
+  }
+};
+template <> struct FwdMfma<4> {
+  static __device__ __forceinline__ void run(f32x4& am, f32x4& ac, const f32x4 (&uh)[4],
+                                             const f32x4 (&ul)[4], const h8 (&bh)[4],
+                                             const h8 (&bl)[4]) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %2, %10, 0\n\t"      // am  = uh0 bh0
+        "v_mfma_f32_16x16x32_f16 %1, %2, %14, 0\n\t"      // ac  = uh0 bl0
+        "v_mfma_f32_16x16x32_f16 %0, %3, %11, %0\n\t"     // am += uh1 bh1
+        "v_mfma_f32_16x16x32_f16 %1, %6, %10, %1\n\t"     // ac += ul0 bh0
+        "v_mfma_f32_16x16x32_f16 %0, %4, %12, %0\n\t"     // am += uh2 bh2
+        "v_mfma_f32_16x16x32_f16 %1, %3, %15, %1\n\t"     // ac += uh1 bl1
+        "v_mfma_f32_16x16x32_f16 %0, %5, %13, %0\n\t"     // am += uh3 bh3
+        "v_mfma_f32_16x16x32_f16 %1, %7, %11, %1\n\t"     // ac += ul1 bh1
+        "v_mfma_f32_16x16x32_f16 %1, %4, %16, %1\n\t"     // ac += uh2 bl2
+        "v_mfma_f32_16x16x32_f16 %1, %8, %12, %1\n\t"     // ac += ul2 bh2
+        "v_mfma_f32_16x16x32_f16 %1, %5, %17, %1\n\t"     // ac += uh3 bl3
+        "v_mfma_f32_16x16x32_f16 %1, %9, %13, %1\n\t"     // ac += ul3 bh3
+        "s_nop 11"
+        : "=&v"(am), "=&v"(ac)
+        : "a"(uh[0]), "a"(uh[1]), "a"(uh[2]), "a"(uh[3]), "a"(ul[0]), "a"(ul[1]), "a"(ul[2]),
+          "a"(ul[3]), "v"(bh[0]), "v"(bh[1]), "v"(bh[2]), "v"(bh[3]), "v"(bl[0]), "v"(bl[1]),
+          "v"(bl[2]), "v"(bl[3]));
+  }
+};
+
+template <int NKW, bool FAST, int NT, int PLACE>
+__device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg, float* lds) {
+  // Requires H == 128 * NKW (every lane's gather groups and units exist)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, nl = lane & 15;
+  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
+  const int UG = H >> 2;
+  const int per_dir = NT == 2 ? (p.NB >> 1) : p.NB;
+  const int dir = unit / per_dir, bt0 = NT * (unit % per_dir);
+  const int ug = wg * 4 + w;                       // the unit group this wave FINISHES
+  const int u = 4 * ug + g;
+  const int kbase = 32 * NKW * w;                  // first unit of this wave's K slice
+  f32x4* part = reinterpret_cast<f32x4*>(lds);     // [2 bufs][4 waves][4 gate tiles][64 lanes]
+
+  f32x4 ufh[4][NKW], ufl[4][NKW];                  // bit patterns of 8 halfs each (AGPRs)
 #pragma unroll
-  for (int i = 0; i < NL; ++i)
-    x |= ((v[i][0] ^ flip) | (v[i][1] ^ flip)) | ((v[i][2] ^ flip) | (v[i][3] ^ flip));
-  return (x & 1u) == 0u;
+  for (int j = 0; j < 4; ++j) {
+    const int ugj = wg * 4 + j;
+#pragma unroll
+    for (int kk = 0; kk < NKW; ++kk) {
+      h8 hv, lv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = kbase + 32 * kk + 8 * g + e;
+        _Float16 hi, lo;
+        split_f16(p.U[((size_t)(dir * H + k)) * H4 + 16 * ugj + nl], hi, lo);
+        hv[e] = hi; lv[e] = lo;
+      }
+      ufh[j][kk] = __builtin_bit_cast(f32x4, hv);
+      ufl[j][kk] = __builtin_bit_cast(f32x4, lv);
+      asm volatile("" : "+a"(ufh[j][kk]), "+a"(ufl[j][kk]));   // AGPR-class from here on
+    }
+  }
+  const int slot_words = UG * (p.xstride / 4);
+  const int s_end = p.s_begin + p.s_count;
+  int n[NT];
+  float mask[NT], c[NT];
+  unsigned* xch[NT];
+#pragma unroll
+  for (int x = 0; x < NT; ++x) {
+    const int bt = bt0 + x;
+    n[x] = bt * 16 + nl;
+    mask[x] = p.mask_u ? p.mask_u[((size_t)dir * p.n_pad + n[x]) * H + u] : 1.f;
+    c[x] = 0.f;
+    xch[x] = p.xbuf + (size_t)(dir * p.NB + bt) * p.xchain_words;
+    if (p.s_begin > 0) {
+      const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
+      c[x] = p.cell[(((size_t)tpp * p.n_pad + n[x]) * 2 + dir) * H + u];
+    }
+  }
+  auto load_zx = [&](int x, int ss) -> float4 {
+    const int sc = ss < s_end ? ss : s_end - 1;    // past the end: a valid, unused row
+    const int tt = dir == 0 ? sc : p.T - 1 - sc;
+    return *reinterpret_cast<const float4*>(
+        p.zx + (((size_t)tt * p.n_pad + n[x]) * 2 + dir) * H4 + 4 * u);
+  };
+  float4 zx_next[NT];
+#pragma unroll
+  for (int x = 0; x < NT; ++x) zx_next[x] = load_zx(x, p.s_begin);
+  // group i = (kk, half): units kbase + 32 kk + 8 g + 4 half .. +3 of sample nl; consecutive
+  // groups are xstride bytes apart ((kk, half) -> unit group + 2 kk' + half with kk' = 4 kk)
+  constexpr int NL = 2 * NKW;
+  const unsigned goff = (unsigned)(((kbase + 8 * g) / 4) * p.xstride + nl * 16);
+  const unsigned gstep = (unsigned)p.xstride;      // between the two halves of a kk
+  bool dead = false;
+  u32x4 v[NT][NL];
+  // the exchange slot holding h of step `ss` of tile x
+  auto slot = [&](int x, int ss) -> __amdgpu_buffer_rsrc_t {
+    return __builtin_amdgcn_make_buffer_rsrc(xch[x] + (size_t)(ss & 1) * slot_words, 0,
+                                             slot_words * 4, 0x00020000);
+  };
+  auto load_groups = [&](int x, const __amdgpu_buffer_rsrc_t& rsrc) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      v[x][i] = __builtin_amdgcn_raw_buffer_load_b128(
+          rsrc, goff, (unsigned)((8 * (i >> 1) + (i & 1))) * gstep, FAST ? kNt : kSc1);
+  };
+  auto issue = [&](int x, int ss) {
+    for (int i = 0; i < p.prepoll; ++i) __builtin_amdgcn_s_sleep(1);
+    load_groups(x, slot(x, ss));
+  };
+  auto await = [&](int x, int ss, unsigned tag) {
+    const unsigned flip = 0u - tag;
+    bool stale = !all_tagged<NL>(v[x], flip);
+    if (__builtin_amdgcn_ballot_w64(stale) == 0ull) return;
+    if (!p.poll || dead) return;
+    const __amdgpu_buffer_rsrc_t rsrc = slot(x, ss);
+    const long long t0 = wall_clock64();
+    bool gave_up = false;
+    while (stale) {
+      for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
+      load_groups(x, rsrc);
+      stale = !all_tagged<NL>(v[x], flip);
+      if (stale && wall_clock64() - t0 > kSpinTicks) { gave_up = true; break; }
+    }
+    if (__builtin_amdgcn_ballot_w64(gave_up) != 0ull) {
+      dead = true;
+      if (gave_up) mark_timeout(p.status);
+    }
+  };
+  // cell update of tile x at step s from the recurrent contribution `a`; publishes h
+  auto finish_step = [&](int x, int s, const f32x4& a, const float4& zx4) {
+    const int t = dir == 0 ? s : p.T - 1 - s;
+    const CellFwd o = cell_forward(a, zx4, c[x], mask[x]);
+    c[x] = o.c;
+    const unsigned w0 = packed_word(o.hm, (unsigned)(s >> 1) & 1u);
+    // (the last step's word is published too: nobody reads it, and no branch is needed)
+    __builtin_amdgcn_raw_buffer_store_b32(w0, slot(x, s),
+                                          (unsigned)(ug * p.xstride + nl * 16 + g * 4), 0,
+                                          FAST ? 0 : kSc1);
+    const size_t row = (size_t)t * p.n_pad + n[x];
+    p.y[row * H2 + dir * H + u] = o.h;
+    p.cell[(row * 2 + dir) * H + u] = c[x];
+    *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
+        make_float4(o.gi, o.gf, o.gg, o.go);
+  };
+  // one phase = one step (s >= 1) of tile x
+  auto phase = [&](auto xc, int s) {
+    constexpr int x = decltype(xc)::value;
+    constexpr int ox = NT == 2 ? 1 - x : x;
+    const int os = (NT == 2 && x == 0) ? s - 1 : s;
+    const float4 zx4 = zx_next[x];
+    await(x, s - 1, (unsigned)((s - 1) >> 1) & 1u);
+    zx_next[x] = load_zx(x, s + 1);
+    // exchanged word = fp16 hi << 16 | fp16 lo (tag = LSB of lo, left in place)
+    h8 bh[NKW], bl[NKW];
+#pragma unroll
+    for (int kk = 0; kk < NKW; ++kk) {
+      const u32x4 q0 = v[x][2 * kk], q1 = v[x][2 * kk + 1];
+      u32x4 hi, lo;
+      hi[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x07060302u);
+      hi[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x07060302u);
+      hi[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x07060302u);
+      hi[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x07060302u);
+      lo[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x05040100u);
+      lo[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x05040100u);
+      lo[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x05040100u);
+      lo[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x05040100u);
+      bh[kk] = __builtin_bit_cast(h8, hi);
+      bl[kk] = __builtin_bit_cast(h8, lo);
+    }
+    if (NT == 2 && PLACE == 0) issue(ox, os);
+    // NT = 2: one LDS buffer per tile (a wave that writes tile x again has passed the other
+    // tile's barrier, which every wave reaches only after its reads of this buffer); NT = 1:
+    // two buffers by step parity
+    const int buf = NT == 2 ? x : (s & 1);
+    f32x4* mine = part + ((size_t)buf * 4 + w) * 4 * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 am, ac;
+      FwdMfma<NKW>::run(am, ac, ufh[j], ufl[j], bh, bl);
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(ac[e], 1.f / kLoScale, am[e]);
+      mine[j * 64 + lane] = r;
+    }
+    if (NT == 2 && PLACE == 3) issue(ox, os);
+    __syncthreads();
+    const f32x4* all = part + (size_t)buf * 4 * 4 * 64 + (size_t)w * 64 + lane;
+    const f32x4 a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
+    if (NT == 2 && PLACE == 1) issue(ox, os);
+    finish_step(x, s, a, zx4);
+    if (NT == 1 || PLACE == 2) issue(ox, os);
+  };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  int s = p.s_begin;
+  if (s == 0) {
+    // step 0: h_prev = 0, nothing to gather
+#pragma unroll
+    for (int x = 0; x < NT; ++x) {
+      const float4 zx4 = zx_next[x];
+      zx_next[x] = load_zx(x, 1);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      finish_step(x, 0, zero, zx4);
+    }
+    s = 1;
+  }
+  if (s < s_end) {
+    issue(0, s - 1);
+    if constexpr (NT == 2) {
+      phase(T0{}, s);
+      for (;;) {
+        phase(T1{}, s);
+        if (++s >= s_end) break;
+        phase(T0{}, s);
+      }
+    } else {
+      for (; s < s_end; ++s) phase(T0{}, s);
+    }
+  }
+}
+
+template <int NKW, int NT, int PLACE>
+__global__ void __launch_bounds__(kThreads)
+lstm_fwd_kernel_x(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int unit_local, wg;
+  if (!map_block(p, unit_local, wg)) return;
+  const int unit = p.chain_begin + unit_local;
+  const bool fast = chain_on_one_xcd(p, unit, wg, reinterpret_cast<int*>(lds));
+  if (fast) fwd_body_x<NKW, true, NT, PLACE>(p, unit, wg, lds);
+  else fwd_body_x<NKW, false, NT, PLACE>(p, unit, wg, lds);
 }
 
 // am = Uh0*Bh0 + Uh1*Bh1 ; ac = Uh0*Bl0 + Ul0*Bh0 + Uh1*Bl1 + Ul1*Bh1 (K = 2 x 32), i.e.
@@ -2273,6 +2536,14 @@ kern_t pick_fwd_k2(int nkk, int place) {
        : place == 1 ? lstm_fwd_kernel_k2<4, 1>
        : place == 3 ? lstm_fwd_kernel_k2<4, 3> : lstm_fwd_kernel_k2<4, 2>;
 }
+kern_t pick_fwd_x(int nkk, int nt, int place) {
+  if (nkk <= 8) return nt == 1 ? lstm_fwd_kernel_x<2, 1, 1>
+                     : place == 0 ? lstm_fwd_kernel_x<2, 2, 0>
+                     : place == 3 ? lstm_fwd_kernel_x<2, 2, 3> : lstm_fwd_kernel_x<2, 2, 1>;
+  return nt == 1 ? lstm_fwd_kernel_x<4, 1, 1>
+       : place == 0 ? lstm_fwd_kernel_x<4, 2, 0>
+       : place == 3 ? lstm_fwd_kernel_x<4, 2, 3> : lstm_fwd_kernel_x<4, 2, 1>;
+}
 kern_t pick_bwd_h2(int tpw, int place) {
   if (tpw <= 4) return place == 3 ? lstm_bwd_kernel_h2<4, 3>
                      : place == 2 ? lstm_bwd_kernel_h2<4, 2> : lstm_bwd_kernel_h2<4, 1>;
@@ -2354,10 +2625,19 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
         k = pick_fwd_k(pl.NKK);
         // two batch tiles per workgroup (ASR_LSTM_PAIR=0 disables): persistent mode, an
         // even number of tiles, every lane's gather groups and units present
-        if (env_int("ASR_LSTM_PAIR", 1) && a->mode == 0 && (a->n_pad / 16) % 2 == 0 &&
-            (H == 256 || H == 512)) {
+        // ASR_LSTM_FWD_GEN: 3 = fwd_body_x (default: one or two tiles per workgroup),
+        // 2 = fwd_body_k2 when paired, 1 = fwd_body_k
+        const int gen = env_int("ASR_LSTM_FWD_GEN", 3);
+        const bool wide = a->mode == 0 && (H == 256 || H == 512);
+        const bool even = (a->n_pad / 16) % 2 == 0;
+        const int pair_f = env_int("ASR_LSTM_PAIR", 1);
+        const int place_f = env_int("ASR_LSTM_PAIR_PLACE", 1);
+        if (wide && gen >= 3) {
+          pl.pair = (pair_f && even) ? 1 : 0;
+          k = pick_fwd_x(pl.NKK, pl.pair ? 2 : 1, place_f);
+        } else if (wide && gen == 2 && pair_f && even) {
           pl.pair = 1;
-          k = pick_fwd_k2(pl.NKK, env_int("ASR_LSTM_PAIR_PLACE", 1));
+          k = pick_fwd_k2(pl.NKK, place_f);
         }
       }
     }
@@ -2378,12 +2658,12 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       k = variants ? pick_bwd_hv(pl.TPW) : pick_bwd_h(pl.TPW);
       // plain cell, persistent mode, H = 256 / 512: the third-generation kernel
       // (ASR_LSTM_BWD_GEN: 3 = bwd_body_x (default), 2 = bwd_body_h2 when paired, 1 = bwd_body_h),
-      // with two batch tiles per workgroup when the tile count is even (ASR_LSTM_PAIR_B=0:
-      // one tile per workgroup)
+      // one batch tile per workgroup; ASR_LSTM_PAIR_B=1: two when the tile count is even
+      // (measured slower: 2.70 vs 1.75 us per step at H = 256, 5.5 vs 3.35 at H = 512)
       const int gen = env_int("ASR_LSTM_BWD_GEN", 3);
       const bool wide = !variants && a->mode == 0 && (H == 256 || H == 512);
       const bool even = (a->n_pad / 16) % 2 == 0;
-      const int pair_b = env_int("ASR_LSTM_PAIR_B", gen >= 3 ? 1 : 0);
+      const int pair_b = env_int("ASR_LSTM_PAIR_B", 0);
       const int place_b = env_int("ASR_LSTM_PAIR_PLACE_B", 1);
       if (wide && gen >= 3) {
         pl.pair = (pair_b && even) ? 1 : 0;

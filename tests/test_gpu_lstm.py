@@ -404,8 +404,9 @@ def test_layer_normalised_cell(T, N, H, use_mi, use_zone, use_mask):
 
 
 @pytest.mark.parametrize('N,H', [(32, 256), (64, 512), (16, 512), (48, 256)])
-def test_bptt_kernel_generations_agree_and_emit_bias_gradient(N, H, monkeypatch):
-    """The default BPTT kernel (lstm_bwd_kernel_x: MFMA operands in AGPRs, integer tag test,
+def test_recurrent_kernel_generations_agree_and_bptt_emits_bias_gradient(N, H, monkeypatch):
+    """Forward: the default kernel (lstm_fwd_kernel_x) against the first-generation one, one
+    tile per workgroup == two, sliced == whole, both transports, bit for bit.  The default BPTT kernel (lstm_bwd_kernel_x: MFMA operands in AGPRs, integer tag test,
     bias gradient accumulated in registers) against the first-generation one
     (ASR_LSTM_BWD_GEN=1) on the same activations: gate gradients to 1e-6 of the largest;
     one tile per workgroup == two tiles per workgroup, sliced == whole, bit for bit;
@@ -420,10 +421,32 @@ def test_bptt_kernel_generations_agree_and_emit_bias_gradient(N, H, monkeypatch)
     U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
     dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.1).astype(np.float32)).to(dev)
     mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
-    y = torch.zeros(T, n_pad, 2 * H, device=dev)
-    cell = torch.zeros(T, n_pad, 2, H, device=dev)
-    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
-    ops.lstm_status(ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask))
+    def fwd(ranges):
+        y = torch.full((T, n_pad, 2 * H), 3.0, device=dev)
+        cell = torch.full((T, n_pad, 2, H), 3.0, device=dev)
+        gates = torch.full((T, n_pad, 2, 4 * H), 3.0, device=dev)
+        for r in ranges:
+            ws = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask, steps=r)
+        ops.lstm_status(ws)
+        return y, cell, gates
+    # forward: first generation vs the default kernel (lstm_fwd_kernel_x), one / two tiles per
+    # workgroup, sliced, both transports
+    monkeypatch.setenv('ASR_LSTM_FWD_GEN', '1')
+    want_f = [t.cpu().numpy() for t in fwd([None])]
+    monkeypatch.setenv('ASR_LSTM_FWD_GEN', '3')
+    monkeypatch.setenv('ASR_LSTM_PAIR', '0')
+    y, cell, gates = fwd([None])
+    got_f = [t.cpu().numpy() for t in (y, cell, gates)]
+    for a, b in zip(got_f, want_f):
+        assert np.abs(a - b).max() < 2e-6 * max(1.0, np.abs(b).max())
+    for pair, ranges, transport in (('0', [(0, 1), (1, 16), (17, 28)], '1'), ('1', [None], '1'),
+                                    ('1', [(0, 30), (30, 15)], '0'), ('0', [None], '0')):
+        monkeypatch.setenv('ASR_LSTM_PAIR', pair)
+        monkeypatch.setenv('ASR_LSTM_FAST', transport)
+        for a, b in zip([t.cpu().numpy() for t in fwd(ranges)], got_f):
+            assert np.array_equal(a, b), (pair, ranges, transport)
+    monkeypatch.delenv('ASR_LSTM_PAIR')
+    monkeypatch.delenv('ASR_LSTM_FAST')
 
     def run(ranges):
         dz = torch.full((T, n_pad, 2, 4 * H), 7.0, device=dev)

@@ -3,7 +3,7 @@
 its own run, MI355X_MICROARCH.md "rocprofv3 PMC slots").  Counter unit: KiB-ish "kilobytes"
 as rocprofv3 reports them; the gfx950 correction from the guide's HBM section (FETCH_SIZE
 tallies 128-B requests at 64 B for wide coalesced reads) is applied as a x2 column.
-Usage: summarize_pmc.py <dir_with_pmc_FETCH_SIZE_and_pmc_WRITE_SIZE> <out.md> [steps]"""
+Usage: summarize_pmc.py <dir_with_pmc_FETCH_SIZE_and_pmc_WRITE_SIZE> <out.md> [config]"""
 import collections
 import csv
 import os
@@ -29,11 +29,12 @@ def load(d, counter):
 
 def main():
     d, out = sys.argv[1:3]
+    config = sys.argv[3] if len(sys.argv) > 3 else 'cfg2'
     rd, wr = load(d, 'FETCH_SIZE'), load(d, 'WRITE_SIZE')
     names = sorted(set(rd) | set(wr), key=lambda k: -(sum(rd.get(k, [0])) * 2 + sum(wr.get(k, [0]))))
     lines = ['# HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs)',
              '', 'Command: `rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python bench.py '
-             '--steps 3 --warmup 1 --no-cpu-baseline` (cfg2).  MB = counter kilobytes / 1000.',
+             '--steps 3 --warmup 1 --no-cpu-baseline --no-extras` (%s).  MB = counter kilobytes / 1000.' % config,
              '"fetch x2" applies the gfx950 correction for wide coalesced reads; writes are '
              'uncalibrated (taken as reported).', '',
              '| kernel | launches | fetch MB | fetch x2 MB | write MB | traffic MB (fetch x2 + write) |',
