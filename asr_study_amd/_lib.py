@@ -38,6 +38,26 @@ class GemmArgs(C.Structure):
                 ('a_absmax', void_p), ('b_absmax', void_p)]
 
 
+class PackArgs(C.Structure):
+    _fields_ = [('src', void_p), ('rows', C.c_int), ('cols', C.c_int), ('ld', C.c_int),
+                ('mask', void_p), ('mask_period', C.c_int), ('mask_ld', C.c_int),
+                ('absmax', void_p), ('scale_out', void_p),
+                ('r_hi', void_p), ('r_lo', void_p), ('ldk_r', C.c_int),
+                ('c_hi', void_p), ('c_lo', void_p), ('ldk_c', C.c_int)]
+
+
+class GemmHlArgs(C.Structure):
+    _fields_ = [('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
+                ('a_hi', void_p), ('a_lo', void_p), ('lda', C.c_int),
+                ('b_hi', void_p), ('b_lo', void_p), ('ldb', C.c_int),
+                ('a_scale', void_p), ('b_scale', void_p),
+                ('C', void_p), ('ldc', C.c_int),
+                ('alpha', C.c_float), ('beta', C.c_float),
+                ('bias', void_p),
+                ('c_scale', void_p), ('c_scale_period', C.c_int), ('c_scale_ld', C.c_int),
+                ('split_k', C.c_int)]
+
+
 class LstmArgs(C.Structure):
     _fields_ = [('T', C.c_int), ('n_pad', C.c_int), ('H', C.c_int), ('mode', C.c_int),
                 ('U', void_p), ('mask_u', void_p),
@@ -89,6 +109,9 @@ SIGNATURES = {
                                         void_p]),
     'asr_gemm_workspace_bytes': (C.c_size_t, [C.POINTER(GemmArgs)]),
     'asr_gemm': (C.c_int, [C.POINTER(GemmArgs), void_p, C.c_size_t, void_p]),
+    'asr_pack_hl': (C.c_int, [C.POINTER(PackArgs), void_p]),
+    'asr_gemm_hl_workspace_bytes': (C.c_size_t, [C.POINTER(GemmHlArgs)]),
+    'asr_gemm_hl': (C.c_int, [C.POINTER(GemmHlArgs), void_p, C.c_size_t, void_p]),
     'asr_absmax': (C.c_int, [void_p, C.c_int64, void_p, void_p]),
     'asr_colsum_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'asr_colsum': (C.c_int, [void_p, C.c_int, C.c_int, C.c_int, void_p, C.c_float, void_p,

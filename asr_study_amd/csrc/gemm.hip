@@ -772,6 +772,276 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
     }
 }
 
+// ===========================================================================
+// Packed split-fp16 operands ("hl" planes): convert once, multiply many times.
+//
+// gemm_f16x2_fast_kernel splits every fp32 element into hi/lo halfs INSIDE its K loop
+// (~140 VALU per 24 MFMAs and slab), and a tile of an operand is re-read -- and re-split --
+// by every workgroup of its row / column band (a dz element ~20 times per step).  Here the
+// split happens once per tensor: pack_hl_kernel writes two fp16 planes hi = fp16(x*s),
+// lo = fp16(x*s - hi) (s = the per-tensor power of two of pow2_scale; variational-dropout
+// masks are multiplied in BEFORE the split, in fp32, so the GEMM needs no mask path) with the
+// reduction index contiguous, in either or both orientations of the source:
+//   "r" planes (rows, ldk_r): K = the source's columns  (A of x@W, A of dz@W^T)
+//   "c" planes (cols, ldk_c): K = the source's rows     (both operands of the weight
+//                                                         gradients x^T dz and h^T dz)
+// rows of a plane are ldk halfs long (ldk % 32 == 0, zero padded).  gemm_hl_kernel is then a
+// plain fp16 GEMM with three MFMAs per fragment pair and fp32 accumulation: 16-byte global
+// loads -> ds_write_b128 -> ds_read_b128 -> v_mfma_f32_32x32x16_f16, no VALU in the K loop
+// besides addresses.  Tile / LDS image / epilogue are those of the fast kernel.
+struct HlSrc {
+  const _Float16* hi; const _Float16* lo;
+  int ld;                 // halfs per plane row
+  int rows;               // MN extent
+  unsigned extent;        // bytes addressable from hi / lo
+};
+
+// 64 x 64 source tile per workgroup; thread (ty = tid >> 4, tx = tid & 15) owns the 4 x 4
+// block rows 4 ty.., columns 4 tx..
+__global__ void __launch_bounds__(256)
+pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
+               const float* __restrict__ mask, int pmask, int mask_ld,
+               const float* __restrict__ absmax, float* __restrict__ scale_out,
+               _Float16* __restrict__ r_hi, _Float16* __restrict__ r_lo, int ldk_r,
+               _Float16* __restrict__ c_hi, _Float16* __restrict__ c_lo, int ldk_c) {
+  __shared__ __attribute__((aligned(16))) _Float16 th[64][72], tl[64][72];   // [col][row]
+  const int tid = threadIdx.x;
+  const int ty = tid >> 4, tx = tid & 15;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const float s = pow2_scale(absmax);
+  if (scale_out && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *scale_out = s;
+  const int c = c0 + 4 * tx;
+  hx4 hi[4], lo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + 4 * ty + i;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      const float* q = src + (size_t)r * ld + c;
+      if (c + 3 < cols) {
+        const float4 t = *reinterpret_cast<const float4*>(q);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] = q[e];
+      }
+      if (mask) {
+        const float* m = mask + (size_t)(r & pmask) * mask_ld + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] *= m[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = v[e] * s;
+      const _Float16 h = (_Float16)x;
+      hi[i][e] = h;
+      lo[i][e] = (_Float16)(x - (float)h);
+    }
+    if (r_hi && r < rows && c < ldk_r) {      // (columns in [cols, ldk_r) receive zeros)
+      *reinterpret_cast<hx4*>(r_hi + (size_t)r * ldk_r + c) = hi[i];
+      *reinterpret_cast<hx4*>(r_lo + (size_t)r * ldk_r + c) = lo[i];
+    }
+  }
+  if (!c_hi) return;
+  // transposed planes through LDS: [col][row], then 16-byte runs along the rows
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hx4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = hi[i][e]; b[i] = lo[i][e]; }
+    *reinterpret_cast<hx4*>(&th[4 * tx + e][4 * ty]) = a;
+    *reinterpret_cast<hx4*>(&tl[4 * tx + e][4 * ty]) = b;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + 256 * it;             // 64 columns x 8 chunks of 8 rows
+    const int cc = idx >> 3, rq = (idx & 7) * 8;
+    const int col = c0 + cc, row = r0 + rq;
+    if (col < cols && row < ldk_c) {            // (rows in [rows, ldk_c) receive zeros)
+      *reinterpret_cast<hx8*>(c_hi + (size_t)col * ldk_c + row) =
+          *reinterpret_cast<const hx8*>(&th[cc][rq]);
+      *reinterpret_cast<hx8*>(c_lo + (size_t)col * ldk_c + row) =
+          *reinterpret_cast<const hx8*>(&tl[cc][rq]);
+    }
+  }
+}
+
+// One operand's share of a K slab: 128 rows x 32 halfs per plane = 512 16-byte chunks;
+// thread t takes chunks t and t + 256 (row = chunk >> 2, k chunk = chunk & 3) of both planes.
+struct HlLoader {
+  __amdgpu_buffer_rsrc_t rh, rl;
+  unsigned off[2];                 // byte offsets at k_begin (kOob for rows outside)
+  int kq[2];                       // first k of the chunk relative to the slab
+  int k_begin, k_end;
+  __device__ __forceinline__ void init(const HlSrc& s, int row0, int kb, int ke) {
+    const int tid = threadIdx.x;
+    rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.hi), 0, s.extent, 0x00020000);
+    rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.lo), 0, s.extent, 0x00020000);
+    k_begin = kb; k_end = ke;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = tid + 256 * i;
+      const int row = row0 + (ch >> 2);
+      kq[i] = 8 * (ch & 3);
+      off[i] = row < s.rows ? (unsigned)(((size_t)row * s.ld + kb + kq[i]) * 2) : kOob;
+    }
+  }
+  __device__ __forceinline__ void load(int kt, u32x4g (&h)[2], u32x4g (&l)[2]) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = k_begin + kt * HBK + kq[i] < k_end && off[i] != kOob;
+      const unsigned o = ok ? off[i] + (unsigned)(kt * HBK * 2) : kOob;
+      h[i] = __builtin_amdgcn_raw_buffer_load_b128(rh, o, 0, 0);
+      l[i] = __builtin_amdgcn_raw_buffer_load_b128(rl, o, 0, 0);
+    }
+  }
+  __device__ __forceinline__ static void store(const u32x4g (&h)[2], const u32x4g (&l)[2],
+                                               _Float16 (*Shi)[HLD], _Float16 (*Slo)[HLD]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = tid + 256 * i;
+      *reinterpret_cast<u32x4g*>(&Shi[ch >> 2][8 * (ch & 3)]) = h[i];
+      *reinterpret_cast<u32x4g*>(&Slo[ch >> 2][8 * (ch & 3)]) = l[i];
+    }
+  }
+};
+
+__global__ void __launch_bounds__(256)
+gemm_hl_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int splits, Epilogue ep,
+               const float* __restrict__ a_scale, const float* __restrict__ b_scale) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
+  // [buf 2][A_hi, A_lo, B_hi, B_lo][128][HLD]
+  auto tile = [&](int buf, int which) {
+    return reinterpret_cast<_Float16 (*)[HLD]>(hsm + ((size_t)(buf * 4 + which) * 128) * HLD);
+  };
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const TileId tb = tile_of_block((M + BM - 1) / BM, (N + BN - 1) / BN, splits);
+  const int m0 = tb.tm * BM, n0 = tb.tn * BN;
+  const int k_begin = tb.z * k_per_split;
+  int k_end = k_begin + k_per_split;
+  if (k_end > K) k_end = K;
+  const float sa = a_scale ? *a_scale : 1.f, sb = b_scale ? *b_scale : 1.f;
+
+  f32x16 am[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) am[i][j][e] = 0.f;
+
+  HlLoader la, lb;
+  la.init(A, m0, k_begin, k_end);
+  lb.init(B, n0, k_begin, k_end);
+  // two register sets: slab kt is multiplied out of LDS while slab kt+1 (loaded an iteration
+  // ago) is written into the other LDS buffer and the loads of slab kt+2 are in flight
+  u32x4g ah0[2], al0[2], bh0[2], bl0[2], ah1[2], al1[2], bh1[2], bl1[2];
+  const int nk = (k_end - k_begin + HBK - 1) / HBK;
+  la.load(0, ah0, al0);
+  lb.load(0, bh0, bl0);
+  la.load(1, ah1, al1);
+  lb.load(1, bh1, bl1);
+  HlLoader::store(ah0, al0, tile(0, 0), tile(0, 1));
+  HlLoader::store(bh0, bl0, tile(0, 2), tile(0, 3));
+  __syncthreads();
+  const int lrow = lane & 31, lk = 8 * (lane >> 5);
+  auto slab = [&](int kt, u32x4g (&lah)[2], u32x4g (&lal)[2], u32x4g (&lbh)[2],
+                  u32x4g (&lbl)[2], u32x4g (&sah)[2], u32x4g (&sal)[2], u32x4g (&sbh)[2],
+                  u32x4g (&sbl)[2]) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    // past the last slab every offset is out of range: those loads return zeros, unused
+    la.load(kt + 2, lah, lal);
+    lb.load(kt + 2, lbh, lbl);
+    _Float16 (*Ah)[HLD] = tile(cur, 0);
+    _Float16 (*Al)[HLD] = tile(cur, 1);
+    _Float16 (*Bh)[HLD] = tile(cur, 2);
+    _Float16 (*Bl)[HLD] = tile(cur, 3);
+#pragma unroll
+    for (int ks = 0; ks < HBK / 16; ++ks) {
+      hx8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const hx8*>(&Ah[wm * 64 + i * 32 + lrow][16 * ks + lk]);
+        al[i] = *reinterpret_cast<const hx8*>(&Al[wm * 64 + i * 32 + lrow][16 * ks + lk]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = *reinterpret_cast<const hx8*>(&Bh[wn * 64 + j * 32 + lrow][16 * ks + lk]);
+        bl[j] = *reinterpret_cast<const hx8*>(&Bl[wn * 64 + j * 32 + lrow][16 * ks + lk]);
+      }
+      // term-major order: consecutive MFMAs go to four different accumulators
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], am[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], am[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], am[i][j], 0, 0, 0);
+    }
+    HlLoader::store(sah, sal, tile(nxt, 0), tile(nxt, 1));
+    HlLoader::store(sbh, sbl, tile(nxt, 2), tile(nxt, 3));
+    __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    slab(kt, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1);     // loads kt+2 -> set 0, stores set 1
+    if (kt + 1 < nk) slab(kt + 1, ah1, al1, bh1, bl1, ah0, al0, bh0, bl0);
+  }
+  const float unscale = 1.f / (sa * sb);
+  const int lcol = lane & 31, lhalf = lane >> 5;
+  const bool interior = m0 + BM <= M && n0 + BN <= N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + lcol;
+      const int row0 = m0 + wm * 64 + i * 32 + 4 * lhalf;
+      if (!interior && col >= N) continue;
+      if (ep.partial) {
+        float* dst = ep.partial + ((size_t)tb.z * M + row0) * N + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int dr = (e & 3) + 8 * (e >> 2);
+          if (interior || row0 + dr < M) dst[(size_t)dr * N] = am[i][j][e] * unscale;
+        }
+        continue;
+      }
+      float* dst = ep.C + (size_t)row0 * ep.ldc + col;
+      const float bias = ep.bias ? ep.bias[col] : 0.f;
+      float old[16], msk[16];
+      const bool use_old = ep.beta != 0.f;
+      const bool use_msk = ep.c_scale != nullptr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int dr = (e & 3) + 8 * (e >> 2);
+        const bool ok = interior || row0 + dr < M;
+        old[e] = (use_old && ok) ? dst[(size_t)dr * ep.ldc] : 0.f;
+        msk[e] = (use_msk && ok)
+            ? ep.c_scale[(size_t)mod_period(row0 + dr, ep.c_period) * ep.c_ld + col] : 1.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int dr = (e & 3) + 8 * (e >> 2);
+        if (!(interior || row0 + dr < M)) continue;
+        const float v = (am[i][j][e] * unscale * ep.alpha + bias) * msk[e];
+        dst[(size_t)dr * ep.ldc] = use_old ? v + ep.beta * old[e] : v;
+      }
+    }
+}
+
 // max |x| of a flat tensor -> out[0] (float).  Two launches: per-block maxima via
 // atomicMax on the float bits (all non-negative, so integer order == float order).
 __global__ void __launch_bounds__(256)
@@ -1010,6 +1280,110 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
     ep2.partial = nullptr;
     const size_t total = (size_t)a->M * a->N;
     int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256),
+                       lds_ballast((const void*)gemm_splitk_reduce_kernel), stream,
+                       reinterpret_cast<const float*>(workspace), splits, a->M, a->N, ep2);
+    ASR_CHECK_LAUNCH();
+  }
+  return ASR_OK;
+}
+
+extern "C" int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(a && a->src && a->rows > 0 && a->cols > 0 && a->ld >= a->cols,
+                "pack_hl: bad source");
+  ASR_CHECK_ARG(aligned16(a->src) && a->ld % 4 == 0, "pack_hl: source rows must be 16-byte aligned");
+  ASR_CHECK_ARG((a->r_hi != nullptr) == (a->r_lo != nullptr) &&
+                (a->c_hi != nullptr) == (a->c_lo != nullptr) && (a->r_hi || a->c_hi),
+                "pack_hl: need the hi and lo plane of at least one orientation");
+  if (a->r_hi)
+    ASR_CHECK_ARG(a->ldk_r % 32 == 0 && a->ldk_r >= a->cols && a->ldk_r < a->cols + 32 &&
+                  aligned16(a->r_hi) && aligned16(a->r_lo), "pack_hl: bad row-plane geometry");
+  if (a->c_hi)
+    ASR_CHECK_ARG(a->ldk_c % 32 == 0 && a->ldk_c >= a->rows && a->ldk_c < a->rows + 32 &&
+                  aligned16(a->c_hi) && aligned16(a->c_lo), "pack_hl: bad column-plane geometry");
+  int pmask = 0;
+  if (a->mask) {
+    ASR_CHECK_ARG(a->mask_period > 0 && (a->mask_period & (a->mask_period - 1)) == 0 &&
+                  a->mask_ld >= a->cols, "pack_hl: mask period must be a power of two");
+    pmask = a->mask_period - 1;
+  }
+  dim3 grid((a->cols + 63) / 64, (a->rows + 63) / 64);
+  hipLaunchKernelGGL(pack_hl_kernel, grid, dim3(256), 0, stream, a->src, a->rows, a->cols, a->ld,
+                     a->mask, pmask, a->mask_ld, a->absmax, a->scale_out,
+                     reinterpret_cast<_Float16*>(a->r_hi), reinterpret_cast<_Float16*>(a->r_lo),
+                     a->ldk_r, reinterpret_cast<_Float16*>(a->c_hi),
+                     reinterpret_cast<_Float16*>(a->c_lo), a->ldk_c);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}
+
+static int hl_splits(const asr_gemm_hl_args* a, int* kps_out) {
+  int splits = a->split_k > 1 ? a->split_k : 1;
+  int kps = (a->K + splits - 1) / splits;
+  kps = (kps + HBK - 1) / HBK * HBK;
+  while (splits > 1 && (size_t)(splits - 1) * kps >= (size_t)a->K) --splits;
+  if (kps_out) *kps_out = kps;
+  return splits;
+}
+
+extern "C" size_t asr_gemm_hl_workspace_bytes(const asr_gemm_hl_args* a) {
+  if (!a) return 0;
+  const int splits = hl_splits(a, nullptr);
+  if (splits <= 1) return 0;
+  return asr_align_up((size_t)splits * a->M * a->N * sizeof(float), 256);
+}
+
+extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws_bytes,
+                           asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(a && a->a_hi && a->a_lo && a->b_hi && a->b_lo && a->C, "gemm_hl: null pointer");
+  ASR_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 8 == 0,
+                "gemm_hl: bad shape %d %d %d (K must be a multiple of 8)", a->M, a->N, a->K);
+  ASR_CHECK_ARG(a->lda >= a->K && a->ldb >= a->K && a->lda % 8 == 0 && a->ldb % 8 == 0 &&
+                a->ldc >= a->N, "gemm_hl: bad leading dimensions");
+  ASR_CHECK_ARG(aligned16(a->a_hi) && aligned16(a->a_lo) && aligned16(a->b_hi) &&
+                aligned16(a->b_lo), "gemm_hl: planes must be 16-byte aligned");
+  const size_t ext_a = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
+  const size_t ext_b = ((size_t)(a->N - 1) * a->ldb + a->K) * 2;
+  const size_t lim = ((size_t)1 << 32) - ((size_t)1 << 20);
+  ASR_CHECK_ARG(ext_a < lim && ext_b < lim, "gemm_hl: operand larger than 4 GiB");
+  int kps = 0;
+  const int splits = hl_splits(a, &kps);
+  Epilogue ep;
+  ep.C = a->C; ep.ldc = a->ldc; ep.alpha = a->alpha; ep.beta = a->beta; ep.bias = a->bias;
+  ep.c_scale = a->c_scale; ep.c_period = a->c_scale_period > 0 ? a->c_scale_period : 1;
+  ep.c_ld = a->c_scale_ld; ep.partial = nullptr;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * a->M * a->N * sizeof(float);
+    if (!workspace || ws_bytes < need) {
+      asr_set_error("gemm_hl: split-K workspace %zu < %zu bytes", ws_bytes, need);
+      return ASR_ERR_WORKSPACE;
+    }
+    ep.partial = reinterpret_cast<float*>(workspace);
+  }
+  HlSrc A, B;
+  A.hi = reinterpret_cast<const _Float16*>(a->a_hi); A.lo = reinterpret_cast<const _Float16*>(a->a_lo);
+  A.ld = a->lda; A.rows = a->M; A.extent = (unsigned)ext_a;
+  B.hi = reinterpret_cast<const _Float16*>(a->b_hi); B.lo = reinterpret_cast<const _Float16*>(a->b_lo);
+  B.ld = a->ldb; B.rows = a->N; B.extent = (unsigned)ext_b;
+  const size_t shm = (size_t)2 * 4 * 128 * HLD * sizeof(_Float16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    ASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hl_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_done = true;
+  }
+  const int total = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) * splits;
+  hipLaunchKernelGGL(gemm_hl_kernel, dim3(total), dim3(256), shm, stream, A, B, a->M, a->N, a->K,
+                     kps, splits, ep, a->a_scale, a->b_scale);
+  ASR_CHECK_LAUNCH();
+  if (splits > 1) {
+    Epilogue ep2 = ep;
+    ep2.partial = nullptr;
+    const size_t tot = (size_t)a->M * a->N;
+    int blocks = (int)((tot + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256),
                        lds_ballast((const void*)gemm_splitk_reduce_kernel), stream,

@@ -2625,12 +2625,13 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
         k = pick_fwd_k(pl.NKK);
         // two batch tiles per workgroup (ASR_LSTM_PAIR=0 disables): persistent mode, an
         // even number of tiles, every lane's gather groups and units present
-        // ASR_LSTM_FWD_GEN: 3 = fwd_body_x (default: one or two tiles per workgroup),
-        // 2 = fwd_body_k2 when paired, 1 = fwd_body_k
+        // ASR_LSTM_FWD_GEN: 3 = fwd_body_x (default; one batch tile per workgroup, ASR_LSTM_PAIR=1:
+        // two -- measured slower with this generation: 1.88 vs 1.58 us per step at H = 256,
+        // 2.70 vs 1.91 at H = 512), 2 = fwd_body_k2 when paired, 1 = fwd_body_k
         const int gen = env_int("ASR_LSTM_FWD_GEN", 3);
         const bool wide = a->mode == 0 && (H == 256 || H == 512);
         const bool even = (a->n_pad / 16) % 2 == 0;
-        const int pair_f = env_int("ASR_LSTM_PAIR", 1);
+        const int pair_f = env_int("ASR_LSTM_PAIR", gen >= 3 ? 0 : 1);
         const int place_f = env_int("ASR_LSTM_PAIR_PLACE", 1);
         if (wide && gen >= 3) {
           pl.pair = (pair_f && even) ? 1 : 0;
@@ -2791,9 +2792,9 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.poll = stepwise ? 0 : 1;
   p.allow_fast = env_int("ASR_LSTM_FAST", 1);
   p.dbg = env_int("ASR_LSTM_DBG", 0);
-  // measured optimum on MI355X (tools/sweep_poll.sh): forward 14-16 naps (~0.4 us),
-  // BPTT 8 for chains of <= 16 workgroups and none for wider ones
-  p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.pair ? 0 : pl.P <= 16 ? 8 : 0)
+  // measured optimum on MI355X (tools/sweep_poll.sh, tools/sweep_r2c.sh): forward 8-16 naps
+  // (~0.4 us; flat in that range), BPTT 4
+  p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.pair ? 0 : 4)
                   : env_int("ASR_LSTM_PREPOLL_F", pl.pair ? 0 : pl.P <= 16 ? 12 : 16);
   p.repoll = bwd ? env_int("ASR_LSTM_REPOLL_B", 1) : env_int("ASR_LSTM_REPOLL_F", 1);
   p.xstride = fwd_xstride();

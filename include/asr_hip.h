@@ -135,6 +135,48 @@ typedef struct asr_gemm_args {
 size_t asr_gemm_workspace_bytes(const asr_gemm_args* a);
 int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes,
              asr_stream_t stream);
+/* ------------------------------------------------------------------------ */
+/* K4/K6 with operands converted ONCE: packed split-fp16 planes.  asr_pack_hl  */
+/* turns an fp32 matrix (rows, cols) -- optionally times a variational-dropout */
+/* mask[(row % period), col] (core/models.py:265-266), applied in fp32 before   */
+/* the split -- into two fp16 planes hi = fp16(x*s), lo = fp16(x*s - hi) with   */
+/* s = the power of two that maps *absmax into [2^8, 2^9) (1 if absmax is       */
+/* NULL), in either or both orientations:                                       */
+/*   r planes (rows, ldk_r): the reduction index of the later GEMM = columns,   */
+/*   c planes (cols, ldk_c): the reduction index = rows (weight gradients);     */
+/* ldk_* = the extent rounded up to a multiple of 32 halfs, zero padded.  The   */
+/* scale is written to *scale_out (device float).  asr_gemm_hl then computes    */
+/*   C[M,N] = alpha/(sa*sb) * (Ah Bh^T + Ah Bl^T + Al Bh^T) (+bias) (*c_scale)  */
+/*            + beta*C                                                          */
+/* from A planes (M, lda) and B planes (N, ldb), reduction index contiguous in  */
+/* both, fp32 accumulation (2^-22 relative per product: the arithmetic of       */
+/* asr_gemm precision 1 without its per-tile conversions).  A sub-matrix is a   */
+/* pointer offset (16-byte aligned) with the same leading dimension; K % 8 == 0.*/
+/* ------------------------------------------------------------------------ */
+typedef struct asr_pack_args {
+  const float* src; int rows, cols, ld;
+  const float* mask; int mask_period, mask_ld;   /* or NULL; period a power of two    */
+  const float* absmax;                           /* device float, or NULL (scale 1)   */
+  float* scale_out;                              /* device float, or NULL             */
+  void* r_hi; void* r_lo; int ldk_r;             /* (rows, ldk_r) halfs each, or NULL */
+  void* c_hi; void* c_lo; int ldk_c;             /* (cols, ldk_c) halfs each, or NULL */
+} asr_pack_args;
+int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream);
+typedef struct asr_gemm_hl_args {
+  int M, N, K;
+  const void* a_hi; const void* a_lo; int lda;   /* halfs per row                     */
+  const void* b_hi; const void* b_lo; int ldb;
+  const float* a_scale; const float* b_scale;    /* device floats (asr_pack_hl) or NULL */
+  float* C; int ldc;
+  float alpha, beta;
+  const float* bias;                             /* (N) or NULL                       */
+  const float* c_scale; int c_scale_period; int c_scale_ld;   /* mask on C rows or NULL */
+  int split_k;                                   /* 0/1 = none                        */
+} asr_gemm_hl_args;
+size_t asr_gemm_hl_workspace_bytes(const asr_gemm_hl_args* a);
+int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws_bytes,
+                asr_stream_t stream);
+
 /* out[0] = max |x[i]| over a 16-byte aligned flat tensor (HBM-bound).         */
 int asr_absmax(const float* x, int64_t n, float* out, asr_stream_t stream);
 /* out[n] = beta*out[n] + sum_m X[m, n]  (bias gradients; X read once,       */

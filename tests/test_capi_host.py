@@ -129,8 +129,13 @@ int main(void) {
   printf("frontend %zu %zu\\n", sizeof(asr_frontend_cfg), offsetof(asr_frontend_cfg, eps));
   printf("gemm %zu %zu %zu\\n", sizeof(asr_gemm_args), offsetof(asr_gemm_args, bias),
          offsetof(asr_gemm_args, b_absmax));
-  printf("lstm %zu %zu %zu %zu\\n", sizeof(asr_lstm_args), offsetof(asr_lstm_args, dz_absmax),
-         offsetof(asr_lstm_args, step_begin), offsetof(asr_lstm_args, dmi));
+  printf("lstm %zu %zu %zu %zu %zu\\n", sizeof(asr_lstm_args), offsetof(asr_lstm_args, dz_absmax),
+         offsetof(asr_lstm_args, step_begin), offsetof(asr_lstm_args, dmi),
+         offsetof(asr_lstm_args, db_part));
+  printf("pack %zu %zu %zu\\n", sizeof(asr_pack_args), offsetof(asr_pack_args, scale_out),
+         offsetof(asr_pack_args, ldk_c));
+  printf("gemmhl %zu %zu %zu %zu\\n", sizeof(asr_gemm_hl_args), offsetof(asr_gemm_hl_args, b_scale),
+         offsetof(asr_gemm_hl_args, bias), offsetof(asr_gemm_hl_args, split_k));
   printf("segment %zu %zu\\n", sizeof(asr_segment), offsetof(asr_segment, l2));
   printf("lstmln %zu %zu %zu\\n", sizeof(asr_lstm_ln_args), offsetof(asr_lstm_ln_args, cellp),
          offsetof(asr_lstm_ln_args, dparams));
@@ -146,7 +151,11 @@ int main(void) {
     F, G, Ls, S = _lib.FrontendCfg, _lib.GemmArgs, _lib.LstmArgs, _lib.Segment
     assert out['frontend'] == [C.sizeof(F), F.eps.offset]
     assert out['gemm'] == [C.sizeof(G), G.bias.offset, G.b_absmax.offset]
-    assert out['lstm'] == [C.sizeof(Ls), Ls.dz_absmax.offset, Ls.step_begin.offset, Ls.dmi.offset]
+    assert out['lstm'] == [C.sizeof(Ls), Ls.dz_absmax.offset, Ls.step_begin.offset, Ls.dmi.offset,
+                           Ls.db_part.offset]
+    P, GH = _lib.PackArgs, _lib.GemmHlArgs
+    assert out['pack'] == [C.sizeof(P), P.scale_out.offset, P.ldk_c.offset]
+    assert out['gemmhl'] == [C.sizeof(GH), GH.b_scale.offset, GH.bias.offset, GH.split_k.offset]
     assert out['segment'] == [C.sizeof(S), S.l2.offset]
     LN = _lib.LstmLnArgs
     assert out['lstmln'] == [C.sizeof(LN), LN.cellp.offset, LN.dparams.offset]
