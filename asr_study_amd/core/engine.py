@@ -128,6 +128,11 @@ class Model(object):
         self._pipe_split16 = min(15, max(9, int(_os.environ.get('ASR_PIPE_SPLIT', '12'))))
         self.pipeline = self.overlap and self._pipeline_mode == '1'
         self._pipe = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        # big GEMMs on operands packed once into split-fp16 planes (ops.pack_hl / gemm_hl);
+        # ASR_GEMM_PACKED=0 keeps the convert-per-tile kernels, ASR_GEMM_PREC=0 (exact fp32) too
+        self.packed = (_os.environ.get('ASR_GEMM_PACKED', '1') != '0'
+                       and _os.environ.get('ASR_GEMM_PREC', '1') != '0')
+        self._hl = {}
         self._rng = torch.Generator(device=self.device)
         self._rng.manual_seed(int(seed) + 12345)
         self._layout(seed)
@@ -371,9 +376,71 @@ class Model(object):
     def _gview(self, off, n):
         return self.grads[off:off + n]
 
+    # ------------------------------------------------------------------ packed operands
+    def _planes(self, name, rows, k):
+        """Cached ops.HlPlanes buffer (rows, k) under `name` (stale shapes dropped)."""
+        key = (name, int(rows), int(k))
+        b = self._hl.get(key)
+        if b is None:
+            for kk in [kk for kk in self._hl if kk[0] == name]:
+                del self._hl[kk]
+            b = ops.HlPlanes(rows, k, self.device)
+            self._hl[key] = b
+        return b
+
+    def _const_one(self):
+        if not hasattr(self, '_one'):
+            self._one = torch.ones(1, dtype=torch.float32, device=self.device)
+        return self._one
+
+    def _stage_packed(self, s):
+        """Whether a BiLSTM stage's GEMMs run on packed operands (plain cell only)."""
+        return self.packed and s.kind == 'bilstm' and s.mi is None and s.ln is None
+
+    def _pack_weights(self):
+        """W of every packed stage -> planes for x@W (reduction over the input features:
+        (8H, in)) and for dz@W^T (reduction over the gate columns: (in, 8H)); one pass per W,
+        ~0.3 GB per step at cfg3."""
+        for si, s in enumerate(self.stages):
+            if not self._stage_packed(s):
+                continue
+            n = s.f_in_pad * 8 * s.Hp
+            w = self.params[s.oW:s.oW + n]
+            amax = ops.absmax(w, self._buf('wamax%d' % si, (1,)))
+            ops.pack_hl(self.params, s.f_in_pad, 8 * s.Hp, src_off=s.oW, absmax=amax,
+                        r=self._planes('Wn%d' % si, s.f_in_pad, 8 * s.Hp),
+                        c=self._planes('Wt%d' % si, 8 * s.Hp, s.f_in_pad))
+
+    def _pack_input(self, si, s, a, BW, rows, n_pad, amax, need_c):
+        """The stage's input slab (rows, f_in_pad) [x B_W of each direction] -> planes with the
+        features as reduction index (x@W) and, for training, with the rows as reduction index
+        (dW = x^T dz).  One entry per direction when masks are on, else one shared entry."""
+        out = []
+        for d in range(2 if BW is not None else 1):
+            r = self._planes('ar%d_%d' % (si, d), rows, s.f_in_pad)
+            c = self._planes('ac%d_%d' % (si, d), s.f_in_pad, rows) if need_c else None
+            ops.pack_hl(a, rows, s.f_in_pad, mask=None if BW is None else BW[d],
+                        mask_period=n_pad, absmax=amax, r=r, c=c)
+            out.append((r, c))
+        return out
+
+    def _gate_gemm_hl(self, s, si, pa, zx, rows):
+        """zx = (a (.) B_W) @ W + b from packed planes (both directions in one GEMM without
+        masks, one GEMM per direction with them)."""
+        Hp = s.Hp
+        Wt = self._planes('Wt%d' % si, 8 * Hp, s.f_in_pad)
+        bias = self._view(s.ob, 8 * Hp)
+        if len(pa) == 1:
+            ops.gemm_hl(pa[0][0], Wt, zx, rows, 8 * Hp, s.f_in_pad, bias=bias)
+            return
+        for d in range(2):
+            ops.gemm_hl(pa[d][0], Wt, zx, rows, 4 * Hp, s.f_in_pad, b_row=d * 4 * Hp,
+                        c_off=d * 4 * Hp, ldc=8 * Hp, bias=bias[d * 4 * Hp:(d + 1) * 4 * Hp])
+
     # ------------------------------------------------------------------ forward
-    def forward(self, x, training=False, masks=None):
+    def forward(self, x, training=False, masks=None, need_grad=True):
         """x: (T, n_pad, F) float32 CUDA slab -> logits (T, n_pad, C).
+        need_grad=False (evaluation / prediction) skips what only BPTT would read.
 
         masks: optional explicit variational-dropout masks (parity tests):
         {stage_index: (BW (2, n_pad, f_in_pad), BU (2, n_pad, Hp))}.
@@ -396,9 +463,14 @@ class Model(object):
         drawn = [None]
         nb = 0
         self._pipe_now = self._pipeline_on(n_pad)
-        pipe = self._pipe_now and self._pipe is not None and self.lstm_mode == 0 and T >= 16
+        # (the packed-operand GEMMs take whole slabs: no frame-range pipelining with them)
+        pipe = (self._pipe_now and self._pipe is not None and self.lstm_mode == 0 and T >= 16
+                and not self.packed)
+        self._pipe_now = self._pipe_now and not self.packed
         S = (self._pipe_split16 * T) // 16
         pre = {}
+        if any(self._stage_packed(st) for st in self.stages):
+            self._pack_weights()
 
         def stage_masks(i):
             st = self.stages[i]
@@ -445,7 +517,14 @@ class Model(object):
                 nb += 1
                 main = torch.cuda.current_stream(self.device)
                 inner_done = pre.pop(si, None)
-                if inner_done is None:
+                if self._stage_packed(s):
+                    # |y| < 1 behind a BiLSTM stage; anything else is measured
+                    prev = self.stages[si - 1] if si > 0 else None
+                    amax = self._const_one() if (prev is not None and prev.kind == 'bilstm') \
+                        else ops.absmax(a, self._buf('aamax%d' % si, (1,)))
+                    rec['pa'] = self._pack_input(si, s, a, BW, rows, n_pad, amax, need_grad)
+                    self._gate_gemm_hl(s, si, rec['pa'], zx, rows)
+                elif inner_done is None:
                     self._gate_gemm(a, s, zx, BW, 0, rows, n_pad)
                 else:       # frames [T-S, S) were projected while the previous layer ran
                     self._gate_gemm(a, s, zx, BW, 0, (T - S) * n_pad, n_pad)
@@ -731,6 +810,43 @@ class Model(object):
                                                    dz_absmax=zmx, **var)
                     flush_side()    # previous layer's dW/dU/db now overlap this BPTT
                 y = rec['y']
+                hl = self._stage_packed(s)
+                pdz_r = pdz_c = None
+                if hl:
+                    # dz -> planes, once: gate columns as reduction index for dX, rows for the
+                    # weight gradients (the scale is the BPTT kernel's own max|dz|)
+                    pdz_r = None if first else self._planes('dzr%d' % par, rows, 8 * Hp)
+                    pdz_c = self._planes('dzc%d' % par, 8 * Hp, rows)
+                    ops.pack_hl(dz, rows, 8 * Hp, absmax=zmx, r=pdz_r, c=pdz_c)
+
+                def grads_U_hl(wsn, s=s, y=y, BU=BU, Hp=Hp, pdz_c=pdz_c):
+                    # dU[d] = (h_prev (.) B_U)^T dz[d] from planes with the rows as reduction
+                    # index; h_prev = y one frame earlier in the direction's processing order
+                    kk = (T - 1) * n_pad
+                    for d in range(2):
+                        if kk <= 0:
+                            self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
+                            continue
+                        yu = self._planes('yu%d' % d, Hp, rows)
+                        ops.pack_hl(y, rows, Hp, ld=2 * Hp, src_off=d * Hp,
+                                    mask=None if BU is None else BU[d], mask_period=n_pad,
+                                    absmax=self._const_one(), c=yu)
+                        ops.gemm_hl(yu, pdz_c, self.grads, Hp, 4 * Hp, kk,
+                                    a_k=0 if d == 0 else n_pad, b_row=d * 4 * Hp,
+                                    b_k=n_pad if d == 0 else 0, c_off=s.oU + d * Hp * 4 * Hp,
+                                    split_k=split, ws_name=wsn)
+
+                def grads_W_hl(wsn, s=s, pa=rec.get('pa'), Hp=Hp, pdz_c=pdz_c, pgrad=pgrad):
+                    if len(pa) == 1:
+                        ops.gemm_hl(pa[0][1], pdz_c, self.grads, s.f_in_pad, 8 * Hp, rows,
+                                    c_off=s.oW, split_k=split, ws_name=wsn)
+                    else:
+                        for d in range(2):
+                            ops.gemm_hl(pa[d][1], pdz_c, self.grads, s.f_in_pad, 4 * Hp, rows,
+                                        b_row=d * 4 * Hp, c_off=s.oW + d * 4 * Hp, ldc=8 * Hp,
+                                        split_k=split, ws_name=wsn)
+                    buf, nrow, ncol, goff = pgrad
+                    ops.colsum(buf, nrow, ncol, ncol, self._gview(goff, ncol), ws_name=wsn + '_cs')
 
                 def grads_U(wsn, s=s, dz=dz, y=y, BU=BU, Hp=Hp, zmx=zmx):
                     # dU[d] = (h_prev (.) B_U)^T dz[d]: h_prev is y shifted by one step in
@@ -765,6 +881,9 @@ class Model(object):
                     buf, nrow, ncol, goff = pgrad
                     ops.colsum(buf, nrow, ncol, ncol, self._gview(goff, ncol), ws_name=wsn + '_cs')
 
+                if hl:
+                    grads_U, grads_W = grads_U_hl, grads_W_hl
+
                 def weight_grads(wsn, gu=grads_U, gw=grads_W):
                     gu(wsn)
                     gw(wsn)
@@ -773,6 +892,17 @@ class Model(object):
                     self._dx_gemm(dz, s, dx, BW, 0, (T - S) * n_pad, n_pad, zmx)
                     self._dx_gemm(dz, s, dx, BW, S * n_pad, rows, n_pad, zmx)
                     main.wait_event(dx_inner)
+                    da = dx
+                elif not first and hl:
+                    dx = self._buf('da_s%d' % si, (T, n_pad, s.f_in_pad))
+                    Wn = self._planes('Wn%d' % si, s.f_in_pad, 8 * Hp)
+                    if BW is None:
+                        ops.gemm_hl(pdz_r, Wn, dx, rows, s.f_in_pad, 8 * Hp)
+                    else:       # dx = sum_d B_W[d] (.) (dz_d @ W_d^T)
+                        for d in range(2):
+                            ops.gemm_hl(pdz_r, Wn, dx, rows, s.f_in_pad, 4 * Hp, a_k=d * 4 * Hp,
+                                        b_k=d * 4 * Hp, c_scale=BW[d], c_scale_period=n_pad,
+                                        beta=0.0 if d == 0 else 1.0)
                     da = dx
                 elif not first:
                     dx = self._buf('da_s%d' % si, (T, n_pad, s.f_in_pad))
@@ -962,7 +1092,7 @@ class Model(object):
         slab, labels, lens = self._unpack_inputs(inputs)
         N = len(labels)
         lab, lab_len, sl = self._prep_labels(labels, lens, slab.shape[0])
-        logits = self.forward(slab, training=False)
+        logits = self.forward(slab, training=False, need_grad=False)
         ctc = ops.ctc_loss_grad(logits, lab, lab_len, sl, N, grad=None)
         hyps = None
         dec = dlen = None
@@ -994,7 +1124,7 @@ class Model(object):
         slab = x if (torch.is_tensor(x) and x.dim() == 3 and x.shape[1] % 16 == 0) else self.to_slab(x)
         N = len(inputs_length) if inputs_length is not None else slab.shape[1]
         lens = np.asarray(inputs_length if inputs_length is not None else [slab.shape[0]] * N).reshape(-1)
-        logits = self.forward(slab, training=False)
+        logits = self.forward(slab, training=False, need_grad=False)
         if self.decoder is None:
             return logits[:, :N].permute(1, 0, 2).contiguous().cpu().numpy()
         sl = torch.as_tensor(lens.astype(np.int32)).to(self.device)

@@ -427,3 +427,69 @@ def lstm_ln_seq_bwd(dy, wx, U, cellp, uh, y, cell, gates, duh, dwx, dparams, T, 
     ws = WS.get('lstm_ln', nbytes, dy.device)
     L.check(lib.asr_lstm_ln_seq_bwd(C.byref(a), _ptr(ws), nbytes, _stream()),
             'asr_lstm_ln_seq_bwd')
+
+
+# --------------------------------------------------------------------------- packed operands
+class HlPlanes(object):
+    """Two fp16 planes (hi, lo) of a matrix whose rows are ``ld`` halfs long, reduction index
+    contiguous, plus the device float holding the power-of-two scale they were packed with
+    (include/asr_hip.h, asr_pack_hl)."""
+
+    def __init__(self, rows, k, device):
+        self.rows, self.k = int(rows), int(k)
+        self.ld = (self.k + 31) // 32 * 32
+        self.hi = torch.empty((self.rows, self.ld), dtype=torch.float16, device=device)
+        self.lo = torch.empty((self.rows, self.ld), dtype=torch.float16, device=device)
+        self.scale = torch.ones(1, dtype=torch.float32, device=device)
+
+
+def pack_hl(src, rows, cols, ld=None, src_off=0, mask=None, mask_period=0, absmax=None,
+            r=None, c=None):
+    """src (rows, cols) float32 (row stride ld, element offset src_off) [* mask[(row % period)]]
+    -> r planes (rows, cols as K) and / or c planes (cols, rows as K); both get the same scale."""
+    lib = L.load()
+    a = L.PackArgs()
+    a.src = src.data_ptr() + 4 * int(src_off)
+    a.rows, a.cols, a.ld = int(rows), int(cols), int(ld if ld is not None else cols)
+    a.mask = mask.data_ptr() if mask is not None else None
+    a.mask_period = int(mask_period)
+    a.mask_ld = int(mask.shape[-1]) if mask is not None else 0
+    a.absmax = absmax.data_ptr() if absmax is not None else None
+    first = r if r is not None else c
+    a.scale_out = first.scale.data_ptr()
+    if r is not None:
+        assert r.rows >= rows and r.k == cols
+        a.r_hi, a.r_lo, a.ldk_r = r.hi.data_ptr(), r.lo.data_ptr(), r.ld
+    if c is not None:
+        assert c.rows >= cols and c.k == rows
+        a.c_hi, a.c_lo, a.ldk_c = c.hi.data_ptr(), c.lo.data_ptr(), c.ld
+    L.check(lib.asr_pack_hl(C.byref(a), _stream()), 'asr_pack_hl')
+    if r is not None and c is not None:
+        c.scale = r.scale               # one scale for both orientations
+    return r, c
+
+
+def gemm_hl(A, B, Cm, M, N, K, a_row=0, a_k=0, b_row=0, b_k=0, c_off=0, ldc=None, alpha=1.0,
+            beta=0.0, bias=None, c_scale=None, c_scale_period=0, split_k=0, ws_name='gemm'):
+    """C[M,N] (float32 storage Cm, element offset c_off) = alpha * A @ B^T (+bias)(*c_scale)
+    + beta*C from packed planes: A rows [a_row, a_row+M), reduction range [a_k, a_k+K) of its
+    planes; B rows [b_row, b_row+N), range [b_k, b_k+K)."""
+    lib = L.load()
+    g = L.GemmHlArgs()
+    g.M, g.N, g.K = int(M), int(N), int(K)
+    ao = 2 * (int(a_row) * A.ld + int(a_k))
+    bo = 2 * (int(b_row) * B.ld + int(b_k))
+    g.a_hi, g.a_lo, g.lda = A.hi.data_ptr() + ao, A.lo.data_ptr() + ao, A.ld
+    g.b_hi, g.b_lo, g.ldb = B.hi.data_ptr() + bo, B.lo.data_ptr() + bo, B.ld
+    g.a_scale, g.b_scale = A.scale.data_ptr(), B.scale.data_ptr()
+    g.C = Cm.data_ptr() + 4 * int(c_off)
+    g.ldc = int(ldc if ldc is not None else N)
+    g.alpha, g.beta = float(alpha), float(beta)
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.c_scale = c_scale.data_ptr() if c_scale is not None else None
+    g.c_scale_period = int(c_scale_period)
+    g.c_scale_ld = int(c_scale.shape[-1]) if c_scale is not None else 0
+    g.split_k = _resolve_split(split_k, M, N, K)
+    nbytes = lib.asr_gemm_hl_workspace_bytes(C.byref(g))
+    ws = WS.get(ws_name, nbytes, Cm.device) if nbytes else None
+    L.check(lib.asr_gemm_hl(C.byref(g), _ptr(ws), nbytes, _stream()), 'asr_gemm_hl')

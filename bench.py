@@ -136,16 +136,16 @@ def cpu_baseline(cfg):
     try:
         import multiprocessing as mp
         ncpu = os.cpu_count() or 1
+        per = 8                                           # utterances per worker
         with mp.get_context('fork').Pool(ncpu) as pool:
-            jobs = [(kind, kw, 100 + i) for i in range(2 * ncpu)]
-            pool.map(_fe_job, jobs[:ncpu])                # warm the workers
+            pool.map(_fe_job, [(kind, kw, 50 + i, 1) for i in range(ncpu)], chunksize=1)  # warm
             t0 = time.time()
-            pool.map(_fe_job, jobs)
+            pool.map(_fe_job, [(kind, kw, 100 + i, per) for i in range(ncpu)], chunksize=1)
             dta = time.time() - t0
-        out['frontend_allcores'] = {'value': round(10.0 * len(jobs) / dta, 1),
+        out['frontend_allcores'] = {'value': round(10.0 * per * ncpu / dta, 1),
                                     'unit': 'audio-seconds/s', 'cores': ncpu,
-                                    'sample': '%d x 10 s utterances over a %d-process pool'
-                                              % (len(jobs), ncpu)}
+                                    'sample': '%d x 10 s utterances over a %d-process pool, one '
+                                              'BLAS thread each' % (per * ncpu, ncpu)}
     except Exception as e:                                # never fail the bench on the baseline
         out['frontend_allcores'] = {'error': repr(e)[:200]}
     # (3) cfg1: 26-dim MFCC, 1 x BiLSTM(100), batch 4 x 10 s (the reference's CPU-runnable case)
@@ -158,9 +158,18 @@ def cpu_baseline(cfg):
 
 def _fe_job(job):
     from oracle import frontend as OF
-    kind, kw, seed = job
-    os.environ['OMP_NUM_THREADS'] = '1'
-    return OF.extract(kind, np.random.RandomState(seed).randn(SAMPLES), **kw).shape[0]
+    kind, kw, seed, count = job
+    try:                                   # one BLAS / OpenMP thread per worker process
+        import threadpoolctl
+        ctx = threadpoolctl.threadpool_limits(1)
+    except Exception:
+        ctx = None
+    sig = np.random.RandomState(seed).randn(SAMPLES)
+    n = 0
+    for _ in range(count):
+        n += OF.extract(kind, sig, **kw).shape[0]
+    del ctx
+    return n
 
 
 def _sub_bench(config, env_extra, steps, warmup, dropout):
@@ -188,7 +197,7 @@ def _sub_bench(config, env_extra, steps, warmup, dropout):
                                                'us_per_timestep', 'avg_launch_ms', 'traffic')}
     keep['roofline_gate_gemm'] = {kk: d['roofline_gate_gemm'].get(kk) for kk in
                                   ('kernel', 'achieved', 'peak', 'unit', 'frac',
-                                   'algorithmic_fp32_tflops', 'avg_launch_ms')}
+                                   'algorithmic_fp32_tflops', 'avg_launch_ms', 'pack_ms')}
     return keep
 
 
@@ -366,15 +375,27 @@ def main():
         xg = torch.randn(rows, 2 * H, device=dev)
         wg = torch.randn(2 * H, 8 * H, device=dev) * 0.05
         zg = torch.empty(rows, 8 * H, device=dev)
-        tg = ev_time(lambda: ops.gemm(xg, wg, zg, rows, 8 * H, 2 * H))
         gf = 2.0 * rows * 8 * H * 2 * H
         exact = os.environ.get('ASR_GEMM_PREC', '1') == '0'
+        packed = model.packed
+        t_pack = None
+        if packed:
+            # operands converted once (asr_pack_hl), then the plain fp16 x 3 GEMM (asr_gemm_hl)
+            pa, pb = ops.HlPlanes(rows, 2 * H, dev), ops.HlPlanes(8 * H, 2 * H, dev)
+            one = torch.ones(1, device=dev)
+            ops.pack_hl(wg, 2 * H, 8 * H, absmax=ops.absmax(wg), c=pb)
+            t_pack = ev_time(lambda: ops.pack_hl(xg, rows, 2 * H, absmax=one, r=pa))
+            tg = ev_time(lambda: ops.gemm_hl(pa, pb, zg, rows, 8 * H, 2 * H))
+        else:
+            tg = ev_time(lambda: ops.gemm(xg, wg, zg, rows, 8 * H, 2 * H))
         # split-fp16: every fp32 product is three fp16 MFMAs, so the matrix pipes execute
         # 3x the algorithmic flops; the roofline is the dense fp16 MFMA peak
         mult, peak = (1, PEAK_F32_MFMA_TFLOPS) if exact else (3, PEAK_F16_MFMA_TFLOPS)
         extra['roofline_gate_gemm'] = {
             'kernel': '%s %dx%dx%d (x@W, one BiLSTM layer)' % (
-                'gemm_f32_mfma_kernel' if exact else 'gemm_f16x2_fast_kernel', rows, 8 * H, 2 * H),
+                'gemm_f32_mfma_kernel' if exact else
+                'gemm_hl_kernel' if packed else 'gemm_f16x2_fast_kernel', rows, 8 * H, 2 * H),
+            'pack_ms': None if t_pack is None else round(t_pack, 4),
             'bound': 'mfma', 'achieved': round(mult * gf / tg / 1e9, 2), 'peak': peak,
             'unit': 'TFLOP/s', 'frac': round(mult * gf / tg / 1e9 / peak, 4),
             'algorithmic_fp32_tflops': round(gf / tg / 1e9, 2),
@@ -399,6 +420,7 @@ def main():
                     'reachable for a sequential recursion (DESIGN.md 8) and the kernel is '
                     'about 1 % of the step'}
         del xg, wg, zg, lg, gg
+        pa = pb = None
     if rank == 0:
         T = 999
         n_pad = ops.pad16(N)

@@ -156,3 +156,106 @@ def test_gate_projection_roles(masked):
         torch.cuda.synchronize()
         assert np.abs(dW.cpu().numpy()[:, cols] - (x * mrows).T @ dz[:, cols]).max() < 1e-3
         assert np.abs(db.cpu().numpy() - dz[:, cols].sum(0)).max() < 1e-4
+
+
+def _hl_ref(x, s):
+    """float64 value represented by the (hi, lo) planes of x * s."""
+    xs = (x * s).astype(np.float32)
+    hi = xs.astype(np.float16)
+    lo = (xs - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+@pytest.mark.parametrize('rows,cols,ld,period', [(300, 200, 200, 0), (128, 64, 64, 0),
+                                                 (999 * 16, 80, 80, 16), (70, 1024, 1040, 32),
+                                                 (257, 40, 40, 0)])
+def test_pack_hl_planes_both_orientations(rows, cols, ld, period):
+    """asr_pack_hl: hi/lo planes equal the reference split of (src * mask) * scale bit for bit,
+    in the row orientation (K = columns) and the transposed one (K = rows); padding is zero;
+    the scale is the power of two that maps max|src| into [2^8, 2^9)."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(rows + cols)
+    src = (rs.randn(rows, ld) * 3e-3).astype(np.float32)
+    mask = ((rs.rand(period, cols) > 0.2) / 0.8).astype(np.float32) if period else None
+    sd = to_dev(src)
+    amax = ops.absmax(sd)
+    r = ops.HlPlanes(rows, cols, 'cuda:0')
+    c = ops.HlPlanes(cols, rows, 'cuda:0')
+    for t in (r.hi, r.lo, c.hi, c.lo):
+        t.fill_(7.0)
+    ops.pack_hl(sd, rows, cols, ld=ld, mask=to_dev(mask) if period else None, mask_period=period,
+                absmax=amax, r=r, c=c)
+    torch.cuda.synchronize()
+    s = float(r.scale.cpu().numpy()[0])
+    m = np.abs(src).max()
+    assert 2.0 ** 8 <= m * s < 2.0 ** 9 and np.log2(s) == np.round(np.log2(s))
+    x = src[:, :cols].copy()
+    if period:
+        x = x * mask[np.arange(rows) % period]
+    hi, lo = _hl_ref(x, np.float32(s))
+    got_hi, got_lo = r.hi.cpu().numpy(), r.lo.cpu().numpy()
+    assert np.array_equal(got_hi[:, :cols], hi) and np.array_equal(got_lo[:, :cols], lo)
+    assert not got_hi[:, cols:].any() and not got_lo[:, cols:].any()
+    ch, cl = c.hi.cpu().numpy(), c.lo.cpu().numpy()
+    assert np.array_equal(ch[:, :rows], hi.T) and np.array_equal(cl[:, :rows], lo.T)
+    assert not ch[:, rows:].any() and not cl[:, rows:].any()
+    # 22-bit operands: hi + lo reproduces x * s to 2^-22 of the maximum
+    back = hi.astype(np.float64) + lo.astype(np.float64)
+    assert np.abs(back - x.astype(np.float64) * s).max() < 2.0 ** -21 * m * s
+
+
+@pytest.mark.parametrize('M,N,K,sk', [(300, 200, 64, 0), (128, 128, 32, 0), (257, 130, 40, 0),
+                                      (80, 1024, 999 * 16, 0), (1000, 260, 96, 0),
+                                      (512, 96, 704, 3), (63, 2048, 1024, 0)])
+def test_gemm_hl_matches_float64(M, N, K, sk):
+    """asr_gemm_hl on packed planes vs float64: the error of a split-fp16 product is 2^-22
+    relative per term (tolerance as for asr_gemm precision 1); with bias, alpha, beta and a
+    C-row mask, interior and edge tiles, K not a multiple of the 32-wide slab, split-K."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    A = rs.randn(M, K).astype(np.float32)
+    B = (rs.randn(K, N) * 0.05).astype(np.float32)
+    C0 = rs.randn(M, N).astype(np.float32)
+    bias = rs.randn(N).astype(np.float32)
+    cm = ((rs.rand(16, N) > 0.3) / 0.7).astype(np.float32)
+    pa = ops.HlPlanes(M, K, 'cuda:0')
+    pb = ops.HlPlanes(N, K, 'cuda:0')
+    Ad, Bd = to_dev(A), to_dev(B)
+    ops.pack_hl(Ad, M, K, absmax=ops.absmax(Ad), r=pa)
+    ops.pack_hl(Bd, K, N, absmax=ops.absmax(Bd), c=pb)         # B^T planes: (N, K)
+    Cd = to_dev(C0)
+    split = 0 if sk == 0 and K < 4096 else (sk or 'auto')
+    ops.gemm_hl(pa, pb, Cd, M, N, K, alpha=0.75, beta=0.5, bias=to_dev(bias),
+                c_scale=to_dev(cm), c_scale_period=16, split_k=split)
+    torch.cuda.synchronize()
+    want = (0.75 * (A.astype(np.float64) @ B.astype(np.float64)) + bias) * cm[np.arange(M) % 16] \
+        + 0.5 * C0
+    err = report('gemm_hl %dx%dx%d sk=%s' % (M, N, K, split), Cd.cpu().numpy(), want)
+    assert err < 2e-6 * np.abs(A).max() * np.abs(B).max() * K + 2e-5
+
+
+def test_gemm_hl_sub_views_and_k_offsets():
+    """Row / reduction-range offsets into packed planes: the dU = h_prev^T dz pattern (A's K
+    range shifted by one frame against B's) and a column slice of a wider operand."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(5)
+    T, NB, H = 12, 16, 24
+    rows = T * NB
+    y = rs.randn(rows, 2 * H).astype(np.float32)
+    dz = (rs.randn(rows, 8 * H) * 1e-4).astype(np.float32)
+    yd, dzd = to_dev(y), to_dev(dz)
+    py = ops.HlPlanes(2 * H, rows, 'cuda:0')
+    pdz = ops.HlPlanes(8 * H, rows, 'cuda:0')
+    ops.pack_hl(yd, rows, 2 * H, absmax=ops.absmax(yd), c=py)
+    ops.pack_hl(dzd, rows, 8 * H, absmax=ops.absmax(dzd), c=pdz)
+    K = (T - 1) * NB
+    for d in range(2):
+        out = torch.zeros((H, 4 * H), dtype=torch.float32, device='cuda:0')
+        a_k, b_k = (0, NB) if d == 0 else (NB, 0)
+        ops.gemm_hl(py, pdz, out, H, 4 * H, K, a_row=d * H, a_k=a_k, b_row=d * 4 * H, b_k=b_k)
+        torch.cuda.synchronize()
+        ys = y[a_k:a_k + K, d * H:(d + 1) * H].astype(np.float64)
+        zs = dz[b_k:b_k + K, d * 4 * H:(d + 1) * 4 * H].astype(np.float64)
+        want = ys.T @ zs
+        assert report('gemm_hl dU d=%d' % d, out.cpu().numpy(), want) < \
+            2e-6 * np.abs(y).max() * np.abs(dz).max() * K
