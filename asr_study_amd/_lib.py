@@ -113,6 +113,14 @@ SIGNATURES = {
     'asr_gemm_hl_workspace_bytes': (C.c_size_t, [C.POINTER(GemmHlArgs)]),
     'asr_gemm_hl': (C.c_int, [C.POINTER(GemmHlArgs), void_p, C.c_size_t, void_p]),
     'asr_absmax': (C.c_int, [void_p, C.c_int64, void_p, void_p]),
+    'asr_dropout_masks': (C.c_int, [void_p, C.c_int64, C.c_float, C.c_float, C.c_uint64,
+                                    C.c_uint32, C.c_uint32, void_p]),
+    'asr_dropout_apply': (C.c_int, [void_p, void_p, void_p, C.c_int64, C.c_float, C.c_float,
+                                    C.c_uint64, C.c_uint32, C.c_uint32, void_p]),
+    'asr_gaussian_noise': (C.c_int, [void_p, void_p, C.c_int64, C.c_float, C.c_uint64,
+                                     C.c_uint32, C.c_uint32, void_p]),
+    'asr_random_words': (C.c_int, [void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, void_p]),
+    'asr_mul': (C.c_int, [C.c_int64, void_p, void_p, void_p, void_p]),
     'asr_colsum_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'asr_colsum': (C.c_int, [void_p, C.c_int, C.c_int, C.c_int, void_p, C.c_float, void_p,
                              C.c_size_t, void_p]),

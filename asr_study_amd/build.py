@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libasr_hip.so')
 SOURCES = ['capi.cpp', 'ctc.hip', 'frontend.hip', 'gemm.hip', 'lstm.hip', 'lstm_ln.hip',
-           'optim.hip', 'decode_host.cpp', 'comm.cpp', 'roles.cpp']
+           'optim.hip', 'random.hip', 'decode_host.cpp', 'comm.cpp', 'roles.cpp']
 ARCH = 'gfx950'
 
 

@@ -133,8 +133,10 @@ class Model(object):
         self.packed = (_os.environ.get('ASR_GEMM_PACKED', '1') != '0'
                        and _os.environ.get('ASR_GEMM_PREC', '1') != '0')
         self._hl = {}
-        self._rng = torch.Generator(device=self.device)
-        self._rng.manual_seed(int(seed) + 12345)
+        # training-time noise comes from the library's counter-based streams (ops.dropout_masks
+        # ...: Philox-4x32-10 keyed by this seed; stream id = 4 * stage index + kind, step =
+        # the optimisation step), so a step's masks are a pure function of (seed, stage, step)
+        self.rng_seed = (int(seed) + 12345) & (2 ** 64 - 1)
         self._layout(seed)
 
     # ------------------------------------------------------------------ params
@@ -485,16 +487,17 @@ class Model(object):
             rec = {'in': a}
             if s.kind == 'noise':
                 if training and s.value > 0:
-                    noise = torch.randn(a.shape, generator=self._rng, device=self.device)
-                    a = a + s.value * noise
+                    out = self._buf('noise%d' % si, a.shape)
+                    a = ops.gaussian_noise(a, out, s.value, self.rng_seed, 4 * si, self._step)
                     if s.f_out_pad != s.f_out and si == 0:
                         a[:, :, s.f_out:] = 0.0        # keep the input pad columns zero
             elif s.kind == 'dropout':
                 if training and s.value > 0:
-                    keep = (torch.rand(a.shape, generator=self._rng, device=self.device)
-                            >= s.value).to(torch.float32) / (1.0 - s.value)
+                    keep = self._buf('dropmask%d' % si, a.shape)
+                    out = self._buf('dropout%d' % si, a.shape)
+                    a = ops.dropout_apply(a, out, keep, s.value, 1.0 / (1.0 - s.value),
+                                          self.rng_seed, 4 * si, self._step)
                     rec['mask'] = keep
-                    a = a * keep
             elif s.kind == 'merge':       # residual: c * (new + skip)
                 out = self._buf('merge%d' % si, a.shape)
                 a = ops.axpby(s.coef, a, s.coef, self._acts[s.skip]['out'], out)
@@ -595,8 +598,8 @@ class Model(object):
                         return None
                     buf = self._buf('%s%d' % (name, si), (T, 2, s.Hp))
                     if training:    # keep mask, shared over the batch, fresh every frame
-                        buf.copy_((torch.rand(buf.shape, generator=self._rng, device=self.device)
-                                   >= level).to(torch.float32))
+                        ops.dropout_masks(buf, level, 1.0, self.rng_seed,
+                                          4 * si + (2 if name == 'zonec' else 3), self._step)
                     else:           # test phase: (h - h_prev) * (1 - level) + h_prev
                         buf.fill_(1.0 - level)
                     return buf
@@ -642,36 +645,22 @@ class Model(object):
                           dx_beta=0.0 if d == 0 else 1.0)
 
     def _draw_all_masks(self, n_pad):
-        """Variational-dropout masks of every BiLSTM stage for one batch, drawn with ONE
-        uniform fill + one select over a flat buffer (per-element drop probabilities and
-        1/(1-p) scales are cached): {stage: (B_W (2, n_pad, in), B_U (2, n_pad, H))}."""
-        plan = self._mask_plan.get(n_pad) if hasattr(self, '_mask_plan') else None
-        if plan is None:
-            if not hasattr(self, '_mask_plan'):
-                self._mask_plan = {}
-            segs, pvals, off = [], [], 0
-            for si, s in enumerate(self.stages):
-                if s.kind != 'bilstm' or not (s.dropout_W > 0 or s.dropout_U > 0):
-                    continue
-                nw, nu = 2 * n_pad * s.f_in_pad, 2 * n_pad * s.Hp
-                segs.append((si, off, nw, nu, s.f_in_pad, s.Hp))
-                pvals += [(nw, s.dropout_W), (nu, s.dropout_U)]
-                off += nw + nu
-            if off == 0:
-                plan = (segs, None, None, 0)
-            else:
-                p = torch.cat([torch.full((n,), float(v)) for n, v in pvals]).to(self.device)
-                plan = (segs, p, 1.0 / (1.0 - p), off)
-            self._mask_plan[n_pad] = plan
-        segs, p, scale, total = plan
-        if total == 0:
-            return {}
-        u = torch.rand(total, generator=self._rng, device=self.device)
-        flat = torch.where(u >= p, scale, torch.zeros((), device=self.device))
+        """Variational-dropout masks of every BiLSTM stage for one batch (core/models.py:265-266:
+        one mask per batch and direction, constant over time, inverted scaling), from the
+        library's counter-based streams: {stage: (B_W (2, n_pad, in), B_U (2, n_pad, H))} with
+        stream id 4 * stage (B_W) / 4 * stage + 1 (B_U) at step self._step."""
         out = {}
-        for si, off, nw, nu, fin, Hp in segs:
-            out[si] = (flat[off:off + nw].view(2, n_pad, fin),
-                       flat[off + nw:off + nw + nu].view(2, n_pad, Hp))
+        for si, s in enumerate(self.stages):
+            if s.kind != 'bilstm' or not (s.dropout_W > 0 or s.dropout_U > 0):
+                continue
+            BW = self._buf('BW%d' % si, (2, n_pad, s.f_in_pad))
+            BU = self._buf('BU%d' % si, (2, n_pad, s.Hp))
+            for k, (t, p) in enumerate(((BW, s.dropout_W), (BU, s.dropout_U))):
+                if p > 0:
+                    ops.dropout_masks(t, p, 1.0 / (1.0 - p), self.rng_seed, 4 * si + k, self._step)
+                else:
+                    t.fill_(1.0)
+            out[si] = (BW, BU)
         return out
 
     # ------------------------------------------------------------------ backward
@@ -726,7 +715,7 @@ class Model(object):
                 continue
             if s.kind == 'dropout':
                 if 'mask' in rec:
-                    da = da * rec['mask']
+                    da = ops.mul(da, rec['mask'], self._buf('ddrop%d' % si, da.shape))
                 continue
             if s.kind == 'dense':
                 gmx = ops.absmax(da, self._buf('damax%d' % si, (1,)))

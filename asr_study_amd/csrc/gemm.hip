@@ -1042,6 +1042,182 @@ gemm_hl_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int split
     }
 }
 
+// ---------------------------------------------------------------------------
+// 256 x 256 x 32 tile variant of gemm_hl_kernel (the default for outputs of at least 256 x 256).
+// With 128 x 128 tiles both split-fp16 GEMMs sit at ~250 TF/s algorithmic whatever the K loop
+// costs: a workgroup moves 32 KB from L2 per 1 MFLOP (32 flop/B), i.e. ~7.5 TB/s at that
+// rate, with an L2 hit rate of ~72 % -- the loop is fed at the L2 / fabric rate.  A 256 x 256
+// tile halves the bytes per flop.  512 threads = 8 waves (2 x 4, 128 x 64 each = 4 x 2 MFMA
+// tiles, 128 accumulator registers); LDS image per plane [256 rows][32 halfs] UNPADDED
+// (64-byte rows; 4 planes x 2 buffers = 128 KB) with the 16-byte chunk index XOR-swizzled by
+// (row >> 2) & 3, which makes both the ds_write_b128 of the staging pass and the ds_read_b128
+// of the fragments bank-conflict free (lane groups of MI355X_MICROARCH.md "LDS").
+constexpr int TM2 = 256, TN2 = 256;
+
+__device__ __forceinline__ int hl256_slot(int row, int kc) {      // half index in a plane
+  return row * 32 + ((kc ^ ((row >> 2) & 3)) << 3);
+}
+
+struct HlLoader256 {
+  __amdgpu_buffer_rsrc_t rh, rl;
+  unsigned off[2];
+  int kq[2];
+  int k_begin, k_end;
+  __device__ __forceinline__ void init(const HlSrc& s, int row0, int kb, int ke) {
+    const int tid = threadIdx.x;
+    rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.hi), 0, s.extent, 0x00020000);
+    rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.lo), 0, s.extent, 0x00020000);
+    k_begin = kb; k_end = ke;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = tid + 512 * i;                // 256 rows x 4 chunks
+      const int row = row0 + (ch >> 2);
+      kq[i] = 8 * (ch & 3);
+      off[i] = row < s.rows ? (unsigned)(((size_t)row * s.ld + kb + kq[i]) * 2) : kOob;
+    }
+  }
+  __device__ __forceinline__ void load(int kt, u32x4g (&h)[2], u32x4g (&l)[2]) const {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = k_begin + kt * HBK + kq[i] < k_end && off[i] != kOob;
+      const unsigned o = ok ? off[i] + (unsigned)(kt * HBK * 2) : kOob;
+      h[i] = __builtin_amdgcn_raw_buffer_load_b128(rh, o, 0, 0);
+      l[i] = __builtin_amdgcn_raw_buffer_load_b128(rl, o, 0, 0);
+    }
+  }
+  __device__ __forceinline__ static void store(const u32x4g (&h)[2], const u32x4g (&l)[2],
+                                               _Float16* Shi, _Float16* Slo) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = tid + 512 * i;
+      const int slot = hl256_slot(ch >> 2, ch & 3);
+      *reinterpret_cast<u32x4g*>(Shi + slot) = h[i];
+      *reinterpret_cast<u32x4g*>(Slo + slot) = l[i];
+    }
+  }
+};
+
+__global__ void __launch_bounds__(512)
+gemm_hl256_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int splits,
+                  Epilogue ep, const float* __restrict__ a_scale,
+                  const float* __restrict__ b_scale) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
+  constexpr int kPlane = 256 * 32;                   // halfs per plane
+  auto plane = [&](int buf, int which) { return hsm + (size_t)(buf * 4 + which) * kPlane; };
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;           // 2 x 4 waves, 128 x 64 each
+  const TileId tb = tile_of_block((M + TM2 - 1) / TM2, (N + TN2 - 1) / TN2, splits);
+  const int m0 = tb.tm * TM2, n0 = tb.tn * TN2;
+  const int k_begin = tb.z * k_per_split;
+  int k_end = k_begin + k_per_split;
+  if (k_end > K) k_end = K;
+  const float sa = a_scale ? *a_scale : 1.f, sb = b_scale ? *b_scale : 1.f;
+
+  f32x16 am[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) am[i][j][e] = 0.f;
+
+  HlLoader256 la, lb;
+  la.init(A, m0, k_begin, k_end);
+  lb.init(B, n0, k_begin, k_end);
+  // one register set: the loads of slab kt+1 are issued before slab kt is multiplied and
+  // written to the other LDS buffer after it (48 MFMAs per wave = their latency cover)
+  u32x4g ah[2], al[2], bh[2], bl[2];
+  const int nk = (k_end - k_begin + HBK - 1) / HBK;
+  la.load(0, ah, al);
+  lb.load(0, bh, bl);
+  HlLoader256::store(ah, al, plane(0, 0), plane(0, 1));
+  HlLoader256::store(bh, bl, plane(0, 2), plane(0, 3));
+  __syncthreads();
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    // past the last slab every offset is out of range: those loads return zeros, unused
+    la.load(kt + 1, ah, al);
+    lb.load(kt + 1, bh, bl);
+    const _Float16* Ah = plane(cur, 0);
+    const _Float16* Al = plane(cur, 1);
+    const _Float16* Bh = plane(cur, 2);
+    const _Float16* Bl = plane(cur, 3);
+#pragma unroll
+    for (int ks = 0; ks < HBK / 16; ++ks) {
+      hx8 fah[4], fal[4], fbh[2], fbl[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int slot = hl256_slot(wm * 128 + i * 32 + lrow, 2 * ks + lhalf);
+        fah[i] = *reinterpret_cast<const hx8*>(Ah + slot);
+        fal[i] = *reinterpret_cast<const hx8*>(Al + slot);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int slot = hl256_slot(wn * 64 + j * 32 + lrow, 2 * ks + lhalf);
+        fbh[j] = *reinterpret_cast<const hx8*>(Bh + slot);
+        fbl[j] = *reinterpret_cast<const hx8*>(Bl + slot);
+      }
+      // term-major order: consecutive MFMAs go to eight different accumulators
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh[j], am[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], am[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], am[i][j], 0, 0, 0);
+    }
+    HlLoader256::store(ah, al, plane(nxt, 0), plane(nxt, 1));
+    HlLoader256::store(bh, bl, plane(nxt, 2), plane(nxt, 3));
+    __syncthreads();
+  }
+  const float unscale = 1.f / (sa * sb);
+  const int lcol = lane & 31;
+  const bool interior = m0 + TM2 <= M && n0 + TN2 <= N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + lcol;
+      const int row0 = m0 + wm * 128 + i * 32 + 4 * lhalf;
+      if (!interior && col >= N) continue;
+      if (ep.partial) {
+        float* dst = ep.partial + ((size_t)tb.z * M + row0) * N + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int dr = (e & 3) + 8 * (e >> 2);
+          if (interior || row0 + dr < M) dst[(size_t)dr * N] = am[i][j][e] * unscale;
+        }
+        continue;
+      }
+      float* dst = ep.C + (size_t)row0 * ep.ldc + col;
+      const float bias = ep.bias ? ep.bias[col] : 0.f;
+      const bool use_old = ep.beta != 0.f;
+      const bool use_msk = ep.c_scale != nullptr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int dr = (e & 3) + 8 * (e >> 2);
+        if (!(interior || row0 + dr < M)) continue;
+        float v = am[i][j][e] * unscale * ep.alpha + bias;
+        if (use_msk)
+          v *= ep.c_scale[(size_t)mod_period(row0 + dr, ep.c_period) * ep.c_ld + col];
+        if (use_old) v += ep.beta * dst[(size_t)dr * ep.ldc];
+        dst[(size_t)dr * ep.ldc] = v;
+      }
+    }
+}
+
 // max |x| of a flat tensor -> out[0] (float).  Two launches: per-block maxima via
 // atomicMax on the float bits (all non-negative, so integer order == float order).
 __global__ void __launch_bounds__(256)
@@ -1375,9 +1551,25 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     attr_done = true;
   }
-  const int total = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) * splits;
-  hipLaunchKernelGGL(gemm_hl_kernel, dim3(total), dim3(256), shm, stream, A, B, a->M, a->N, a->K,
-                     kps, splits, ep, a->a_scale, a->b_scale);
+  // tile: 256 x 256 (512 threads, 128 KB LDS) for outputs of at least that size, else 128 x 128
+  // (ASR_GEMM_HL_TILE=128 forces the small tile)
+  static const int tile_env = [] { const char* v = getenv("ASR_GEMM_HL_TILE"); return v ? atoi(v) : 256; }();
+  if (tile_env >= 256 && a->M >= TM2 && a->N >= TN2) {
+    const size_t shm2 = (size_t)2 * 4 * 256 * 32 * sizeof(_Float16);
+    static bool attr2_done = false;
+    if (!attr2_done) {
+      ASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hl256_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
+      attr2_done = true;
+    }
+    const int total = ((a->M + TM2 - 1) / TM2) * ((a->N + TN2 - 1) / TN2) * splits;
+    hipLaunchKernelGGL(gemm_hl256_kernel, dim3(total), dim3(512), shm2, stream, A, B, a->M, a->N,
+                       a->K, kps, splits, ep, a->a_scale, a->b_scale);
+  } else {
+    const int total = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) * splits;
+    hipLaunchKernelGGL(gemm_hl_kernel, dim3(total), dim3(256), shm, stream, A, B, a->M, a->N,
+                       a->K, kps, splits, ep, a->a_scale, a->b_scale);
+  }
   ASR_CHECK_LAUNCH();
   if (splits > 1) {
     Epilogue ep2 = ep;

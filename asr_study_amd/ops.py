@@ -493,3 +493,47 @@ def gemm_hl(A, B, Cm, M, N, K, a_row=0, a_k=0, b_row=0, b_k=0, c_off=0, ldc=None
     nbytes = lib.asr_gemm_hl_workspace_bytes(C.byref(g))
     ws = WS.get(ws_name, nbytes, Cm.device) if nbytes else None
     L.check(lib.asr_gemm_hl(C.byref(g), _ptr(ws), nbytes, _stream()), 'asr_gemm_hl')
+
+
+# --------------------------------------------------------------------------- random streams
+def dropout_masks(out, p, scale, seed, stream_id, step):
+    """out (any shape, contiguous float32) <- keep mask of the stream (seed, stream_id, step):
+    scale where u >= p, else 0 (include/asr_hip.h K12)."""
+    _check_f32(out)
+    L.check(L.load().asr_dropout_masks(_ptr(out), out.numel(), float(p), float(scale),
+                                       int(seed) & (2 ** 64 - 1), int(stream_id), int(step),
+                                       _stream()), 'asr_dropout_masks')
+    return out
+
+
+def dropout_apply(x, out, mask_out, p, scale, seed, stream_id, step):
+    _check_f32(x, out, mask_out)
+    L.check(L.load().asr_dropout_apply(_ptr(x), _ptr(out), _ptr(mask_out), x.numel(), float(p),
+                                       float(scale), int(seed) & (2 ** 64 - 1), int(stream_id),
+                                       int(step), _stream()), 'asr_dropout_apply')
+    return out
+
+
+def gaussian_noise(x, out, sigma, seed, stream_id, step):
+    """out = x + sigma * N(0, 1) (x may be None: pure noise)."""
+    _check_f32(x, out)
+    L.check(L.load().asr_gaussian_noise(_ptr(x), _ptr(out), out.numel(), float(sigma),
+                                        int(seed) & (2 ** 64 - 1), int(stream_id), int(step),
+                                        _stream()), 'asr_gaussian_noise')
+    return out
+
+
+def random_words(n, seed, stream_id, step, device):
+    out = torch.empty(int(n), dtype=torch.int32, device=device)
+    L.check(L.load().asr_random_words(_ptr(out), int(n), int(seed) & (2 ** 64 - 1),
+                                      int(stream_id), int(step), _stream()), 'asr_random_words')
+    return out
+
+
+def mul(x, y, out=None):
+    _check_f32(x, y, out)
+    assert x.numel() == y.numel()
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.load().asr_mul(x.numel(), _ptr(x), _ptr(y), _ptr(out), _stream()), 'asr_mul')
+    return out

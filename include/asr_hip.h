@@ -448,6 +448,33 @@ int asr_gemm_gate_dgrad(const asr_gate_gemm_args* g, void* workspace, size_t ws_
 int asr_gemm_gate_wgrad(const asr_gate_gemm_args* g, void* workspace, size_t ws_bytes,
                         asr_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* K12 counter-based random numbers for the training-time noise of the path:  */
+/* replaces the TF random ops behind GaussianNoise (core/models.py:250-251),  */
+/* the input Dropout (:257-258), the variational dropout masks B_W / B_U      */
+/* (:265-266; one mask per batch, inverted scaling) and the zoneout keep      */
+/* masks (core/layers_utils.py:34-42).  Philox-4x32-10; key = seed, counter = */
+/* (block, stream_id, step, block >> 32); element 4b+j = word j of block b.   */
+/* Stateless: (seed, stream_id, step) fully determine the tensor.             */
+/*   asr_dropout_masks : out[i] = u_i >= p ? scale : 0, u = (word >> 8) 2^-24 */
+/*   asr_dropout_apply : out = in * that mask (mask_out receives it, or NULL) */
+/*   asr_gaussian_noise: out = in + sigma * N(0,1) (Box-Muller; in may be     */
+/*                       NULL = pure noise, or equal to out)                  */
+/*   asr_random_words  : the raw 32-bit words (tests)                         */
+/*   asr_mul           : out = x * y elementwise (mask applied to a gradient) */
+/* All pointers 16-byte aligned device memory.                                */
+/* ------------------------------------------------------------------------ */
+int asr_dropout_masks(float* out, int64_t n, float p, float scale, uint64_t seed,
+                      uint32_t stream_id, uint32_t step, asr_stream_t stream);
+int asr_dropout_apply(const float* in, float* out, float* mask_out, int64_t n, float p,
+                      float scale, uint64_t seed, uint32_t stream_id, uint32_t step,
+                      asr_stream_t stream);
+int asr_gaussian_noise(const float* in, float* out, int64_t n, float sigma, uint64_t seed,
+                       uint32_t stream_id, uint32_t step, asr_stream_t stream);
+int asr_random_words(unsigned* out, int64_t n, uint64_t seed, uint32_t stream_id, uint32_t step,
+                     asr_stream_t stream);
+int asr_mul(int64_t n, const float* x, const float* y, float* out, asr_stream_t stream);
+
 /* K9 / K10 under their operation names (same arguments as the *_host forms).  */
 int asr_ctc_beam(const float* logits_host, const int* seq_len_host, int T, int N,
                  int n_pad, int C, int beam_width, int merge_repeated, int* decoded,

@@ -204,7 +204,8 @@ def test_pack_hl_planes_both_orientations(rows, cols, ld, period):
     assert np.abs(back - x.astype(np.float64) * s).max() < 2.0 ** -21 * m * s
 
 
-@pytest.mark.parametrize('M,N,K,sk', [(300, 200, 64, 0), (128, 128, 32, 0), (257, 130, 40, 0),
+@pytest.mark.parametrize('M,N,K,sk', [(300, 200, 64, 0), (128, 128, 32, 0), (257, 132, 40, 0),
+                                      (700, 512, 160, 0), (1024, 768, 2048, 4),
                                       (80, 1024, 999 * 16, 0), (1000, 260, 96, 0),
                                       (512, 96, 704, 3), (63, 2048, 1024, 0)])
 def test_gemm_hl_matches_float64(M, N, K, sk):
