@@ -20,8 +20,8 @@ class FrontendCfg(C.Structure):
                 ('nfft', C.c_int), ('num_filt', C.c_int), ('num_cep', C.c_int),
                 ('append_energy', C.c_int), ('d', C.c_int), ('dd', C.c_int),
                 ('stride', C.c_int), ('num_context', C.c_int),
-                ('mean_norm', C.c_int), ('var_norm', C.c_int),
-                ('pre_emph', C.c_float), ('eps', C.c_float)]
+                ('mean_norm', C.c_int), ('var_norm', C.c_int), ('reserved', C.c_int),
+                ('pre_emph', C.c_double), ('eps', C.c_double)]
 
 
 class GemmArgs(C.Structure):

@@ -130,8 +130,11 @@ class Model(object):
         self._pipe = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         # big GEMMs on operands packed once into split-fp16 planes (ops.pack_hl / gemm_hl);
         # ASR_GEMM_PACKED=0 keeps the convert-per-tile kernels, ASR_GEMM_PREC=0 (exact fp32) too
-        self.packed = (_os.environ.get('ASR_GEMM_PACKED', '1') != '0'
-                       and _os.environ.get('ASR_GEMM_PREC', '1') != '0')
+        # 'auto': from 512 hidden units on (measured: +4 % at 5 x BiLSTM(512) with the 256 x 256
+        # tile, -6 % at 5 x BiLSTM(256), where the frame-range pipelining of the per-tile path
+        # and the absent pack passes win)
+        self._packed_mode = _os.environ.get('ASR_GEMM_PACKED', 'auto')
+        self.packed = False                       # decided in _layout (needs the stage list)
         self._hl = {}
         # training-time noise comes from the library's counter-based streams (ops.dropout_masks
         # ...: Philox-4x32-10 keyed by this seed; stream id = 4 * stage index + kind, step =
@@ -232,6 +235,10 @@ class Model(object):
             s.f_out, s.f_out_pad = f_real, f_pad
             s.p_hi = off
             self.stages.append(s)
+        import os as _os
+        widest = max([st.Hp for st in self.stages if st.kind == 'bilstm'] + [0])
+        self.packed = (_os.environ.get('ASR_GEMM_PREC', '1') != '0' and
+                       (self._packed_mode == '1' or (self._packed_mode == 'auto' and widest >= 512)))
         self.num_classes = f_real
         self.n_params = off
         self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
@@ -397,7 +404,8 @@ class Model(object):
 
     def _stage_packed(self, s):
         """Whether a BiLSTM stage's GEMMs run on packed operands (plain cell only)."""
-        return self.packed and s.kind == 'bilstm' and s.mi is None and s.ln is None
+        return (self.packed and s.kind == 'bilstm' and s.mi is None and s.ln is None
+                and s.f_in_pad % 8 == 0 and s.Hp % 8 == 0)      # 16-byte rows of the planes
 
     def _pack_weights(self):
         """W of every packed stage -> planes for x@W (reduction over the input features:

@@ -11,8 +11,14 @@
 //   Stockham FFT (4 stages x one butterfly per lane) in LDS plus the real-FFT
 //   split; power spectrum, frame energy, the (sparse) triangular mel filters,
 //   log and the 13-column DCT (lifter folded into the table) all stay in LDS /
-//   registers.  Only T x (13 | nfilt[+1]) base features are written.
-// Kernel 2 (fe_finalize_kernel): one workgroup per utterance.  Deltas and
+//   registers.  Only T x (13 | nfilt[+1]) base features are written.  This per-frame chain
+//   runs in FLOAT64 (tables included): the reference computes in float64, and a float32
+//   FFT leaves ~1e-7 x the frame's largest bin as absolute error in every bin, which under
+//   a nearly empty narrow mel filter became 3.6e-4 after log and standardisation; in float64
+//   the standardised features agree with the reference to ~1e-5 (test bar: 1e-4).  The
+//   kernel is ~0.3 ms of a 50 ms step, so the fp64 rate is irrelevant.
+// Kernel 2 (fe_finalize_kernel), float64 too (the base features stay float64 in the
+//   workspace; only the standardised output is float32): one workgroup per utterance.  Deltas and
 //   delta-deltas (edge-replicated, audio_utils.py:153-173), stride / context
 //   stacking, per-column mean / population-std (float64 accumulators, wave
 //   shuffles + LDS) and the normalised write into the time-major (T, N, F) slab,
@@ -26,24 +32,22 @@ constexpr int NBINS = NFFT / 2 + 1;     // 257
 constexpr int FRAMES_PER_WAVE = 4;
 constexpr int WAVES = 4;
 constexpr int FRAMES_PER_BLOCK = FRAMES_PER_WAVE * WAVES;
-constexpr float kF64Eps = 2.220446049250313e-16f;   // np.finfo(float).eps
+constexpr double kF64Eps = 2.220446049250313e-16;   // np.finfo(float).eps
 
-struct float2c { float x, y; };
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
 __global__ void __launch_bounds__(256)
 fe_frames_kernel(asr_frontend_cfg cfg, const float* __restrict__ audio,
                  const int* __restrict__ offsets, const int* __restrict__ lengths,
-                 const float* __restrict__ window, const float* __restrict__ mel,
-                 const int* __restrict__ mel_range, const float* __restrict__ dct,
-                 float* __restrict__ base, int max_frames, int fb) {
-  __shared__ float2 tw[384 + 1];                 // e^{-2 pi i m / 512}, m = 0..384
-  __shared__ float2 buf[WAVES][2][256];          // ping-pong complex buffers
-  __shared__ float pspec[WAVES][NBINS + 3];
-  __shared__ float lmel[WAVES][128];
+                 const double* __restrict__ window, const double* __restrict__ mel,
+                 const int* __restrict__ mel_range, const double* __restrict__ dct,
+                 double* __restrict__ base, int max_frames, int fb) {
+  __shared__ double2 tw[384 + 1];                // e^{-2 pi i m / 512}, m = 0..384
+  __shared__ double2 buf[WAVES][2][256];         // ping-pong complex buffers
+  __shared__ double pspec[WAVES][NBINS + 3];
+  __shared__ double lmel[WAVES][128];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -58,25 +62,25 @@ fe_frames_kernel(asr_frontend_cfg cfg, const float* __restrict__ audio,
   if (f_block >= nframes) return;                 // uniform per block
 
   for (int m = tid; m <= 384; m += 256) {
-    float s, c;
-    sincospif(-(float)m / 256.0f, &s, &c);        // angle = -2 pi m / 512
-    tw[m] = make_float2(c, s);
+    double s, c;
+    sincospi(-(double)m / 256.0, &s, &c);         // angle = -2 pi m / 512
+    tw[m] = make_double2(c, s);
   }
   __syncthreads();
 
-  float* real_in = reinterpret_cast<float*>(&buf[w][0][0]);   // 512 reals == 256 complex
+  double* real_in = reinterpret_cast<double*>(&buf[w][0][0]);   // 512 reals == 256 complex
   for (int fi = 0; fi < FRAMES_PER_WAVE; ++fi) {
     const int f = f_block + w * FRAMES_PER_WAVE + fi;
     const bool live = f < nframes;
     // ---- load + pre-emphasis + window (zero padded to 512)
     const int s0 = f * cfg.frame_step;
     for (int i = lane; i < NFFT; i += 64) {
-      float v = 0.f;
+      double v = 0.0;
       if (live && i < cfg.frame_len) {
         const int idx = s0 + i;
         if (idx < len) {
-          const float x = audio[off + idx];
-          const float xp = idx > 0 ? audio[off + idx - 1] : 0.f;
+          const double x = (double)audio[off + idx];
+          const double xp = idx > 0 ? (double)audio[off + idx - 1] : 0.0;
           v = (idx > 0 ? x - cfg.pre_emph * xp : x) * window[i];
         }
       }
@@ -88,66 +92,66 @@ fe_frames_kernel(asr_frontend_cfg cfg, const float* __restrict__ audio,
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int Ns = 1 << (2 * s);
-      const float2* in = buf[w][cur];
-      float2* out = buf[w][cur ^ 1];
+      const double2* in = buf[w][cur];
+      double2* out = buf[w][cur ^ 1];
       const int j = lane;
       const int k = j & (Ns - 1);
-      float2 v0 = in[j], v1 = in[j + 64], v2 = in[j + 128], v3 = in[j + 192];
+      double2 v0 = in[j], v1 = in[j + 64], v2 = in[j + 128], v3 = in[j + 192];
       if (s > 0) {
         const int tstep = (128 / Ns) * k;        // index into tw (512-based): 2*(64/Ns)*k
         v1 = cmul(v1, tw[tstep]);
         v2 = cmul(v2, tw[2 * tstep]);
         v3 = cmul(v3, tw[3 * tstep]);
       }
-      const float2 t0 = make_float2(v0.x + v2.x, v0.y + v2.y);
-      const float2 t1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-      const float2 t2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-      const float2 d = make_float2(v1.x - v3.x, v1.y - v3.y);
-      const float2 t3 = make_float2(d.y, -d.x);  // -i * (v1 - v3)
+      const double2 t0 = make_double2(v0.x + v2.x, v0.y + v2.y);
+      const double2 t1 = make_double2(v0.x - v2.x, v0.y - v2.y);
+      const double2 t2 = make_double2(v1.x + v3.x, v1.y + v3.y);
+      const double2 d = make_double2(v1.x - v3.x, v1.y - v3.y);
+      const double2 t3 = make_double2(d.y, -d.x);  // -i * (v1 - v3)
       const int base_idx = ((j - k) << 2) + k;   // (j / Ns) * Ns * 4 + k
-      out[base_idx] = make_float2(t0.x + t2.x, t0.y + t2.y);
-      out[base_idx + Ns] = make_float2(t1.x + t3.x, t1.y + t3.y);
-      out[base_idx + 2 * Ns] = make_float2(t0.x - t2.x, t0.y - t2.y);
-      out[base_idx + 3 * Ns] = make_float2(t1.x - t3.x, t1.y - t3.y);
+      out[base_idx] = make_double2(t0.x + t2.x, t0.y + t2.y);
+      out[base_idx + Ns] = make_double2(t1.x + t3.x, t1.y + t3.y);
+      out[base_idx + 2 * Ns] = make_double2(t0.x - t2.x, t0.y - t2.y);
+      out[base_idx + 3 * Ns] = make_double2(t1.x - t3.x, t1.y - t3.y);
       cur ^= 1;
       __syncthreads();
     }
     // ---- real-FFT split + power spectrum / nfft, frame energy
-    const float2* Z = buf[w][cur];
-    float esum = 0.f;
+    const double2* Z = buf[w][cur];
+    double esum = 0.0;
     for (int k = lane; k < NBINS; k += 64) {
-      const float2 zk = Z[k & 255];
-      const float2 zc = Z[(256 - k) & 255];
-      const float2 zn = make_float2(zc.x, -zc.y);                 // conj
-      const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
-      const float2 dd = make_float2(zk.x - zn.x, zk.y - zn.y);
-      const float2 o = make_float2(0.5f * dd.y, -0.5f * dd.x);    // -i/2 * (zk - zn)
-      const float2 wo = cmul(tw[k], o);
-      const float xr = e.x + wo.x, xi = e.y + wo.y;
-      const float p = (xr * xr + xi * xi) * (1.0f / NFFT);
+      const double2 zk = Z[k & 255];
+      const double2 zc = Z[(256 - k) & 255];
+      const double2 zn = make_double2(zc.x, -zc.y);                 // conj
+      const double2 e = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y + zn.y));
+      const double2 dd = make_double2(zk.x - zn.x, zk.y - zn.y);
+      const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);      // -i/2 * (zk - zn)
+      const double2 wo = cmul(tw[k], o);
+      const double xr = e.x + wo.x, xi = e.y + wo.y;
+      const double p = (xr * xr + xi * xi) * (1.0 / NFFT);
       pspec[w][k] = p;
       esum += p;
     }
-    esum = asr_wave_sum(esum);
-    if (esum == 0.f) esum = kF64Eps;
+    esum = asr_wave_sum_d(esum);
+    if (esum == 0.0) esum = kF64Eps;
     __syncthreads();
     // ---- mel filterbank (triangles are sparse: only [lo, hi) bins) + log
     for (int jf = lane; jf < cfg.num_filt; jf += 64) {
       const int lo = mel_range[2 * jf], hi = mel_range[2 * jf + 1];
-      const float* mrow = mel + (size_t)jf * NBINS;
-      float acc = 0.f;
+      const double* mrow = mel + (size_t)jf * NBINS;
+      double acc = 0.0;
       for (int k = lo; k < hi; ++k) acc += pspec[w][k] * mrow[k];
-      if (acc == 0.f) acc = kF64Eps;
-      lmel[w][jf] = logf(acc);
+      if (acc == 0.0) acc = kF64Eps;
+      lmel[w][jf] = log(acc);
     }
     __syncthreads();
     // ---- write base features
     if (live) {
-      float* row = base + ((size_t)utt * max_frames + f) * fb;
-      const float le = logf(esum + cfg.eps);
+      double* row = base + ((size_t)utt * max_frames + f) * fb;
+      const double le = log(esum + cfg.eps);
       if (cfg.kind == 0) {
         for (int c = lane; c < cfg.num_cep; c += 64) {
-          float acc = 0.f;
+          double acc = 0.0;
           for (int jf = 0; jf < cfg.num_filt; ++jf)
             acc += lmel[w][jf] * dct[jf * cfg.num_cep + c];
           if (c == 0 && cfg.append_energy) acc = le;
@@ -163,17 +167,17 @@ fe_frames_kernel(asr_frontend_cfg cfg, const float* __restrict__ audio,
 }
 
 // full[t][0:fb] = base, [fb:2fb] = delta, [2fb:3fb] = delta-delta
-__device__ __forceinline__ float delta_at(const float* __restrict__ x, int ld, int T, int t,
-                                          int c) {
+__device__ __forceinline__ double delta_at(const double* __restrict__ x, int ld, int T, int t,
+                                           int c) {
   // sum_{n=-2..2} n * x[clamp(t+n)] / 10, same association order as the reference
-  float acc = 0.f;
+  double acc = 0.0;
 #pragma unroll
   for (int n = -2; n <= 2; ++n) {
     int tt = t + n;
     tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
-    acc += (float)n * x[(size_t)tt * ld + c];
+    acc += (double)n * x[(size_t)tt * ld + c];
   }
-  return acc / 10.0f;
+  return acc / 10.0;
 }
 
 // one 1024-thread workgroup per utterance: 16 row walkers per feature column
@@ -181,7 +185,7 @@ constexpr int kFinalizeThreads = 1024;
 
 __global__ void __launch_bounds__(1024)
 fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
-                   float* __restrict__ full, int max_frames, int fb, int ffull,
+                   double* __restrict__ full, int max_frames, int fb, int ffull,
                    float* __restrict__ out, int t_out, int n_pad, int f_out,
                    int* __restrict__ out_frames) {
   const int utt = blockIdx.x;
@@ -190,7 +194,7 @@ fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
   int T = 1;
   if (len > cfg.frame_len) T = 1 + (len - cfg.frame_len + cfg.frame_step - 1) / cfg.frame_step;
   if (T > max_frames) T = max_frames;
-  float* x = full + (size_t)utt * max_frames * ffull;
+  double* x = full + (size_t)utt * max_frames * ffull;
   // ---- deltas (global scratch, visible block-wide after the barrier)
   if (cfg.d) {
     for (int e = tid; e < T * fb; e += kFinalizeThreads) {
@@ -209,10 +213,10 @@ fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
   const int stride = cfg.stride < 1 ? 1 : cfg.stride;
   const int Ts = (T + stride - 1) / stride;       // frames after feats[::stride]
   const int nctx = 2 * cfg.num_context + 1;
-  auto get = [&](int ts, int col) -> float {
+  auto get = [&](int ts, int col) -> double {
     const int cslot = col / ffull, c = col % ffull;
     const int src = ts + cslot - cfg.num_context;
-    if (src < 0 || src >= Ts) return 0.f;
+    if (src < 0 || src >= Ts) return 0.0;
     return x[(size_t)(src * stride) * ffull + c];
   };
   (void)nctx;
@@ -220,14 +224,14 @@ fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
   constexpr int CX = 64, TY = kFinalizeThreads / 64;
   __shared__ double s_sum[TY][CX];
   __shared__ double s_sq[TY][CX];
-  __shared__ float s_mean[CX];
-  __shared__ float s_inv[CX];
+  __shared__ double s_mean[CX];
+  __shared__ double s_inv[CX];
   const int cx = tid & 63, ty = tid >> 6;
   for (int c0 = 0; c0 < f_out; c0 += CX) {
     const int col = c0 + cx;
     double sum = 0.0;
     if (col < f_out)
-      for (int ts = ty; ts < Ts; ts += TY) sum += (double)get(ts, col);
+      for (int ts = ty; ts < Ts; ts += TY) sum += get(ts, col);
     s_sum[ty][cx] = sum;
     __syncthreads();
     double mean = 0.0;
@@ -240,7 +244,7 @@ fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
     double sq = 0.0;
     if (col < f_out)
       for (int ts = ty; ts < Ts; ts += TY) {
-        const double dlt = (double)get(ts, col) - mean;
+        const double dlt = get(ts, col) - mean;
         sq += dlt * dlt;
       }
     s_sq[ty][cx] = sq;
@@ -250,19 +254,19 @@ fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
 #pragma unroll
       for (int i = 0; i < TY; ++i) tot += s_sq[i][cx];
       const double var = tot / Ts;
-      s_mean[cx] = cfg.mean_norm ? (float)mean : 0.f;
+      s_mean[cx] = cfg.mean_norm ? mean : 0.0;
       double sd = sqrt(var);
       if (!cfg.mean_norm) {
         // std is still computed about the true mean (np.std), only the shift is skipped
       }
-      s_inv[cx] = cfg.var_norm ? (float)(1.0 / (sd + (double)cfg.eps)) : 1.f;
+      s_inv[cx] = cfg.var_norm ? sd + cfg.eps : 1.0;     // the divisor (audio.py:70-75)
     }
     __syncthreads();
     if (col < f_out) {
-      const float mu = s_mean[cx], inv = s_inv[cx];
+      const double mu = s_mean[cx], den = s_inv[cx];
       for (int ts = ty; ts < t_out; ts += TY) {
         float v = 0.f;
-        if (ts < Ts) v = (get(ts, col) - mu) * inv;
+        if (ts < Ts) v = (float)((get(ts, col) - mu) / den);
         out[((size_t)ts * n_pad + utt) * f_out + col] = v;
       }
     }
@@ -304,14 +308,14 @@ extern "C" int asr_frontend_num_feats(const asr_frontend_cfg* cfg) {
 extern "C" size_t asr_frontend_workspace_bytes(const asr_frontend_cfg* cfg, int n_utt,
                                                int max_frames) {
   return asr_align_up((size_t)n_utt * max_frames * asr_frontend_num_feats(cfg) *
-                          sizeof(float), 256);
+                          sizeof(double), 256);
 }
 
 extern "C" int asr_frontend_features(const asr_frontend_cfg* cfg, const float* audio,
                                      const int* offsets, const int* lengths,
                                      const int* host_lengths, int n_utt, int n_pad,
-                                     const float* window, const float* mel,
-                                     const int* mel_range, const float* dct,
+                                     const double* window, const double* mel,
+                                     const int* mel_range, const double* dct,
                                      float* out, int t_out, int* out_frames,
                                      void* workspace, size_t ws_bytes,
                                      asr_stream_t stream_) {
@@ -339,7 +343,7 @@ extern "C" int asr_frontend_features(const asr_frontend_cfg* cfg, const float* a
     asr_set_error("frontend: workspace %zu < %zu bytes", ws_bytes, need);
     return ASR_ERR_WORKSPACE;
   }
-  float* full = reinterpret_cast<float*>(workspace);
+  double* full = reinterpret_cast<double*>(workspace);
   dim3 grid((max_frames + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK, n_utt);
   hipLaunchKernelGGL(fe_frames_kernel, grid, dim3(256), 0, stream, *cfg, audio, offsets,
                      lengths, window, mel, mel_range, dct, full, max_frames, ffull);

@@ -9,8 +9,8 @@
 extern "C" int asr_frontend_mfcc_batch(const asr_frontend_cfg* cfg, const float* audio,
                                        const int* offsets, const int* lengths,
                                        const int* host_lengths, int n_utt, int n_pad,
-                                       const float* window, const float* mel,
-                                       const int* mel_range, const float* dct, float* out,
+                                       const double* window, const double* mel,
+                                       const int* mel_range, const double* dct, float* out,
                                        int t_out, int* out_frames, void* workspace,
                                        size_t ws_bytes, asr_stream_t stream) {
   ASR_CHECK_ARG(cfg && cfg->kind == 0, "asr_frontend_mfcc_batch: cfg->kind must be 0 (MFCC)");
@@ -22,7 +22,7 @@ extern "C" int asr_frontend_mfcc_batch(const asr_frontend_cfg* cfg, const float*
 extern "C" int asr_frontend_logfbank_batch(const asr_frontend_cfg* cfg, const float* audio,
                                            const int* offsets, const int* lengths,
                                            const int* host_lengths, int n_utt, int n_pad,
-                                           const float* window, const float* mel,
+                                           const double* window, const double* mel,
                                            const int* mel_range, float* out, int t_out,
                                            int* out_frames, void* workspace, size_t ws_bytes,
                                            asr_stream_t stream) {

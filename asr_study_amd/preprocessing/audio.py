@@ -179,8 +179,8 @@ class FBank(Feature):
             if len(nz):
                 rng[j] = (nz[0], nz[-1] + 1)
         tables = {
-            'window': torch.from_numpy(window.astype(np.float32)).to(dev),
-            'mel': torch.from_numpy(np.ascontiguousarray(fb, dtype=np.float32)).to(dev),
+            'window': torch.from_numpy(np.ascontiguousarray(window, dtype=np.float64)).to(dev),
+            'mel': torch.from_numpy(np.ascontiguousarray(fb, dtype=np.float64)).to(dev),
             'mel_range': torch.from_numpy(rng).to(dev),
         }
         if self.KIND == 0:
@@ -190,7 +190,7 @@ class FBank(Feature):
             if self.cep_lifter > 0:
                 n = np.arange(self.num_cep)
                 D = D * (1 + (self.cep_lifter / 2) * np.sin(np.pi * n / self.cep_lifter))
-            tables['dct'] = torch.from_numpy(np.ascontiguousarray(D, dtype=np.float32)).to(dev)
+            tables['dct'] = torch.from_numpy(np.ascontiguousarray(D, dtype=np.float64)).to(dev)
         self._tables = (cfg, tables)
 
     def batch(self, signals, t_out=None, n_pad=None):

@@ -70,8 +70,9 @@ typedef struct asr_frontend_cfg {
   int stride;        /* keep every stride-th frame                           */
   int num_context;   /* +-context frame stacking (zero rows off the edges)   */
   int mean_norm, var_norm;
-  float pre_emph;    /* 0.97                                                 */
-  float eps;         /* 1e-8                                                 */
+  int reserved;      /* (keeps the doubles 8-byte aligned)                   */
+  double pre_emph;   /* 0.97 -- float64: the per-frame chain runs in float64 */
+  double eps;        /* 1e-8                                                 */
 } asr_frontend_cfg;
 
 /* Number of frames for a signal of `samples` samples (audio_utils.py:29-32). */
@@ -85,7 +86,8 @@ size_t asr_frontend_workspace_bytes(const asr_frontend_cfg* cfg, int n_utt,
  * row-major, from audio.py:255-277 computed on the host in float64), mel_range
  * (num_filt x {first, last+1} non-zero bin of each filter, device int32), dct
  * (num_filt x num_cep: scipy DCT-II 'ortho' with the lifter folded in; MFCC
- * only) are float32 device tables.  out is the (T_out, n_pad, F_out) time-major
+ * only) are FLOAT64 device tables (the reference computes in float64; see
+ * csrc/frontend.hip).  out is the float32 (T_out, n_pad, F_out) time-major
  * slab (row stride n_pad*F_out), zero-filled past each utterance's frames
  * (pad_sequences(padding='post'), datasets/dataset_generator.py:227);
  * out_frames[i] (device int32) receives the frame count after striding.
@@ -93,8 +95,8 @@ size_t asr_frontend_workspace_bytes(const asr_frontend_cfg* cfg, int n_utt,
 int asr_frontend_features(const asr_frontend_cfg* cfg, const float* audio,
                           const int* offsets, const int* lengths,
                           const int* host_lengths, int n_utt, int n_pad,
-                          const float* window, const float* mel,
-                          const int* mel_range, const float* dct, float* out,
+                          const double* window, const double* mel,
+                          const int* mel_range, const double* dct, float* out,
                           int t_out,
                           int* out_frames, void* workspace, size_t ws_bytes,
                           asr_stream_t stream);
@@ -400,14 +402,14 @@ int asr_axpby(int64_t n, float a, const float* x, float b, const float* y, float
 int asr_frontend_mfcc_batch(const asr_frontend_cfg* cfg, const float* audio,
                             const int* offsets, const int* lengths,
                             const int* host_lengths, int n_utt, int n_pad,
-                            const float* window, const float* mel,
-                            const int* mel_range, const float* dct, float* out,
+                            const double* window, const double* mel,
+                            const int* mel_range, const double* dct, float* out,
                             int t_out, int* out_frames, void* workspace,
                             size_t ws_bytes, asr_stream_t stream);
 int asr_frontend_logfbank_batch(const asr_frontend_cfg* cfg, const float* audio,
                                 const int* offsets, const int* lengths,
                                 const int* host_lengths, int n_utt, int n_pad,
-                                const float* window, const float* mel,
+                                const double* window, const double* mel,
                                 const int* mel_range, float* out, int t_out,
                                 int* out_frames, void* workspace, size_t ws_bytes,
                                 asr_stream_t stream);

@@ -1,8 +1,9 @@
 """-m gpu: MFCC / log-mel front-end through the product classes vs the golden
 vectors generated from the reference's own code (tests/golden) and the oracle.
-Tolerance on the standardised (unit-variance) features: 2e-4 + 1e-4*|x| -- the
-float32 FFT resolves a log-mel outlier at -6 sigma (a nearly empty narrow filter)
-to ~6e-5 relative."""
+Tolerance on the standardised (unit-variance) features: 1e-4 absolute (the north-star
+bar): the per-frame chain runs in float64 like the reference (csrc/frontend.hip), so what
+remains is the float32 cast of the input samples (<= 6e-6, measured with the oracle) and of
+the output."""
 import os
 
 import numpy as np
@@ -12,7 +13,7 @@ import torch
 from oracle import frontend as OF
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-4
+TOL = 1e-4
 
 CONFIGS = {
     'mfcc39': ('MFCC', {}),
@@ -40,7 +41,7 @@ def test_against_reference_golden(name, golden_dir):
         y = feat(x)
         assert y.shape == g[key].shape, (key, y.shape, g[key].shape)
         report('%s %s' % (name, key), y, g[key])
-        worst = max(worst, float(np.max(np.abs(y - g[key]) - 1e-4 * np.abs(g[key]))) if y.size else 0.0)
+        worst = max(worst, float(np.max(np.abs(y - g[key]))) if y.size else 0.0)
     assert worst < TOL
 
 
@@ -74,4 +75,4 @@ def test_no_norm_and_properties():
     assert np.abs(y[:, live].std(0) - 1).max() < 1e-3
     y2 = audio.MFCC(mean_norm=False, var_norm=False)(x)
     want = OF.extract('mfcc', x, mean_norm=False, var_norm=False)
-    assert np.abs(y2 - want).max() < 5e-4 * max(1.0, np.abs(want).max())
+    assert np.abs(y2 - want).max() < 1e-5 * max(1.0, np.abs(want).max())

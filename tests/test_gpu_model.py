@@ -312,3 +312,61 @@ def test_brsmv1_layer_normalisation(with_mi):
     for (name, g), gg in zip(flat, got):
         scale = max(1e-3, np.abs(g).max())
         assert report('LN grad ' + name, gg, g) < 2e-4 * scale + 1e-6, name
+
+
+@pytest.mark.parametrize('use_masks', [False, True])
+def test_brsmv1_packed_operand_gemm_path(use_masks, monkeypatch):
+    """ASR_GEMM_PACKED=1 (the default from 512 hidden units on): every BiLSTM GEMM runs on
+    operands packed once into split-fp16 planes (asr_pack_hl / asr_gemm_hl), dropout masks
+    folded into the pack -- logits, loss and all gradients vs the oracle, and the same weights
+    after two optimiser steps as the per-tile path."""
+    from asr_study_amd.core import models, optimizers
+    rs = np.random.RandomState(21)
+    N, T, F, C, L, H = 20, 37, 16, 7, 3, 24
+    x, labels, lens = _batch(rs, N, T, F, C)
+    n_pad = 32
+    results = {}
+    for packed in ('1', '0'):
+        monkeypatch.setenv('ASR_GEMM_PACKED', packed)
+        model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
+                              dropout=0.0, weight_decay=1e-3, seed=3)
+        assert model.packed == (packed == '1')
+        rw = np.random.RandomState(5)
+        w = [a + rw.randn(*a.shape).astype(np.float32) * 0.2 for a in model.get_weights()]
+        model.set_weights(w)
+        model.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=0.5))
+        masks_o = masks_g = None
+        if use_masks:
+            rm = np.random.RandomState(9)
+            masks_o, masks_g = [], {}
+            n_in = F
+            for li in range(L):
+                mo = {}
+                BW = np.ones((2, n_pad, n_in), np.float32)
+                BU = np.ones((2, n_pad, H), np.float32)
+                for di, d in enumerate(('fwd', 'bwd')):
+                    bw = ((rm.rand(N, n_in) > 0.2) / 0.8)
+                    bu = ((rm.rand(N, H) > 0.2) / 0.8)
+                    mo[d] = (bw, bu)
+                    BW[di, :N] = bw
+                    BU[di, :N] = bu
+                masks_o.append(mo)
+                masks_g[li + 1] = (torch.from_numpy(BW).cuda(), torch.from_numpy(BU).cuda())
+                n_in = 2 * H
+        slab = model.to_slab(x)
+        ctc, logits, _ = model.loss_and_grads(slab, labels, lens, training=True, masks=masks_g)
+        torch.cuda.synchronize()
+        if packed == '1':
+            params = _oracle_params(w, L)
+            xt = np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float64)
+            want = OL.loss_and_grads(params, xt, labels, lens, weight_decay=0.0, masks=masks_o)
+            assert report('packed logits', logits.cpu().numpy()[:, :N], want['logits']) < 1e-4
+            np.testing.assert_allclose(ctc.cpu().numpy(), want['ctc'], rtol=1e-4)
+            for (name, g), gg in zip(OL.flatten(want['grads']), model.get_gradients()):
+                scale = max(1e-3, np.abs(g).max())
+                assert report('packed grad ' + name, gg, g) < 1e-4 * scale + 1e-6, name
+        for _ in range(2):
+            model.train_on_batch([('slab', slab), labels, lens], masks=masks_g)
+        results[packed] = model.get_weights()
+    for a, b in zip(results['1'], results['0']):
+        assert np.abs(a - b).max() < 2e-5
