@@ -144,8 +144,15 @@ def train_main(argv=None):
         model = _new_model(args)
     if world > 1:
         parallel.broadcast_parameters(model)
+    lr_callbacks = []
     if args.lr_schedule:
-        raise ValueError('Learning rate schedule unrecognized')
+        # train.py:165-172: the class is looked up by name among the Keras callbacks
+        from .core import callbacks as _cb
+        fn = {k.lower(): getattr(_cb, k) for k in ('ReduceLROnPlateau', 'EarlyStopping')} \
+            .get(str(args.lr_schedule).lower())
+        if fn is None:
+            raise ValueError('Learning rate schedule unrecognized')
+        lr_callbacks.append(fn(**HParams().parse(args.lr_params).values()))
 
     out_dir = args.save or os.path.join('results', '%s_%s' % (args.model, datetime.datetime.now()))
     callbacks = []
@@ -153,6 +160,7 @@ def train_main(argv=None):
         os.makedirs(out_dir, exist_ok=True)
         callbacks = [MetaCheckpoint(os.path.join(out_dir, name), training_args=args, meta=meta)
                      for name in ('model.h5', 'best.h5')]
+    callbacks = callbacks + lr_callbacks          # (every rank adjusts its own optimizer.lr)
 
     feature, labels = resolve_plugins(args)
     gen = DatasetGenerator(feature, labels, batch_size=args.batch_size, seed=args.seed)

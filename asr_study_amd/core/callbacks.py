@@ -13,8 +13,10 @@ then backward W, U, b; ``timedistributed_k`` = W, b), so ``model.load_weights(fi
 the reference's Keras model reads it and utils/core_utils.load_model reads files the
 reference wrote.  Extra attributes ``model_config`` (yaml: factory name + kwargs) let
 this package rebuild the topology without Keras' JSON graph; /optimizer/...; /meta/...
-as core/callbacks.py:47-56.  (Keras' own ``model_config`` JSON and ``optimizer_weights``
-are not emitted: ``keras.models.load_model`` of such a file is not supported.)"""
+as core/callbacks.py:47-56.  The root attributes ``model_config`` / ``training_config`` and
+the ``optimizer_weights`` group of ``keras.models.save_model`` are emitted too
+(utils/keras_config.py: schema restated from memory of keras 1.2.2, with the documented
+residue that a Lambda's function is named, not marshalled)."""
 import numpy as np
 import yaml
 
@@ -108,6 +110,20 @@ def save_model(model, filepath, meta=None, model_config=None):
             for wname, val in ws:
                 lg.write_array(wname, val)
         g.attrs['model_config'] = yaml.safe_dump(model_config or getattr(model, 'config', {}))
+        # what keras.models.save_model writes besides the weights (utils/keras_config.py):
+        # the functional graph, the training configuration and the optimizer slots
+        if hasattr(model, 'stages') and hasattr(model, 'num_features'):
+            from ..utils import keras_config
+            f.attrs['model_config'] = keras_config.model_config(model)
+            tc = keras_config.training_config(model)
+            if tc is not None:
+                f.attrs['training_config'] = tc
+                ow = keras_config.optimizer_weights(model)
+                if ow:
+                    og = f.create_group('optimizer_weights')
+                    og.attrs.set_strings('weight_names', [n for n, _ in ow])
+                    for n, a in ow:
+                        og.write_array(n, a)
         if model.optimizer is not None:
             o = f.create_group('optimizer')
             state, it = model.optimizer.get_state()
@@ -142,4 +158,95 @@ class MetaCheckpoint(Callback):
         self.meta.setdefault('epochs', []).append(epoch)
         for k, v in (logs or {}).items():
             self.meta.setdefault(k, []).append(v)
-        save_model(self.model, self.filepath, self.meta)
+        # core/callbacks.py:45: filepath.format(epoch=epoch, **logs)
+        save_model(self.model, self.filepath.format(epoch=epoch, **(logs or {})), self.meta)
+
+
+class ReduceLROnPlateau(Callback):
+    """keras.callbacks.ReduceLROnPlateau (Keras 1.2.2 semantics, restated): when ``monitor``
+    has not improved by more than ``epsilon`` for ``patience`` epochs, multiply
+    ``model.optimizer.lr`` by ``factor`` (not below ``min_lr``), then wait ``cooldown`` epochs.
+    Reached through ``--lr_schedule ReduceLROnPlateau --lr_params ...`` (train.py:165-172,
+    which resolves the class by name in keras.callbacks)."""
+
+    def __init__(self, monitor='val_loss', factor=0.1, patience=10, verbose=0, mode='auto',
+                 epsilon=1e-4, cooldown=0, min_lr=0, **kwargs):
+        if factor >= 1.0:
+            raise ValueError('ReduceLROnPlateau does not support a factor >= 1.0.')
+        self.monitor, self.factor, self.patience = monitor, float(factor), int(patience)
+        self.verbose, self.epsilon, self.cooldown = verbose, float(epsilon), int(cooldown)
+        self.min_lr = float(min_lr)
+        if mode not in ('auto', 'min', 'max'):
+            mode = 'auto'
+        self.maximise = mode == 'max' or (mode == 'auto' and 'acc' in monitor)
+        self.on_train_begin()
+
+    def on_train_begin(self):
+        self.best = -np.inf if self.maximise else np.inf
+        self.wait, self.cooldown_counter = 0, 0
+
+    def _better(self, cur):
+        return cur > self.best + self.epsilon if self.maximise else cur < self.best - self.epsilon
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs if logs is not None else {}
+        logs['lr'] = float(self.model.optimizer.lr)
+        cur = logs.get(self.monitor)
+        if cur is None:
+            return
+        if self.cooldown_counter > 0:
+            self.cooldown_counter -= 1
+            self.wait = 0
+        if self._better(cur):
+            self.best, self.wait = cur, 0
+        elif self.cooldown_counter <= 0:
+            if self.wait >= self.patience:
+                old = float(self.model.optimizer.lr)
+                if old > self.min_lr + 1e-4 * self.min_lr:
+                    self.model.optimizer.lr = max(old * self.factor, self.min_lr)
+                    if self.verbose:
+                        print('Epoch %05d: reducing learning rate to %s.'
+                              % (epoch, self.model.optimizer.lr))
+                    self.cooldown_counter = self.cooldown
+                    self.wait = 0
+            self.wait += 1
+
+
+class LearningRateScheduler(Callback):
+    """keras.callbacks.LearningRateScheduler: ``schedule(epoch) -> lr`` at every epoch begin
+    (applied at the end of the previous epoch here: the engine calls callbacks at epoch end)."""
+
+    def __init__(self, schedule):
+        self.schedule = schedule
+
+    def on_train_begin(self):
+        if getattr(self, 'model', None) is not None and self.model.optimizer is not None:
+            self.model.optimizer.lr = float(self.schedule(0))
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.model.optimizer.lr = float(self.schedule(epoch + 1))
+
+
+class EarlyStopping(Callback):
+    """keras.callbacks.EarlyStopping (monitor / min_delta / patience / mode)."""
+
+    def __init__(self, monitor='val_loss', min_delta=0, patience=0, verbose=0, mode='auto'):
+        self.monitor, self.min_delta, self.patience = monitor, float(min_delta), int(patience)
+        self.maximise = mode == 'max' or (mode == 'auto' and 'acc' in monitor)
+        self.on_train_begin()
+
+    def on_train_begin(self):
+        self.best = -np.inf if self.maximise else np.inf
+        self.wait = 0
+
+    def on_epoch_end(self, epoch, logs=None):
+        cur = (logs or {}).get(self.monitor)
+        if cur is None:
+            return
+        better = cur - self.min_delta > self.best if self.maximise else cur + self.min_delta < self.best
+        if better:
+            self.best, self.wait = cur, 0
+        else:
+            if self.wait >= self.patience:
+                self.model.stop_training = True
+            self.wait += 1

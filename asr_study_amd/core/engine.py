@@ -722,6 +722,8 @@ class Model(object):
             if s.kind == 'noise':
                 continue
             if s.kind == 'dropout':
+                if first:               # nothing trainable upstream: no gradient needed there
+                    continue
                 if 'mask' in rec:
                     da = ops.mul(da, rec['mask'], self._buf('ddrop%d' % si, da.shape))
                 continue

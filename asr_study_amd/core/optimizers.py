@@ -34,13 +34,14 @@ class Adam(Optimizer):
                  clipnorm=0.0, **kwargs):
         super(Adam, self).__init__(lr, clipnorm)
         self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
-        if decay:
-            raise NotImplementedError('Adam(decay>0)')
+        self.decay = float(decay or 0.0)
 
     def step(self, model):
+        # Keras 1.2.2: lr *= 1 / (1 + decay * iterations), iterations counted BEFORE this update
+        lr = self.lr / (1.0 + self.decay * self.iterations) if self.decay else self.lr
         self.iterations += 1
         ops.clip_adam_step(model.params, model.grads, self.state[0], self.state[1],
-                           model._segs_dev, model._nseg, model._norm, self.clipnorm, self.lr,
+                           model._segs_dev, model._nseg, model._norm, self.clipnorm, lr,
                            self.iterations, self.beta_1, self.beta_2, self.epsilon)
 
 
@@ -51,13 +52,15 @@ class SGD(Optimizer):
                  **kwargs):
         super(SGD, self).__init__(lr, clipnorm)
         self.momentum = float(momentum)
-        if decay or nesterov:
-            raise NotImplementedError('SGD(decay>0 / nesterov)')
+        self.decay = float(decay or 0.0)
+        if nesterov:
+            raise NotImplementedError('SGD(nesterov=True)')
 
     def step(self, model):
+        lr = self.lr / (1.0 + self.decay * self.iterations) if self.decay else self.lr
         self.iterations += 1
         ops.clip_sgd_step(model.params, model.grads, self.state[0], model._segs_dev,
-                          model._nseg, model._norm, self.clipnorm, self.lr, self.momentum)
+                          model._nseg, model._norm, self.clipnorm, lr, self.momentum)
 
 
 def get(name):

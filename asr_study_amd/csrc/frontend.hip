@@ -224,23 +224,39 @@ fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
   constexpr int CX = 64, TY = kFinalizeThreads / 64;
   __shared__ double s_sum[TY][CX];
   __shared__ double s_sq[TY][CX];
+  __shared__ double s_mx[TY][CX];
   __shared__ double s_mean[CX];
   __shared__ double s_inv[CX];
   const int cx = tid & 63, ty = tid >> 6;
   for (int c0 = 0; c0 < f_out; c0 += CX) {
     const int col = c0 + cx;
-    double sum = 0.0;
+    double sum = 0.0, mn = 1e300, mx = -1e300;
     if (col < f_out)
-      for (int ts = ty; ts < Ts; ts += TY) sum += get(ts, col);
+      for (int ts = ty; ts < Ts; ts += TY) {
+        const double v = get(ts, col);
+        sum += v;
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+      }
     s_sum[ty][cx] = sum;
+    s_sq[ty][cx] = mn;            // (s_sq doubles as scratch for the column minimum ...)
+    s_mx[ty][cx] = mx;
     __syncthreads();
     double mean = 0.0;
     if (col < f_out) {
-      double tot = 0.0;
+      double tot = 0.0, lo = 1e300, hi = -1e300;
 #pragma unroll
-      for (int i = 0; i < TY; ++i) tot += s_sum[i][cx];
-      mean = tot / Ts;
+      for (int i = 0; i < TY; ++i) {
+        tot += s_sum[i][cx];
+        lo = s_sq[i][cx] < lo ? s_sq[i][cx] : lo;
+        hi = s_mx[i][cx] > hi ? s_mx[i][cx] : hi;
+      }
+      // a constant column (an empty mel filter: log(eps) in every frame) has exactly its
+      // value as mean -- NumPy's pairwise sum of equal terms is exact there -- so that it
+      // standardises to exactly 0
+      mean = lo == hi ? lo : tot / Ts;
     }
+    __syncthreads();              // (... before s_sq is reused for the squares)
     double sq = 0.0;
     if (col < f_out)
       for (int ts = ty; ts < Ts; ts += TY) {

@@ -106,11 +106,24 @@ class DatasetGenerator(object):
         elif os.path.splitext(fname)[1] == '.npz':
             z = np.load(fname, allow_pickle=True)
             out = [self.flow_from_h5_group(NpzGroup(z, dataset)) for dataset in datasets]
+        elif os.path.splitext(fname)[1] == '.json':
+            out = [self.flow_from_json(fname, None if dataset == '/' else dataset)
+                   for dataset in datasets]
         if out is None:
             raise ValueError("Extension not recognized")
         if len(out) == 1:
             return out[0]
         return out
+
+    def flow_from_json(self, fname, dataset=None):
+        """JSON manifest [{'input': path | samples, 'label': str, 'duration': s,
+        ['dataset': split]}, ...] (datasets/dataset_generator.py:84-92)."""
+        return JSONIterator(fname, dataset, **self._kw())
+
+    def flow_from_dl(self, dl, dataset=None):
+        """Dictionary of lists with the keys 'audio', 'label', 'duration' [, 'dataset']
+        (datasets/dataset_generator.py:94-103)."""
+        return DictListIterator(dl, dataset, **self._kw())
 
     def flow_from_h5_group(self, h5_group=None):
         return H5Iterator(h5_group, **self._kw())
@@ -251,3 +264,48 @@ class NpzGroup(object):
         if name == 'inputs' and self._key('num_feats') in self.z.files:
             attrs['num_feats'] = int(self.z[self._key('num_feats')])
         return _NpzData(list(items), attrs)
+
+
+def _default_raw(kwargs):
+    """input_parser defaults to the pass-through ``audio.raw`` (:283, :318); an explicit None
+    is an error, as in the reference."""
+    from ..preprocessing import audio
+    kwargs.setdefault('input_parser', audio.raw)
+    if kwargs.get('input_parser') is None:
+        raise ValueError("input_parser must be set")
+    if kwargs.get('label_parser') is None:
+        raise ValueError("label_parser must be set")
+
+
+class JSONIterator(DatasetIterator):
+    """datasets/dataset_generator.py:278-313: a JSON list of records."""
+
+    def __init__(self, fname, dataset=None, **kwargs):
+        import codecs
+        import json
+        _default_raw(kwargs)
+        with codecs.open(fname, 'r', encoding='utf8') as f:
+            ld = json.load(f)
+        data = {k: [d[k] for d in ld] for k in ld[0]}          # utils.ld2dl
+        if dataset and 'dataset' not in data:
+            dataset = None                                    # (:297-299: falls back to None)
+        if dataset:
+            keep = [i for i, d in enumerate(data['dataset']) if d == dataset]
+        else:
+            keep = list(range(len(data['input'])))
+        super(JSONIterator, self).__init__([data['input'][i] for i in keep],
+                                           [data['label'][i] for i in keep], **kwargs)
+        self.durations = np.array([data['duration'][i] for i in keep])
+
+
+class DictListIterator(DatasetIterator):
+    """datasets/dataset_generator.py:316-345: a dictionary of lists."""
+
+    def __init__(self, dict_list, dataset=None, **kwargs):
+        _default_raw(kwargs)
+        if dataset:
+            keep = [i for i, d in enumerate(dict_list['dataset']) if d == dataset]
+            dict_list = {k: [v[i] for i in keep] for k, v in dict_list.items()}
+        super(DictListIterator, self).__init__(list(dict_list['audio']), list(dict_list['label']),
+                                               **kwargs)
+        self.durations = np.array(dict_list['duration'])

@@ -56,6 +56,10 @@ def load_model(model_fname, return_meta=False, mode='train', **kwargs):
             o = f['optimizer']
             opt_state = (yaml.safe_load(o.attrs['config']), o['state'][:],
                          int(o.attrs['iterations']))
+        keras_json = f.attrs['model_config'] if 'model_config' in f.attrs else None
+        if cfg is None and 'meta' not in f and keras_json is not None:
+            # a bare keras model.save() file: rebuild the topology from its functional graph
+            cfg = {'keras_json': keras_json}
         if cfg is None:
             # a file written by the reference: the topology is named in meta/training_args
             # (train.py:127-129), input / output widths are read off the weights
@@ -65,9 +69,14 @@ def load_model(model_fname, return_meta=False, mode='train', **kwargs):
             mkw.setdefault('num_features', int(weights[0].shape[0]))
             mkw.setdefault('num_classes', int(weights[-1].shape[0]))
             cfg = {'name': targs['model'], 'kwargs': mkw}
-    factory = utils.get_from_module('core.models', cfg['name'])
-    model = factory(**cfg.get('kwargs', {}))
-    model.config = cfg
+    if 'keras_json' in cfg:
+        from .keras_config import topology_from_config
+        model = topology_from_config(cfg['keras_json'])
+        model.config = {}
+    else:
+        factory = utils.get_from_module('core.models', cfg['name'])
+        model = factory(**cfg.get('kwargs', {}))
+        model.config = cfg
     model.set_weights(weights)
     if mode == 'train' and opt_state is not None:
         oc, state, it = opt_state

@@ -263,3 +263,139 @@ def test_checkpoint_roundtrip_of_cell_variants(tmp_path, monkeypatch, variant):
     assert all(np.array_equal(a, b) for a, b in zip(back2.get_weights(), w))
     with pytest.raises(ValueError):
         callbacks.keras_layers(model, model.get_weights() + [np.zeros(3, np.float32)])
+
+
+def test_keras_model_config_written_and_rebuilds_the_topology(tmp_path, monkeypatch):
+    """save_model also writes what keras.models.save_model does besides the weights -- root
+    attributes model_config / training_config (JSON) and the optimizer_weights group
+    (utils/keras_config.py) -- and a file carrying ONLY the Keras metadata (no factory record,
+    no meta group) is rebuilt from the functional graph."""
+    import json
+    from asr_study_amd.core import callbacks, engine, models, optimizers
+    from asr_study_amd.datasets import h5lite
+    from asr_study_amd.utils import core_utils, keras_config
+    if not h5lite.available():
+        pytest.skip('libhdf5 not present')
+    monkeypatch.setattr(engine, 'DEFAULT_DEVICE', 'cpu')
+    model = models.brsmv1(num_features=9, num_classes=7, num_hiddens=8, num_layers=2,
+                          dropout=0.2, weight_decay=1e-4, residual='sum', mi=[1.0, 0.5, 0.5])
+    model.compile(optimizer=optimizers.Adam(lr=2e-3, clipnorm=400))
+    model.optimizer.iterations = 17
+    cfg = json.loads(keras_config.model_config(model))
+    layers = cfg['config']['layers']
+    names = [l['name'] for l in layers]
+    assert names[0] == 'inputs' and names[-4:] == ['labels', 'inputs_length', 'decoder', 'ctc']
+    assert cfg['config']['output_layers'] == [['ctc', 0, 0], ['decoder', 0, 0]]
+    bi = [l for l in layers if l['class_name'] == 'Bidirectional']
+    assert len(bi) == 2 and bi[0]['config']['layer']['class_name'] == 'LSTM'
+    lc = bi[1]['config']['layer']['config']
+    assert lc['output_dim'] == 8 and lc['consume_less'] == 'gpu' and lc['mi'] == [1.0, 0.5, 0.5]
+    assert lc['dropout_W'] == 0.2 and lc['W_regularizer']['l2'] == 1e-4 and lc['input_dim'] == 16
+    ctc = layers[-1]
+    assert ctc['config']['function'] == 'ctc_lambda_func' and \
+        [n[0] for n in ctc['inbound_nodes'][0]] == [names[-5], 'labels', 'inputs_length']
+    assert any(l['class_name'] == 'Merge' and l['config']['mode'] == 'sum' for l in layers)
+    fname = str(tmp_path / 'k.h5')
+    callbacks.save_model(model, fname, meta={'training_args': {'model': 'brsmv1'}, 'epochs': [0]})
+    with h5lite.File(fname, 'r') as f:
+        tc = json.loads(f.attrs['training_config'])
+        assert tc['optimizer_config'] == {'class_name': 'Adam', 'config': {
+            'lr': 2e-3, 'beta_1': 0.9, 'beta_2': 0.999, 'epsilon': 1e-8, 'decay': 0.0,
+            'clipnorm': 400.0}}
+        assert tc['loss_weights'] == [1, 0]
+        og = f['optimizer_weights']
+        wn = og.attrs.get_strings('weight_names')
+        nw = len(model.get_weights())
+        assert wn[0] == 'iterations:0' and len(wn) == 1 + 2 * nw
+        assert float(np.asarray(og['iterations:0'].read_array()).reshape(-1)[0]) == 17.0
+        assert og['param_0'].read_array().shape == model.get_weights()[0].shape
+    # a file with only Keras' own records
+    bare = str(tmp_path / 'bare.h5')
+    with h5lite.File(bare, 'w') as f:
+        f.attrs['keras_version'] = '1.2.2'
+        f.attrs['model_config'] = keras_config.model_config(model)
+        g = f.create_group('model_weights')
+        ly = callbacks.keras_layers(model, model.get_weights())
+        g.attrs.set_strings('layer_names', [n for n, _ in ly])
+        for name, ws in ly:
+            lg = g.create_group(name)
+            lg.attrs.set_strings('weight_names', [w for w, _ in ws])
+            for wname, val in ws:
+                lg.write_array(wname, val)
+    back = core_utils.load_model(bare, mode='train')
+    assert [s.kind for s in back.stages] == [s.kind for s in model.stages]
+    assert all(np.array_equal(a, b) for a, b in zip(back.get_weights(), model.get_weights()))
+    bl = [s for s in back.stages if s.kind == 'bilstm'][-1]
+    assert bl.mi == [1.0, 0.5, 0.5] and bl.dropout_W == 0.2 and bl.l2_U == 1e-4
+
+
+def test_json_and_dict_list_iterators(tmp_path):
+    """flow_from_fname('.json') / flow_from_dl (datasets/dataset_generator.py:84-103,278-345):
+    records filtered by split, raw pass-through as default input parser, padded batches."""
+    import json
+    from asr_study_amd.datasets.dataset_generator import DatasetGenerator
+    from asr_study_amd.preprocessing import text
+    rs = np.random.RandomState(0)
+    recs = [{'input': rs.randn(5 + i, 3).tolist(), 'label': 'ab' * (1 + i % 2), 'duration': 0.1 * i,
+             'dataset': 'train' if i % 3 else 'valid'} for i in range(7)]
+    fname = str(tmp_path / 'm.json')
+    with open(fname, 'w') as f:
+        json.dump(recs, f)
+    gen = DatasetGenerator(None, text.simple_char_parser, batch_size=3, shuffle=False, seed=0)
+    del gen.input_parser            # constructor stored None: the iterators' default applies
+    gen.input_parser = __import__('asr_study_amd.preprocessing.audio', fromlist=['raw']).raw
+    train, valid = gen.flow_from_fname(fname, datasets=['train', 'valid'])
+    assert train.len == 4 and valid.len == 3 and list(valid.durations) == [0.0, 0.30000000000000004, 0.6000000000000001]
+    (x, labels, lens), _ = next(valid)
+    assert x.shape == (3, 11, 3) and lens.tolist() == [5, 8, 11] and labels.shape == (3, 4)
+    assert np.allclose(x[0, :5], np.asarray(recs[0]['input'], np.float32)) and not x[0, 5:].any()
+    dl = {'audio': [r['input'] for r in recs], 'label': [r['label'] for r in recs],
+          'duration': [r['duration'] for r in recs], 'dataset': [r['dataset'] for r in recs]}
+    flow = gen.flow_from_dl(dl, 'train')
+    assert flow.len == 4
+    (x2, _, lens2), _ = next(flow)
+    assert lens2.tolist() == [6, 7, 9]
+
+
+def test_lr_callbacks_and_optimizer_decay():
+    from asr_study_amd.core import callbacks as cb
+    from asr_study_amd.core import optimizers
+
+    class M(object):
+        stop_training = False
+    m = M()
+    m.optimizer = optimizers.Adam(lr=1e-3, decay=0.5)
+    r = cb.ReduceLROnPlateau(monitor='val_loss', factor=0.5, patience=1, min_lr=2e-4)
+    r.set_model(m)
+    lrs = []
+    for epoch, v in enumerate([3.0, 2.0, 2.0, 2.0, 2.0, 2.0, 2.0]):
+        r.on_epoch_end(epoch, {'val_loss': v})
+        lrs.append(m.optimizer.lr)
+    # Keras: wait counts the epochs without improvement; at wait >= patience the rate is
+    # multiplied by factor (not below min_lr) and wait restarts at 1
+    assert np.allclose(lrs, [1e-3, 1e-3, 1e-3, 5e-4, 2.5e-4, 2e-4, 2e-4])
+    e = cb.EarlyStopping(monitor='val_loss', patience=2)
+    e.set_model(m)
+    for epoch, v in enumerate([1.0, 1.1, 1.2, 1.3]):
+        e.on_epoch_end(epoch, {'val_loss': v})
+    assert m.stop_training
+    s = cb.LearningRateScheduler(lambda ep: 0.1 / (1 + ep))
+    s.set_model(m)
+    s.on_epoch_end(3, {})
+    assert m.optimizer.lr == 0.1 / 5
+    # Keras decay: lr / (1 + decay * iterations), iterations before the update
+    seen = []
+    import asr_study_amd.ops as ops_mod
+    orig = ops_mod.clip_adam_step
+    ops_mod.clip_adam_step = lambda *a, **k: seen.append(a[8])
+    try:
+        opt = optimizers.Adam(lr=1.0, decay=0.5)
+
+        class Fake(object):
+            params = grads = _segs_dev = _nseg = _norm = None
+        opt.state = [None, None]
+        for _ in range(3):
+            opt.step(Fake())
+    finally:
+        ops_mod.clip_adam_step = orig
+    assert seen == [1.0, 1.0 / 1.5, 1.0 / 2.0]

