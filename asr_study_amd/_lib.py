@@ -65,7 +65,8 @@ class LstmArgs(C.Structure):
                 ('dy', void_p), ('dz', void_p), ('dz_absmax', void_p),
                 ('step_begin', C.c_int), ('step_count', C.c_int),
                 ('mi', void_p), ('uh', void_p), ('zone_c', void_p), ('zone_h', void_p),
-                ('wx', void_p), ('dwx', void_p), ('dmi', void_p), ('db_part', void_p)]
+                ('wx', void_p), ('dwx', void_p), ('dmi', void_p), ('db_part', void_p),
+                ('n_valid', C.c_int)]
 
 
 class LstmLnArgs(C.Structure):

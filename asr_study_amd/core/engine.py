@@ -375,7 +375,9 @@ class Model(object):
             # drop stale shapes of the same name to bound memory
             for k in [k for k in self._bufs if k[0] == name]:
                 del self._bufs[k]
-            b = torch.empty(key[1], dtype=torch.float32, device=self.device)
+            # (zero-filled once: kernels that write only the real rows of a slab -- the
+            # single-utterance forward kernel -- must not leave junk in the padding rows)
+            b = torch.zeros(key[1], dtype=torch.float32, device=self.device)
             self._bufs[key] = b
         return b
 
@@ -448,9 +450,10 @@ class Model(object):
                         c_off=d * 4 * Hp, ldc=8 * Hp, bias=bias[d * 4 * Hp:(d + 1) * 4 * Hp])
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, training=False, masks=None, need_grad=True):
+    def forward(self, x, training=False, masks=None, need_grad=True, n_valid=0):
         """x: (T, n_pad, F) float32 CUDA slab -> logits (T, n_pad, C).
-        need_grad=False (evaluation / prediction) skips what only BPTT would read.
+        need_grad=False (evaluation / prediction) skips what only BPTT would read; n_valid=1
+        with it (one utterance, predict.py) selects the tile-free recurrent kernel.
 
         masks: optional explicit variational-dropout masks (parity tests):
         {stage_index: (BW (2, n_pad, f_in_pad), BU (2, n_pad, Hp))}.
@@ -477,6 +480,8 @@ class Model(object):
         pipe = (self._pipe_now and self._pipe is not None and self.lstm_mode == 0 and T >= 16
                 and not self.packed)
         self._pipe_now = self._pipe_now and not self.packed
+        if n_valid == 1 and not need_grad:      # one utterance: the tile-free kernel, whole layers
+            pipe = False
         S = (self._pipe_split16 * T) // 16
         pre = {}
         if any(self._stage_packed(st) for st in self.stages):
@@ -573,7 +578,8 @@ class Model(object):
                                                  mode=self.lstm_mode, steps=(S, T - S))
                 else:
                     rec['ws'] = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
-                                                 mode=self.lstm_mode, **var)
+                                                 mode=self.lstm_mode,
+                                                 n_valid=n_valid if not need_grad else 0, **var)
                 rec.update(y=y, cell=cell, gates=gates)
                 a = y
             rec['out'] = a
@@ -1091,7 +1097,7 @@ class Model(object):
         slab, labels, lens = self._unpack_inputs(inputs)
         N = len(labels)
         lab, lab_len, sl = self._prep_labels(labels, lens, slab.shape[0])
-        logits = self.forward(slab, training=False, need_grad=False)
+        logits = self.forward(slab, training=False, need_grad=False, n_valid=N)
         ctc = ops.ctc_loss_grad(logits, lab, lab_len, sl, N, grad=None)
         hyps = None
         dec = dlen = None
@@ -1123,7 +1129,7 @@ class Model(object):
         slab = x if (torch.is_tensor(x) and x.dim() == 3 and x.shape[1] % 16 == 0) else self.to_slab(x)
         N = len(inputs_length) if inputs_length is not None else slab.shape[1]
         lens = np.asarray(inputs_length if inputs_length is not None else [slab.shape[0]] * N).reshape(-1)
-        logits = self.forward(slab, training=False, need_grad=False)
+        logits = self.forward(slab, training=False, need_grad=False, n_valid=N)
         if self.decoder is None:
             return logits[:, :N].permute(1, 0, 2).contiguous().cpu().numpy()
         sl = torch.as_tensor(lens.astype(np.int32)).to(self.device)

@@ -1370,6 +1370,118 @@ lstm_fwd_kernel_x(LstmParams p) {
   else fwd_body_x<NKW, false, NT, PLACE>(p, unit, wg, lds);
 }
 
+// ---------------------------------------------------------------------------
+// forward, ONE utterance (predict.py:73-93: the reference decodes one file per call).  A
+// 16-row MFMA tile would be 15/16 padding and would exchange 16 x H words per step for one
+// useful row, so this kernel has no tile: a chain is one direction, a workgroup owns 16
+// units = 64 gate columns, thread (kq = tid >> 6, c = tid & 63) keeps the H/4 entries
+// U[kq H/4 .., 64 wg + c] in registers and multiplies them with its quarter of h in plain
+// fp32 FMAs (EXACT fp32: no split), the four partial sums of a column meet in LDS, threads
+// 0..15 finish one unit each.  The exchange is H words per step (tag in the LSB as
+// everywhere), gathered by H/4 lanes with one 16-byte load each: the step is the bare
+// hand-off latency plus ~0.25 us of arithmetic.  Only row 0 of the slabs is read / written.
+template <int KQ /* H / 4 */, bool FAST>
+__device__ __forceinline__ void fwd_body_n1(const LstmParams& p, int dir, int wg, float* lds) {
+  const int tid = threadIdx.x;
+  const int kq = tid >> 6, c = tid & 63;
+  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
+  float* hs = lds;                       // [H] h_{t-1}
+  float* part = lds + H;                 // [4][64] partial gate sums
+  float u[KQ];
+#pragma unroll
+  for (int i = 0; i < KQ; ++i)
+    u[i] = p.U[((size_t)(dir * H + kq * KQ + i)) * H4 + 64 * wg + c];
+  const int unit = 16 * wg + (tid & 15);
+  const float mask = p.mask_u ? p.mask_u[((size_t)dir * p.n_pad) * H + unit] : 1.f;
+  float cst = 0.f;
+  const int s_end = p.s_begin + p.s_count;
+  if (p.s_begin > 0 && tid < 16) {
+    const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
+    cst = p.cell[(((size_t)tpp * p.n_pad) * 2 + dir) * H + unit];
+  }
+  unsigned* xch = p.xbuf + (size_t)dir * p.xchain_words;      // [2 slots][H]
+  bool dead = false;
+  for (int s = p.s_begin; s < s_end; ++s) {
+    const int t = dir == 0 ? s : p.T - 1 - s;
+    float4 zx4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 16)
+      zx4 = *reinterpret_cast<const float4*>(p.zx + (((size_t)t * p.n_pad) * 2 + dir) * H4 + 4 * unit);
+    if (s > 0) {
+      if (tid < H / 4) {
+        const unsigned flip = 0u - ((unsigned)((s - 1) >> 1) & 1u);
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            xch + (size_t)((s - 1) & 1) * H, 0, H * 4, 0x00020000);
+        for (int i = 0; i < p.prepoll; ++i) __builtin_amdgcn_s_sleep(1);
+        u32x4 v = xload<FAST>(rsrc, (unsigned)tid * 16);
+        if (p.poll && !dead) {
+          long long t0 = 0;
+          bool timing = false;
+          while ((((v[0] ^ flip) | (v[1] ^ flip)) | ((v[2] ^ flip) | (v[3] ^ flip))) & 1u) {
+            if (!timing) { t0 = wall_clock64(); timing = true; }
+            else if (wall_clock64() - t0 > kSpinTicks) { dead = true; mark_timeout(p.status); break; }
+            __builtin_amdgcn_s_sleep(1);
+            v = xload<FAST>(rsrc, (unsigned)tid * 16);
+          }
+        }
+        *reinterpret_cast<float4*>(hs + 4 * tid) =
+            make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                        __uint_as_float(v[3]));
+      }
+      __syncthreads();
+      float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < KQ; i += 4) {
+        const float4 h4 = *reinterpret_cast<const float4*>(hs + kq * KQ + i);
+        acc0 = __builtin_fmaf(h4.x, u[i], acc0);
+        acc1 = __builtin_fmaf(h4.y, u[i + 1], acc1);
+        acc0 = __builtin_fmaf(h4.z, u[i + 2], acc0);
+        acc1 = __builtin_fmaf(h4.w, u[i + 3], acc1);
+      }
+      part[kq * 64 + c] = acc0 + acc1;
+      __syncthreads();
+    }
+    if (tid < 16) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (s > 0) {
+#pragma unroll
+        for (int gidx = 0; gidx < 4; ++gidx) {
+          const int col = 4 * tid + gidx;
+          a[gidx] = (part[col] + part[64 + col]) + (part[128 + col] + part[192 + col]);
+        }
+      }
+      const CellFwd o = cell_forward(a, zx4, cst, mask);
+      cst = o.c;
+      __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+          xch + (size_t)(s & 1) * H, 0, H * 4, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b32(tag_word(o.hm, (unsigned)(s >> 1) & 1u), wr,
+                                            (unsigned)unit * 4, 0, FAST ? 0 : kSc1);
+      const size_t row = (size_t)t * p.n_pad;
+      p.y[row * H2 + dir * H + unit] = o.h;
+      p.cell[(row * 2 + dir) * H + unit] = cst;
+      *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * unit) =
+          make_float4(o.gi, o.gf, o.gg, o.go);
+    }
+    // hs / part are rewritten only after the next step's gather, which the 16 finishing
+    // threads reach after reading part; the gather's barrier orders the rest
+    __syncthreads();
+  }
+}
+
+template <int KQ>
+__global__ void __launch_bounds__(kThreads)
+lstm_fwd_kernel_n1(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // blockIdx -> (direction, workgroup): both directions' workgroups use block ids
+  // congruent mod 8 each, as map_block does for chains
+  int dir, wg;
+  if (!map_block(p, dir, wg)) return;
+  dir += p.chain_begin;
+  const bool fast = chain_on_one_xcd(p, dir, wg, reinterpret_cast<int*>(lds));
+  __syncthreads();
+  if (fast) fwd_body_n1<KQ, true>(p, dir, wg, lds);
+  else fwd_body_n1<KQ, false>(p, dir, wg, lds);
+}
+
 // am = Uh0*Bh0 + Uh1*Bh1 ; ac = Uh0*Bl0 + Ul0*Bh0 + Uh1*Bl1 + Ul1*Bh1 (K = 2 x 32), i.e.
 // U^T-slice x dz tile = am + ac / 2048.  U fragments "a" (AGPR), B fragments and results "v".
 // s_nop 1: a VALU-written B operand needs 2 wait states before an MFMA reads it; trailing
@@ -2483,6 +2595,7 @@ lstm_bwd_kernel_x(LstmParams p) {
 struct Plan {
   int R, P, TPW, MAXR, NKK, prec;
   int pair;                // 1: a workgroup serves two batch tiles (lstm_fwd_kernel_k2)
+  int n1;                  // 1: single-utterance forward kernel (2 chains = 2 directions)
   size_t shm;
   size_t xchain_words;
   int chains_per_launch;
@@ -2600,7 +2713,15 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   pl.prec = env_int("ASR_LSTM_PREC", 1) ? 1 : 0;
   pl.NKK = 0;
   pl.pair = 0;
-  if (!bwd) {
+  pl.n1 = 0;
+  if (!bwd && a->n_valid == 1 && a->mode == 0 && (H == 256 || H == 512) &&
+      !(a->mi || a->zone_c || a->zone_h || a->uh) && env_int("ASR_LSTM_N1", 1)) {
+    // one utterance: the tile-free exact-fp32 kernel (fwd_body_n1); 2 chains = 2 directions
+    pl.R = 0; pl.MAXR = 0; pl.TPW = 0; pl.NKK = 0; pl.n1 = 1;
+    pl.shm = (size_t)(H + 256) * 4;
+    pl.xchain_words = (size_t)2 * H;
+    k = H == 256 ? lstm_fwd_kernel_n1<64> : lstm_fwd_kernel_n1<128>;
+  } else if (!bwd) {
     pl.R = up4((H + 3) / 4);
     if (pl.R > 128) {
       asr_set_error("lstm fwd: H=%d too large for the register-resident U slice (max 512)", H);
@@ -2787,7 +2908,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
     ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes + cb_, 0xFF, xb, stream));
   }
   // launch units: chains, or pairs of chains when a workgroup serves two batch tiles
-  const int chains = pl.pair ? p.NB : 2 * p.NB;
+  const int chains = pl.n1 ? 2 : pl.pair ? p.NB : 2 * p.NB;
   const bool stepwise = a->mode == 1;
   p.poll = stepwise ? 0 : 1;
   p.allow_fast = env_int("ASR_LSTM_FAST", 1);

@@ -20,6 +20,7 @@ Besides the contract fields the line carries
   cpu_baseline      the NumPy oracle port on this host's cores (bounded sample), N = 1 only,
   cfg2              the same measurement at BASELINE.json configs[1] (its own process),
   exact_fp32        cfg3 again with every product on the exact-fp32 MFMA instructions,
+  predict_latency   one 10 s utterance end to end (predict.py's unit of work), ms,
   allreduce         bus bandwidth of the gradient all-reduce, N > 1 only.
 """
 import argparse
@@ -170,6 +171,42 @@ def _fe_job(job):
         n += OF.extract(kind, sig, **kw).shape[0]
     del ctx
     return n
+
+
+def predict_latency(dev):
+    """predict.py's unit of work (predict.py:73-93): ONE 10 s utterance through front-end,
+    5 x BiLSTM(256) forward (brsmv1 defaults) and greedy decode, in milliseconds per
+    utterance, with the single-utterance recurrent kernel and with the 16-row batch kernel."""
+    import torch
+    from asr_study_amd import ops
+    from asr_study_amd.core import models
+    from asr_study_amd.preprocessing import audio
+    model = models.brsmv1(num_features=39, num_classes=28, num_hiddens=256, num_layers=5,
+                          dropout=0.2, weight_decay=1e-4, seed=0, device=dev)
+    feat = audio.MFCC(device=dev)
+    sig = np.random.RandomState(5).randn(SAMPLES).astype(np.float32)
+    out = {'utterance_seconds': 10.0, 'topology': 'brsmv1 5xBiLSTM(256), MFCC-39'}
+    for name, env in (('n1_kernel_ms', '1'), ('batch_tile_kernel_ms', '0')):
+        os.environ['ASR_LSTM_N1'] = env
+
+        def once():
+            slab, frames = feat.batch([sig])
+            logits = model.forward(slab, training=False, need_grad=False, n_valid=1)
+            return ops.ctc_greedy(logits, frames, 1)
+        for _ in range(3):
+            once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            once()
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+    os.environ.pop('ASR_LSTM_N1', None)
+    for ws in ('lstm_fwd',):
+        ops.lstm_status(ops.WS.get(ws, 0, dev))
+    out['real_time_factor'] = round(10.0 / (out['n1_kernel_ms'] * 1e-3), 1)
+    return out
 
 
 def _sub_bench(config, env_extra, steps, warmup, dropout):
@@ -495,6 +532,10 @@ def main():
             line['cfg2'] = _sub_bench('cfg2', {}, args.steps, args.warmup, args.dropout)
             line['exact_fp32'] = _sub_bench(args.config, {'ASR_LSTM_PREC': '0', 'ASR_GEMM_PREC': '0'},
                                             max(3, args.steps // 2), 2, args.dropout)
+            try:
+                line['predict_latency'] = predict_latency(dev)
+            except Exception as e:                # a companion figure never fails the bench
+                line['predict_latency'] = {'error': repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(line))

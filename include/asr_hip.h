@@ -244,6 +244,10 @@ typedef struct asr_lstm_args {
   /* bias gradient is its sum over axis 0, so no pass over the dz slab is needed for it.      */
   /* With mi set the same sums are dmi[:, :, 3].                                              */
   float* db_part;
+  /* forward, optional: number of real rows of the batch (0 = all n_pad).  n_valid == 1    */
+  /* (predict.py decodes one utterance per call) selects a tile-free exact-fp32 kernel     */
+  /* that reads and writes ROW 0 of the slabs only; the padding rows are left untouched.   */
+  int n_valid;
 } asr_lstm_args;
 size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
 int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,

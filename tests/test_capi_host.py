@@ -131,7 +131,7 @@ int main(void) {
          offsetof(asr_gemm_args, b_absmax));
   printf("lstm %zu %zu %zu %zu %zu\\n", sizeof(asr_lstm_args), offsetof(asr_lstm_args, dz_absmax),
          offsetof(asr_lstm_args, step_begin), offsetof(asr_lstm_args, dmi),
-         offsetof(asr_lstm_args, db_part));
+         offsetof(asr_lstm_args, db_part) + 1000 * offsetof(asr_lstm_args, n_valid));
   printf("pack %zu %zu %zu\\n", sizeof(asr_pack_args), offsetof(asr_pack_args, scale_out),
          offsetof(asr_pack_args, ldk_c));
   printf("gemmhl %zu %zu %zu %zu\\n", sizeof(asr_gemm_hl_args), offsetof(asr_gemm_hl_args, b_scale),
@@ -152,7 +152,7 @@ int main(void) {
     assert out['frontend'] == [C.sizeof(F), F.eps.offset]
     assert out['gemm'] == [C.sizeof(G), G.bias.offset, G.b_absmax.offset]
     assert out['lstm'] == [C.sizeof(Ls), Ls.dz_absmax.offset, Ls.step_begin.offset, Ls.dmi.offset,
-                           Ls.db_part.offset]
+                           Ls.db_part.offset + 1000 * Ls.n_valid.offset]
     P, GH = _lib.PackArgs, _lib.GemmHlArgs
     assert out['pack'] == [C.sizeof(P), P.scale_out.offset, P.ldk_c.offset]
     assert out['gemmhl'] == [C.sizeof(GH), GH.b_scale.offset, GH.bias.offset, GH.split_k.offset]

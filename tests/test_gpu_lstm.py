@@ -483,3 +483,37 @@ def test_recurrent_kernel_generations_agree_and_bptt_emits_bias_gradient(N, H, m
         monkeypatch.setenv('ASR_LSTM_FAST', transport)
         again, _ = run([None])
         assert np.array_equal(paired, again)
+
+
+@pytest.mark.parametrize('H', [256, 512])
+def test_single_utterance_forward_kernel(H):
+    """asr_lstm_args.n_valid = 1 (predict.py: one utterance per call): the tile-free exact-fp32
+    forward kernel against the float64 oracle and against the batch kernel on row 0; sliced ==
+    whole bit for bit; rows 1.. of the slabs are left untouched."""
+    from asr_study_amd import ops
+    T, N, F = 60, 1, 10
+    rs, x, p, masks = _case(T, N, F, H, 3 * H, False)
+    n_pad = 16
+    want = _oracle(x, p, masks, {d: rs.randn(T, N, H) for d in ('fwd', 'bwd')})
+    zx, U, mk = _pack_inputs(x, p, masks, H, n_pad)
+    zx_d, U_d = to_dev(zx), to_dev(U)
+
+    def run(n_valid, ranges):
+        y = torch.full((T, n_pad, 2 * H), 3.0, dtype=torch.float32, device='cuda:0')
+        cell = torch.full((T, n_pad, 2, H), 3.0, dtype=torch.float32, device='cuda:0')
+        gates = torch.full((T, n_pad, 2, 4 * H), 3.0, dtype=torch.float32, device='cuda:0')
+        for r in ranges:
+            ws = ops.lstm_seq_fwd(zx_d, U_d, y, cell, gates, T, n_pad, H, steps=r, n_valid=n_valid)
+        ops.lstm_status(ws)
+        return y.cpu().numpy(), cell.cpu().numpy(), gates.cpu().numpy()
+    y1, c1, g1 = run(1, [None])
+    for di, d in enumerate(('fwd', 'bwd')):
+        assert report('n1 h %s H%d' % (d, H), y1[:, :1, di * H:(di + 1) * H], want[d]['hs']) < 1e-5
+        assert report('n1 c %s H%d' % (d, H), c1[:, :1, di], want[d]['cache']['cs']) < 1e-5
+        assert report('n1 gates %s H%d' % (d, H), g1[:, :1, di],
+                      gate_major_to_unit_major(want[d]['cache']['gates'], H)) < 1e-5
+    assert np.all(y1[:, 1:] == 3.0) and np.all(c1[:, 1:] == 3.0) and np.all(g1[:, 1:] == 3.0)
+    yb, cb, gb = run(0, [None])
+    assert np.abs(yb[:, 0] - y1[:, 0]).max() < 5e-6 and np.abs(cb[:, 0] - c1[:, 0]).max() < 5e-6
+    ys, cs, gs = run(1, [(0, 1), (1, 40), (41, 19)])
+    assert np.array_equal(ys, y1) and np.array_equal(cs, c1) and np.array_equal(gs, g1)
