@@ -229,7 +229,9 @@ def _sub_bench(config, env_extra, steps, warmup, dropout):
         return {'error': repr(e)[:300]}
     keep = {k: d[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'arithmetic')}
     keep['workload'] = d['config']['workload']
-    for k in ('roofline', 'roofline_lstm_fwd'):
+    for k in ('roofline', 'roofline_lstm_fwd', 'roofline_lstm_bwd', 'roofline_gemm_step'):
+        if k not in d:
+            continue
         keep[k] = {kk: d[k].get(kk) for kk in ('kernel', 'achieved', 'peak', 'unit', 'frac',
                                                'us_per_timestep', 'avg_launch_ms', 'traffic')}
     keep['roofline_gate_gemm'] = {kk: d['roofline_gate_gemm'].get(kk) for kk in
@@ -312,20 +314,25 @@ def main():
     lab_d = torch.from_numpy(lab).to(dev)
     lab_len_d = torch.from_numpy(lab_len.astype(np.int32)).to(dev)
 
-    lstm_ev = {'lstm_seq_fwd': [], 'lstm_seq_bwd': []}
+    lstm_ev = {'lstm_seq_fwd': [], 'lstm_seq_bwd': [], 'gemm_hl': [], 'gemm': []}
 
     def _timed(name):
         orig = getattr(ops, name)
 
         def timed(*a, **k):
-            # HIP events on the stream the kernel is launched on (torch's current stream)
+            # HIP events on the stream the kernel is launched on (torch's current stream --
+            # also inside the engine's side-stream blocks)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig(*a, **k)
             e1.record()
-            # a layer's recurrence may be launched in slices (asr_lstm_args.step_count)
-            steps = k.get('steps')
-            lstm_ev[name].append((e0, e1, int(steps[1]) if steps else None))
+            if name.startswith('gemm'):
+                # positional (A, B, C, M, N, K): algorithmic flops of the launch
+                lstm_ev[name].append((e0, e1, 2.0 * a[3] * a[4] * a[5]))
+            else:
+                # a layer's recurrence may be launched in slices (asr_lstm_args.step_count)
+                steps = k.get('steps')
+                lstm_ev[name].append((e0, e1, int(steps[1]) if steps else None))
             return r
         return orig, timed
 
@@ -506,6 +513,34 @@ def main():
                             'neighbouring GEMMs are pipelined): DESIGN.md 5; achieved = '
                             'algorithmic fp32 flop/s vs the fp32-MFMA peak (SURVEY 8d)'}
         split = os.environ.get('ASR_GEMM_PREC', '1') != '0' or os.environ.get('ASR_LSTM_PREC', '1') != '0'
+
+        def gemm_roof():
+            # every big GEMM of the step (x@W, dz@W^T, x^T dz, h^T dz, Dense), timed in place
+            ev = lstm_ev['gemm_hl'] + lstm_ev['gemm']
+            if not ev:
+                return None
+            exact = os.environ.get('ASR_GEMM_PREC', '1') == '0'
+            tot = float(sum(a.elapsed_time(b) for a, b, _ in ev))
+            fl = float(sum(f for _, _, f in ev))
+            mult, peak = (1, PEAK_F32_MFMA_TFLOPS) if exact else (3, PEAK_F16_MFMA_TFLOPS)
+            ach = mult * fl / (tot * 1e-3) / 1e12
+            packed = len(lstm_ev['gemm_hl']) > 0
+            return {'kernel': ('gemm_hl256_kernel / gemm_hl_kernel (operands packed once into '
+                               'split-fp16 planes)' if packed else
+                               'gemm_f32_mfma_kernel' if exact else 'gemm_f16x2_fast_kernel') +
+                              ': all GEMMs of the step',
+                    'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak, 4), 'traffic': pmc.get('gemm'),
+                    'algorithmic_fp32_tflops': round(fl / (tot * 1e-3) / 1e12, 2),
+                    'launches_per_step': round(len(ev) / float(args.steps), 1),
+                    'avg_launch_ms': round(tot / len(ev), 4),
+                    'ms_per_step': round(tot / args.steps, 3),
+                    'algorithmic_tflop_per_step': round(fl / args.steps / 1e12, 3),
+                    'note': 'achieved = executed MFMA flop/s (split-fp16: 3 fp16 MFMAs per fp32 '
+                            'product) summed over the launches, vs the dense fp16 MFMA peak at '
+                            '2.4 GHz (the chip sustains ~1.95 GHz under this load: the pipes '
+                            'are ~51 % busy, profiles/r2g_pmc_gemm_hl.md); event intervals of '
+                            'side-stream launches include contention with the recurrences'}
         line = {
             'metric': 'audio-seconds/sec trained (MFCC+BiLSTM+CTC)',
             'value': round(value, 1), 'unit': 'audio-seconds/s', 'n_gpus': world,
@@ -528,6 +563,17 @@ def main():
                                                      'recurrence of one BiLSTM layer)'),
         }
         line.update(extra)
+        # `roofline` is the family with the largest share of the step: the BPTT recurrence, the
+        # forward recurrence or the GEMMs (all three stay in the line under their own keys)
+        gr = gemm_roof()
+        if gr is not None:
+            line['roofline_gemm_step'] = gr
+            shares = {'roofline_gemm_step': gr['ms_per_step'],
+                      'roofline_lstm_fwd': (fwd_t[1] or 0.0) / args.steps,
+                      'roofline_lstm_bwd': (bwd_t[1] or 0.0) / args.steps}
+            line['roofline_lstm_bwd'] = line['roofline']
+            top = max(shares, key=shares.get)
+            line['roofline'] = dict(line[top], dominant_of={k: round(v, 3) for k, v in shares.items()})
         if world == 1 and not args.no_extras:
             line['cfg2'] = _sub_bench('cfg2', {}, args.steps, args.warmup, args.dropout)
             line['exact_fp32'] = _sub_bench(args.config, {'ASR_LSTM_PREC': '0', 'ASR_GEMM_PREC': '0'},

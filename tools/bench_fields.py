@@ -9,5 +9,5 @@ for ln in sys.stdin:
     d = json.loads(ln)
     print('%s: %.1f %s, %.3f ms/step, bwd %.3f us/step, fwd %.3f us/step, gemm %.1f TF/s' % (
         d['config']['workload'][:5], d['value'], d['unit'], d['ms_per_step'],
-        d['roofline']['us_per_timestep'], d['roofline_lstm_fwd']['us_per_timestep'],
+        d.get('roofline_lstm_bwd', d['roofline'])['us_per_timestep'], d['roofline_lstm_fwd']['us_per_timestep'],
         d['roofline_gate_gemm']['algorithmic_fp32_tflops']))

@@ -2,10 +2,10 @@
 out=gpurun_out/${1:-r2h}
 mkdir -p $out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_lstm.py tests/test_gpu_cli.py -q --timeout 600 -k "single_utterance or cli or predict or cfg5" > $out/pytest.log 2>&1 </dev/null
+timeout 300 python -m pytest tests/test_gpu_parallel.py -q --timeout 300 > $out/pytest.log 2>&1 </dev/null
 tail -5 $out/pytest.log
-/usr/bin/time -v timeout 900 python bench.py > $out/bench.log 2> $out/bench.err </dev/null
-grep -E "Elapsed|Maximum resident" $out/bench.err
+SECONDS=0; timeout 900 python bench.py > $out/bench.log 2> $out/bench.err </dev/null; echo "bench wall ${SECONDS}s"
+
 tail -1 $out/bench.log | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
@@ -14,5 +14,8 @@ print('predict', d.get('predict_latency'))
 print('cfg2', {k: d['cfg2'].get(k) for k in ('value', 'ms_per_step', 'error')})
 print('exact', {k: d['exact_fp32'].get(k) for k in ('value', 'ms_per_step', 'error')})
 print('gemm', d['roofline_gate_gemm'])
+print('roofline', d['roofline'])
+print('gemm_step', d.get('roofline_gemm_step'))
 print('cpu', d['cpu_baseline'])
 "
+tail -3 $out/bench.err
