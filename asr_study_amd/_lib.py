@@ -66,7 +66,7 @@ class LstmArgs(C.Structure):
                 ('step_begin', C.c_int), ('step_count', C.c_int),
                 ('mi', void_p), ('uh', void_p), ('zone_c', void_p), ('zone_h', void_p),
                 ('wx', void_p), ('dwx', void_p), ('dmi', void_p), ('db_part', void_p),
-                ('n_valid', C.c_int)]
+                ('n_valid', C.c_int), ('lds_reserve_kb', C.c_int)]
 
 
 class LstmLnArgs(C.Structure):
@@ -122,6 +122,8 @@ SIGNATURES = {
                                      C.c_uint32, C.c_uint32, void_p]),
     'asr_random_words': (C.c_int, [void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, void_p]),
     'asr_mul': (C.c_int, [C.c_int64, void_p, void_p, void_p, void_p]),
+    'asr_stream_create_cu_mask': (C.c_int, [void_p, C.c_int, C.POINTER(void_p)]),
+    'asr_stream_destroy': (C.c_int, [void_p]),
     'asr_colsum_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'asr_colsum': (C.c_int, [void_p, C.c_int, C.c_int, C.c_int, void_p, C.c_float, void_p,
                              C.c_size_t, void_p]),

@@ -28,3 +28,16 @@ extern "C" int asr_device_info(int* num_cus, int* lds_bytes_per_cu, char* arch,
   }
   return ASR_OK;
 }
+
+extern "C" int asr_stream_create_cu_mask(const uint32_t* mask, int words, asr_stream_t* stream_out) {
+  ASR_CHECK_ARG(mask && words > 0 && stream_out, "stream_create_cu_mask: bad arguments");
+  hipStream_t st = nullptr;
+  ASR_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+  *stream_out = (asr_stream_t)st;
+  return ASR_OK;
+}
+
+extern "C" int asr_stream_destroy(asr_stream_t stream) {
+  ASR_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+  return ASR_OK;
+}

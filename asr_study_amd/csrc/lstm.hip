@@ -2800,8 +2800,12 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   // Own the CU: a latency-bound workgroup must not share its SIMDs / LDS pipe with the
   // GEMM workgroups (80 KB LDS each) that the host overlaps on a second stream, so it
   // reserves enough LDS that none of those fits beside it (ASR_LSTM_EXCL=0 disables).
+  // (asr_lstm_args.lds_reserve_kb = 80 lets exactly TWO recurrent workgroups share a CU and
+  // still keeps every 80 KB GEMM workgroup out: the caller then confines the launch to half
+  // of the CUs with a CU-masked stream and leaves the other half to the GEMM streams)
   static const int excl = env_int("ASR_LSTM_EXCL", 1);
-  if (excl && pl.shm < (size_t)96 * 1024) pl.shm = (size_t)96 * 1024;
+  const size_t reserve = (size_t)(a->lds_reserve_kb > 0 ? a->lds_reserve_kb : 96) * 1024;
+  if (excl && pl.shm < reserve) pl.shm = reserve;
   if (pl.shm > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)pl.shm) != hipSuccess) {

@@ -148,6 +148,31 @@ def colsum(X, M, N, ldx, out, beta=0.0, x_off=0, ws_name='colsum'):
 
 
 # --------------------------------------------------------------------------- LSTM
+# LDS a recurrent workgroup reserves (asr_lstm_args.lds_reserve_kb; 0 = the library's 96 KB).
+# The engine sets 80 while its recurrences run on a CU-masked stream (two workgroups per CU).
+LSTM_LDS_KB = 0
+
+
+def cu_masked_stream(device, n_cus, total_cus):
+    """A torch stream confined to n_cus of the device's total_cus compute units
+    (asr_stream_create_cu_mask).  The mask alternates groups of 8 CUs, which selects the same
+    number of CUs on every XCD whether the runtime numbers them XCD-interleaved or XCD-major."""
+    words = (int(total_cus) + 31) // 32
+    bits = [0] * words
+    chosen = 0
+    for pass_ in range(2):                      # even groups of 8 first, then odd ones
+        for i in range(int(total_cus)):
+            if chosen >= n_cus:
+                break
+            if ((i // 8) % 2 == pass_) and not (bits[i // 32] >> (i % 32)) & 1:
+                bits[i // 32] |= 1 << (i % 32)
+                chosen += 1
+    arr = (C.c_uint32 * words)(*bits)
+    out = C.c_void_p()
+    L.check(L.load().asr_stream_create_cu_mask(arr, words, C.byref(out)), 'asr_stream_create_cu_mask')
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
 def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=None,
                dy=None, dz=None, mode=0, dz_absmax=None, steps=None, mi=None, uh=None,
                zone_c=None, zone_h=None, wx=None, dwx=None, dmi=None, db_part=None):
@@ -172,6 +197,7 @@ def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=
     a = _lstm_args(T, n_pad, H, U, mask_u, zx=zx, y=y, cell=cell, gates=gates, mode=mode,
                    steps=steps, mi=mi, uh=uh, zone_c=zone_c, zone_h=zone_h)
     a.n_valid = int(n_valid)            # 1: single-utterance kernel (row 0 only)
+    a.lds_reserve_kb = LSTM_LDS_KB
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 0)
     ws = WS.get('lstm_fwd', nbytes, zx.device)
     L.check(lib.asr_lstm_seq_fwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_fwd')
@@ -190,6 +216,7 @@ def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check
     a = _lstm_args(T, n_pad, H, U, mask_u, cell=cell, gates=gates, dy=dy, dz=dz, mode=mode,
                    dz_absmax=dz_absmax, steps=steps, mi=mi, uh=uh, zone_c=zone_c,
                    zone_h=zone_h, wx=wx, dwx=dwx, dmi=dmi, db_part=db_part)
+    a.lds_reserve_kb = LSTM_LDS_KB
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 1)
     ws = WS.get('lstm_bwd', nbytes, dy.device)
     L.check(lib.asr_lstm_seq_bwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_bwd')

@@ -248,6 +248,11 @@ typedef struct asr_lstm_args {
   /* (predict.py decodes one utterance per call) selects a tile-free exact-fp32 kernel     */
   /* that reads and writes ROW 0 of the slabs only; the padding rows are left untouched.   */
   int n_valid;
+  /* LDS a recurrent workgroup reserves, in KB (0 = 96: alone on its CU beside 80 KB GEMM    */
+  /* workgroups).  80 = two recurrent workgroups per CU, for launches on a stream confined   */
+  /* to half of the CUs (asr_stream_create_cu_mask): the recurrence is latency-bound, so two */
+  /* chains interleave on one CU while the other half of the chip runs GEMMs.                */
+  int lds_reserve_kb;
 } asr_lstm_args;
 size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
 int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,
@@ -480,6 +485,12 @@ int asr_gaussian_noise(const float* in, float* out, int64_t n, float sigma, uint
 int asr_random_words(unsigned* out, int64_t n, uint64_t seed, uint32_t stream_id, uint32_t step,
                      asr_stream_t stream);
 int asr_mul(int64_t n, const float* x, const float* y, float* out, asr_stream_t stream);
+
+/* A stream whose kernels run only on the compute units set in `mask` (bit i of word i/32 =  */
+/* CU i; hipExtStreamCreateWithCUMask): partitions the chip between the latency-bound        */
+/* recurrences and the GEMMs that run beside them.  Destroy with asr_stream_destroy.         */
+int asr_stream_create_cu_mask(const uint32_t* mask, int words, asr_stream_t* stream_out);
+int asr_stream_destroy(asr_stream_t stream);
 
 /* K9 / K10 under their operation names (same arguments as the *_host forms).  */
 int asr_ctc_beam(const float* logits_host, const int* seq_len_host, int T, int N,
