@@ -133,6 +133,9 @@ class Model(object):
         # to the GEMM streams
         self._rec = None
         self._rec_cus = int(_os.environ.get('ASR_REC_CUS', '0') or 0)
+        # tile of the weight-gradient GEMMs (side stream): 128 = the 4-wave / 80 KB kernel that
+        # can share a CU with a recurrent workgroup (when those reserve no LDS: ASR_LSTM_EXCL=0)
+        self._side_tile = int(_os.environ.get('ASR_SIDE_TILE', '0') or 0)
         # big GEMMs on operands packed once into split-fp16 planes (ops.pack_hl / gemm_hl);
         # ASR_GEMM_PACKED=0 keeps the convert-per-tile kernels, ASR_GEMM_PREC=0 (exact fp32) too
         # 'auto': from 512 hidden units on (measured: +4 % at 5 x BiLSTM(512) with the 256 x 256
@@ -373,16 +376,18 @@ class Model(object):
             optimizer.bind(self)
 
     # ------------------------------------------------------------------ buffers
-    def _buf(self, name, shape):
+    def _buf(self, name, shape, zero=False):
+        """Cached float32 buffer.  zero=True fills it with zeros WHEN IT IS CREATED, on the
+        current stream -- only for buffers whose first user runs on that same stream (a fill
+        kernel is not ordered against the side / pipe streams, which wait on events only)."""
         key = (name, tuple(int(x) for x in shape))
         b = self._bufs.get(key)
         if b is None:
             # drop stale shapes of the same name to bound memory
             for k in [k for k in self._bufs if k[0] == name]:
                 del self._bufs[k]
-            # (zero-filled once: kernels that write only the real rows of a slab -- the
-            # single-utterance forward kernel -- must not leave junk in the padding rows)
-            b = torch.zeros(key[1], dtype=torch.float32, device=self.device)
+            b = (torch.zeros if zero else torch.empty)(key[1], dtype=torch.float32,
+                                                       device=self.device)
             self._bufs[key] = b
         return b
 
@@ -576,9 +581,11 @@ class Model(object):
                     self._gate_gemm(a, s, zx, BW, 0, (T - S) * n_pad, n_pad)
                     self._gate_gemm(a, s, zx, BW, S * n_pad, rows, n_pad)
                     main.wait_event(inner_done)
-                y = self._buf('y%d' % si, (T, n_pad, 2 * Hp))
-                cell = self._buf('cell%d' % si, (T, n_pad, 2, Hp))
-                gates = self._buf('gates%d' % si, (T, n_pad, 2, 4 * Hp))
+                # (the single-utterance kernel writes row 0 only: no junk in the padding rows)
+                one = n_valid == 1 and not need_grad
+                y = self._buf('y%d' % si, (T, n_pad, 2 * Hp), zero=one)
+                cell = self._buf('cell%d' % si, (T, n_pad, 2, Hp), zero=one)
+                gates = self._buf('gates%d' % si, (T, n_pad, 2, 4 * Hp), zero=one)
                 U = self._view(s.oU, 2 * Hp * 4 * Hp)
                 nxt = self.stages[si + 1] if si + 1 < len(self.stages) else None
                 if s.ln is not None:        # generic row-per-workgroup cell (csrc/lstm_ln.hip)
@@ -869,17 +876,17 @@ class Model(object):
                         ops.gemm_hl(yu, pdz_c, self.grads, Hp, 4 * Hp, kk,
                                     a_k=0 if d == 0 else n_pad, b_row=d * 4 * Hp,
                                     b_k=n_pad if d == 0 else 0, c_off=s.oU + d * Hp * 4 * Hp,
-                                    split_k=split, ws_name=wsn)
+                                    split_k=split, ws_name=wsn, tile=self._side_tile)
 
                 def grads_W_hl(wsn, s=s, pa=rec.get('pa'), Hp=Hp, pdz_c=pdz_c, pgrad=pgrad):
                     if len(pa) == 1:
                         ops.gemm_hl(pa[0][1], pdz_c, self.grads, s.f_in_pad, 8 * Hp, rows,
-                                    c_off=s.oW, split_k=split, ws_name=wsn)
+                                    c_off=s.oW, split_k=split, ws_name=wsn, tile=self._side_tile)
                     else:
                         for d in range(2):
                             ops.gemm_hl(pa[d][1], pdz_c, self.grads, s.f_in_pad, 4 * Hp, rows,
                                         b_row=d * 4 * Hp, c_off=s.oW + d * 4 * Hp, ldc=8 * Hp,
-                                        split_k=split, ws_name=wsn)
+                                        split_k=split, ws_name=wsn, tile=self._side_tile)
                     buf, nrow, ncol, goff = pgrad
                     ops.colsum(buf, nrow, ncol, ncol, self._gview(goff, ncol), ws_name=wsn + '_cs')
 

@@ -1554,7 +1554,7 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
   // tile: 256 x 256 (512 threads, 128 KB LDS) for outputs of at least that size, else 128 x 128
   // (ASR_GEMM_HL_TILE=128 forces the small tile)
   static const int tile_env = [] { const char* v = getenv("ASR_GEMM_HL_TILE"); return v ? atoi(v) : 256; }();
-  if (tile_env >= 256 && a->M >= TM2 && a->N >= TN2) {
+  if (tile_env >= 256 && a->tile != 128 && a->M >= TM2 && a->N >= TN2) {
     const size_t shm2 = (size_t)2 * 4 * 256 * 32 * sizeof(_Float16);
     static bool attr2_done = false;
     if (!attr2_done) {

@@ -174,6 +174,11 @@ typedef struct asr_gemm_hl_args {
   const float* bias;                             /* (N) or NULL                       */
   const float* c_scale; int c_scale_period; int c_scale_ld;   /* mask on C rows or NULL */
   int split_k;                                   /* 0/1 = none                        */
+  int tile;                                      /* 0 = library default (256 x 256 for  */
+                                                 /* outputs that large), 128 = the      */
+                                                 /* 128 x 128 kernel: 4 waves, 80 KB    */
+                                                 /* LDS, co-resident with a recurrent   */
+                                                 /* workgroup that reserves no LDS      */
 } asr_gemm_hl_args;
 size_t asr_gemm_hl_workspace_bytes(const asr_gemm_hl_args* a);
 int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws_bytes,
