@@ -135,7 +135,7 @@ int main(void) {
   printf("pack %zu %zu %zu\\n", sizeof(asr_pack_args), offsetof(asr_pack_args, scale_out),
          offsetof(asr_pack_args, ldk_c));
   printf("gemmhl %zu %zu %zu %zu\\n", sizeof(asr_gemm_hl_args), offsetof(asr_gemm_hl_args, b_scale),
-         offsetof(asr_gemm_hl_args, bias), offsetof(asr_gemm_hl_args, split_k));
+         offsetof(asr_gemm_hl_args, bias), offsetof(asr_gemm_hl_args, split_k) + 1000 * offsetof(asr_gemm_hl_args, tile));
   printf("segment %zu %zu\\n", sizeof(asr_segment), offsetof(asr_segment, l2));
   printf("lstmln %zu %zu %zu\\n", sizeof(asr_lstm_ln_args), offsetof(asr_lstm_ln_args, cellp),
          offsetof(asr_lstm_ln_args, dparams));
@@ -155,7 +155,7 @@ int main(void) {
                            Ls.db_part.offset + 1000 * Ls.n_valid.offset]
     P, GH = _lib.PackArgs, _lib.GemmHlArgs
     assert out['pack'] == [C.sizeof(P), P.scale_out.offset, P.ldk_c.offset]
-    assert out['gemmhl'] == [C.sizeof(GH), GH.b_scale.offset, GH.bias.offset, GH.split_k.offset]
+    assert out['gemmhl'] == [C.sizeof(GH), GH.b_scale.offset, GH.bias.offset, GH.split_k.offset + 1000 * GH.tile.offset]
     assert out['segment'] == [C.sizeof(S), S.l2.offset]
     LN = _lib.LstmLnArgs
     assert out['lstmln'] == [C.sizeof(LN), LN.cellp.offset, LN.dparams.offset]
