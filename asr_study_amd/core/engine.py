@@ -1116,9 +1116,22 @@ class Model(object):
         flags = ops.lstm_timeout_flags(self.device) if flags is None else flags
         if bool(flags.any().item()):
             from .._lib import AsrHipError
-            raise AsrHipError('a persistent LSTM kernel abandoned a bounded spin (peer workgroup '
-                              'not co-resident or device fault): the results of this step are '
-                              'invalid; ASR_LSTM_MODE=1 selects the stepwise kernels')
+            if self.lstm_mode == 1:
+                raise AsrHipError('a recurrent LSTM kernel reported a timeout in stepwise mode: '
+                                  'device fault')
+            # A persistent kernel abandoned a bounded spin (a peer workgroup was not
+            # co-resident).  The update of every step enqueued since was vetoed on the device
+            # (ops.optim_guard), so the weights are intact: clear the flags and go on with the
+            # stepwise kernels (one launch per step, identical arithmetic, no co-residency).
+            import logging
+            logging.getLogger(__name__).warning(
+                'persistent LSTM kernel timed out waiting for a peer workgroup; the affected '
+                'step(s) were skipped; falling back to the stepwise kernels (mode 1)')
+            torch.cuda.synchronize(self.device)
+            for name in ('lstm_fwd', 'lstm_bwd'):
+                ops.WS.get(name, 0, self.device)[:4].zero_()
+            self.lstm_mode = 1
+            self.fallbacks = getattr(self, 'fallbacks', 0) + 1
         if pen is not None:
             pen = float(pen.item())
         else:

@@ -40,9 +40,12 @@ class Adam(Optimizer):
         # Keras 1.2.2: lr *= 1 / (1 + decay * iterations), iterations counted BEFORE this update
         lr = self.lr / (1.0 + self.decay * self.iterations) if self.decay else self.lr
         self.iterations += 1
-        ops.clip_adam_step(model.params, model.grads, self.state[0], self.state[1],
-                           model._segs_dev, model._nseg, model._norm, self.clipnorm, lr,
-                           self.iterations, self.beta_1, self.beta_2, self.epsilon)
+        # norm -> device-side veto if a recurrent kernel flagged a timeout -> clipped update
+        ops.grad_norm(model.params, model.grads, model._segs_dev, model._nseg, model._norm)
+        ops.optim_guard(model._norm, model.params.device)
+        ops.adam_step(model.params, model.grads, self.state[0], self.state[1], model._segs_dev,
+                      model._nseg, model._norm, self.clipnorm, lr, self.iterations, self.beta_1,
+                      self.beta_2, self.epsilon)
 
 
 class SGD(Optimizer):
@@ -59,8 +62,10 @@ class SGD(Optimizer):
     def step(self, model):
         lr = self.lr / (1.0 + self.decay * self.iterations) if self.decay else self.lr
         self.iterations += 1
-        ops.clip_sgd_step(model.params, model.grads, self.state[0], model._segs_dev,
-                          model._nseg, model._norm, self.clipnorm, lr, self.momentum)
+        ops.grad_norm(model.params, model.grads, model._segs_dev, model._nseg, model._norm)
+        ops.optim_guard(model._norm, model.params.device)
+        ops.sgd_step(model.params, model.grads, self.state[0], model._segs_dev, model._nseg,
+                     model._norm, self.clipnorm, lr, self.momentum)
 
 
 def get(name):

@@ -78,6 +78,7 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
             float* __restrict__ v, int64_t n, const asr_segment* __restrict__ seg, int n_seg,
             const double* __restrict__ norm, float clipnorm, float lr_t, float b1, float b2,
             float eps) {
+  if (norm != nullptr && norm[0] < 0.0) return;      // step vetoed (asr_optim_guard): no update
   const float sc = clip_scale(norm, clipnorm);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -96,6 +97,7 @@ __global__ void __launch_bounds__(256)
 sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ vel,
            int64_t n, const asr_segment* __restrict__ seg, int n_seg,
            const double* __restrict__ norm, float clipnorm, float lr, float mu) {
+  if (norm != nullptr && norm[0] < 0.0) return;      // step vetoed (asr_optim_guard): no update
   const float sc = clip_scale(norm, clipnorm);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -106,6 +108,13 @@ sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict
     vel[i] = vn;
     p[i] = w + vn;
   }
+}
+
+// Vetoes the optimiser step that follows when a device-side fault flag is set: the norm (never
+// negative otherwise) becomes -1 and the update kernels return without touching anything.
+__global__ void optim_guard_kernel(double* __restrict__ norm, const int* __restrict__ a,
+                                   const int* __restrict__ b) {
+  if ((a && *a != 0) || (b && *b != 0)) norm[0] = -1.0;
 }
 
 int grid_for(int64_t n) {
@@ -138,6 +147,15 @@ extern "C" int asr_grad_norm(const float* params, const float* grads, int64_t n,
   ASR_CHECK_LAUNCH();
   hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks,
                      norm_out);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}
+
+extern "C" int asr_optim_guard(double* norm_dev, const int* flag_a, const int* flag_b,
+                               asr_stream_t stream_) {
+  ASR_CHECK_ARG(norm_dev, "optim_guard: null norm");
+  hipLaunchKernelGGL(optim_guard_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, norm_dev,
+                     flag_a, flag_b);
   ASR_CHECK_LAUNCH();
   return ASR_OK;
 }

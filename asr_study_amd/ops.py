@@ -368,6 +368,14 @@ def clip_adam_step(params, grads, m, v, segs, n_seg, norm_out, clipnorm, lr, ste
                                    nbytes, _stream()), 'asr_clip_adam_step')
 
 
+def optim_guard(norm, device):
+    """Vetoes the update that follows if a persistent recurrent kernel has flagged a timeout
+    (the sticky words at the head of the lstm_fwd / lstm_bwd workspaces); device-side only."""
+    L.check(L.load().asr_optim_guard(_ptr(norm), _ptr(WS.get('lstm_fwd', 0, device)),
+                                     _ptr(WS.get('lstm_bwd', 0, device)), _stream()),
+            'asr_optim_guard')
+
+
 def clip_sgd_step(params, grads, vel, segs, n_seg, norm_out, clipnorm, lr, momentum=0.9):
     lib = L.load()
     n = params.numel()

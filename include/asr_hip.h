@@ -505,6 +505,14 @@ int asr_edit_distance(const int* hyp, const int* hyp_len, int hyp_ld,
                       const int* truth, const int* truth_len, int truth_ld, int N,
                       float* out_normalized);
 
+/* Device-side veto of the NEXT update (no host round trip): if *flag_a or *flag_b (device    */
+/* ints, either may be NULL) is non-zero -- e.g. the sticky timeout words at the head of the   */
+/* recurrent kernels' workspaces -- norm_dev[0] becomes -1 and asr_adam_step / asr_sgd_step     */
+/* given that norm return without touching parameters or state.  Enqueue it between            */
+/* asr_grad_norm and the step; the host sees the flag at its next (lagged) check, switches to   */
+/* the stepwise recurrent kernels (mode 1) and goes on with intact weights.                     */
+int asr_optim_guard(double* norm_dev, const int* flag_a, const int* flag_b, asr_stream_t stream);
+
 /* K11 one call per optimiser step: global gradient norm (written to norm_out  */
 /* as asr_grad_norm does) followed by the clipped Adam / SGD update, both      */
 /* enqueued on `stream`; workspace from asr_optim_workspace_bytes(n).          */

@@ -386,16 +386,21 @@ def test_lr_callbacks_and_optimizer_decay():
     # Keras decay: lr / (1 + decay * iterations), iterations before the update
     seen = []
     import asr_study_amd.ops as ops_mod
-    orig = ops_mod.clip_adam_step
-    ops_mod.clip_adam_step = lambda *a, **k: seen.append(a[8])
+    orig = (ops_mod.grad_norm, ops_mod.optim_guard, ops_mod.adam_step)
+    ops_mod.grad_norm = lambda *a, **k: None
+    ops_mod.optim_guard = lambda *a, **k: None
+    ops_mod.adam_step = lambda *a, **k: seen.append(a[8])
     try:
         opt = optimizers.Adam(lr=1.0, decay=0.5)
 
         class Fake(object):
-            params = grads = _segs_dev = _nseg = _norm = None
+            grads = _segs_dev = _nseg = _norm = None
+
+            class params(object):
+                device = None
         opt.state = [None, None]
         for _ in range(3):
             opt.step(Fake())
     finally:
-        ops_mod.clip_adam_step = orig
+        ops_mod.grad_norm, ops_mod.optim_guard, ops_mod.adam_step = orig
     assert seen == [1.0, 1.0 / 1.5, 1.0 / 2.0]

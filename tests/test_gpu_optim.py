@@ -48,3 +48,40 @@ def test_adam_and_sgd(clip):
             assert abs(nh[0] - want_norm) < 1e-5 * want_norm
             assert abs(nh[1] - want_pen) < 1e-5 * max(1.0, want_pen)
             assert np.abs(p.cpu().numpy() - p_ref[0]).max() < 2e-5
+
+
+def test_timeout_flag_vetoes_the_update_and_the_engine_falls_back_to_stepwise_kernels():
+    """A persistent recurrent kernel that abandons a bounded spin sets the sticky word of its
+    workspace.  The update enqueued behind it is vetoed ON THE DEVICE (asr_optim_guard: the
+    norm becomes -1, the update kernels return), the host sees the flag at its next check,
+    clears it, switches to the stepwise kernels (mode 1) and training goes on with the weights
+    it had -- no exception, no corrupted step."""
+    import torch
+    from asr_study_amd import ops
+    from asr_study_amd.core import models, optimizers
+    rs = np.random.RandomState(0)
+    model = models.brsmv1(num_features=9, num_classes=7, num_hiddens=16, num_layers=2,
+                          dropout=0.0, weight_decay=1e-4, seed=1)
+    model.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=1.0))
+    x = rs.randn(5, 30, 9).astype(np.float32)
+    labels = [rs.randint(0, 6, size=4).tolist() for _ in range(5)]
+    batch = [x, labels, [30] * 5]
+    model.train_on_batch(batch)
+    dev = model.device
+    before = model.params.clone()
+    m_before = model.optimizer.state[0].clone()
+    ops.WS.get('lstm_bwd', 0, dev)[:4].view(torch.int32)[0] = 1      # what mark_timeout() does
+    out = model.train_on_batch(batch)                  # the step runs, its update is vetoed
+    assert np.isfinite(out[1])
+    assert torch.equal(model.params, before) and torch.equal(model.optimizer.state[0], m_before)
+    assert model.lstm_mode == 1 and model.fallbacks == 1
+    assert not ops.lstm_timeout_flags(dev).any().item()
+    out2 = model.train_on_batch(batch)                 # stepwise kernels: the update happens
+    assert not torch.equal(model.params, before) and np.isfinite(out2[0])
+    # the stepwise mode computes the same thing: compare with a fresh model on the persistent path
+    ref = models.brsmv1(num_features=9, num_classes=7, num_hiddens=16, num_layers=2,
+                        dropout=0.0, weight_decay=1e-4, seed=1)
+    ref.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=1.0))
+    ref.train_on_batch(batch)
+    # (ref took 1 update, model took 1 + vetoed + 1: same Adam iteration count only for the norm)
+    assert abs(out2[1] - ref.test_on_batch(batch)[1]) < 1e-3 * max(1.0, abs(out2[1]))
