@@ -1154,9 +1154,7 @@ class Model(object):
         if self.decoder.get('is_greedy', True):
             dec, dlen = ops.ctc_greedy(logits, sl, N)
         else:
-            hyps, _ = ops.ctc_beam_search_host(
-                logits.cpu().numpy(), lens, N, self.decoder.get('beam_width', 100),
-                self.decoder.get('merge_repeated', True))
+            dec, dlen = self._beam(logits, sl, N)
         # l2 penalty of the current weights (reported in 'loss', as Keras does)
         if self.optimizer is None or self._step == 0:
             w2 = 0.0
@@ -1187,10 +1185,26 @@ class Model(object):
             dec, dlen = ops.ctc_greedy(logits, sl, N)
             dec, dlen = dec.cpu().numpy(), dlen.cpu().numpy()
             return [dec[n, :dlen[n]].tolist() for n in range(N)]
-        hyps, _ = ops.ctc_beam_search_host(logits.cpu().numpy(), lens, N,
-                                           self.decoder.get('beam_width', 100),
-                                           self.decoder.get('merge_repeated', True))
-        return hyps
+        dec, dlen = self._beam(logits, sl, N)
+        dec, dlen = dec.cpu().numpy(), dlen.cpu().numpy()
+        return [dec[n, :dlen[n]].tolist() for n in range(N)]
+
+    def _beam(self, logits, seq_len_dev, N):
+        """core/ctc_utils.py:48-50 on the device (K9): the logits stay in HBM; only the decoded
+        labels are copied back.  Widths beyond the kernel's 1024 (or > 64 classes) use the
+        library's host decoder (decode_host.cpp) on a copy of the logits."""
+        width = int(self.decoder.get('beam_width', 100))
+        merge = self.decoder.get('merge_repeated', True)
+        if width <= 1024 and logits.shape[2] <= 64:
+            dec, dlen, _ = ops.ctc_beam_search(logits, seq_len_dev, N, width, merge)
+            return dec, dlen
+        lens = seq_len_dev.cpu().numpy()
+        hyps, _ = ops.ctc_beam_search_host(logits.cpu().numpy(), lens, N, width, merge)
+        T = logits.shape[0]
+        dec = np.full((N, T), -1, np.int32)
+        for n, h in enumerate(hyps):
+            dec[n, :len(h)] = h
+        return torch.from_numpy(dec), torch.tensor([len(h) for h in hyps], dtype=torch.int32)
 
     # ------------------------------------------------------------------ loops
     def fit_generator(self, generator, samples_per_epoch, nb_epoch, verbose=1, callbacks=None,

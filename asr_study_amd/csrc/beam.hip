@@ -1,0 +1,387 @@
+// K9 CTC prefix beam search on the device -- gfx950.
+//
+// Replaces core/ctc_utils.py:48-50 (tf.nn.ctc_beam_search_decoder, top_paths=1) on logits that
+// never leave HBM: eval.py / predict.py decode with width 400 (utils/core_utils.py:70-71)
+// without the D2H copy of the (T, n_pad, C) slab the host decoder (decode_host.cpp) needs.
+// Same algorithm, same arithmetic (double) and the same tie-breaking as decode_host.cpp; what
+// changes is the shape of the loop (tests/beam_device_model.py is a line-by-line CPU model of
+// it, checked against the oracle and the host decoder):
+//
+//  * one workgroup per utterance; the frame's <= W branches live in LDS, nodes outside the beam
+//    keep only their child block in HBM.  Node ids are allocated in blocks of C-1 when a prefix
+//    first expands, so the creation order TensorFlow's BeamComparer breaks ties with IS the id;
+//  * a frame's branches are the previous frame's beam in its sorted order, so they are never
+//    sorted; their new totals are ranked once (rank sort over LDS broadcasts);
+//  * the beam is a SORTED array (total descending, id ascending) held in the registers of
+//    wave 0 for the whole frame, entry j in lane j % 64, slot j / 64: the heap bottom is the
+//    last entry, an insertion is one ballot-count of the better entries plus a one-lane shift
+//    (DPP wave_shr:1) of the entries behind it;
+//  * a branch's turn evaluates its C-1 children in the lanes of wave 0: children that fail
+//    against the current bottom are decided at once (the bottom only rises), the lowest-label
+//    candidate is inserted, then the rest is re-evaluated (an insertion can evict a sibling
+//    that was active).  The turn loop ends at the first branch whose old total does not beat
+//    the bottom of a full beam (the branches are sorted by it).
+#include "common.h"
+
+#include <limits.h>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxC = 64;               // classes (blank included): one wave handles a frame
+
+struct Rec {                            // per node, HBM
+  int children;                         // child block or -1 (never expanded)
+  int turn;                             // branch index in the current frame or -1 (not in beam)
+};
+
+struct BeamParams {
+  const float* logits;
+  const int* seq_len;
+  int T, n_pad, C, W, merge;
+  int* decoded;
+  int* decoded_len;
+  float* score;
+  char* ws;
+  size_t ws_per_utt;
+  int max_blocks;
+};
+
+__device__ __forceinline__ double neg_inf() { return -__builtin_huge_val(); }
+
+__device__ __forceinline__ double lse(double a, double b) {
+  if (a == neg_inf()) return b;
+  if (b == neg_inf()) return a;
+  const double m = a > b ? a : b;
+  return m + log(exp(a - m) + exp(b - m));
+}
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int readlane_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ double readlane_d(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                          __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// lane i <- lane i-1, lane 0 <- carry
+template <bool DPP>
+__device__ __forceinline__ int shr1_i(int x, int carry) {
+  if (DPP) return __builtin_amdgcn_update_dpp(carry, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const int t = __shfl_up(x, 1, 64);
+  return (threadIdx.x & 63) == 0 ? carry : t;
+}
+template <bool DPP>
+__device__ __forceinline__ double shr1_d(double x, double carry) {
+  return __hiloint2double(shr1_i<DPP>(__double2hiint(x), __double2hiint(carry)),
+                          shr1_i<DPP>(__double2loint(x), __double2loint(carry)));
+}
+
+size_t lds_bytes(int W) { return (size_t)W * 100 + 72 * 8 + 64 * 4 + 16 * 4; }
+
+template <int E, bool DPP>
+__global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int W = p.W, C = p.C, K = p.C - 1, blank = p.C - 1;
+  double* b_ob = reinterpret_cast<double*>(smem);       // branch table, by turn
+  double* b_ol = b_ob + W;
+  double* b_ot = b_ol + W;
+  double* b_ot0 = b_ot + W;                              // old total before any reset
+  double* b_nb = b_ot0 + W;
+  double* b_nl = b_nb + W;
+  double* b_nt = b_nl + W;
+  double* h_nt = b_nt + W;                               // the beam between the phases
+  double* inp = h_nt + W;                                // [72]
+  int* b_node = reinterpret_cast<int*>(inp + 72);
+  int* b_par = b_node + W;
+  int* b_pt = b_par + W;                                 // parent's turn or -1
+  int* b_child = b_pt + W;                               // child block or -1
+  int* b_nkids = b_child + W;                            // children that are branches themselves
+  int* b_evicted = b_nkids + W;
+  int* h_ord = b_evicted + W;
+  int* h_tag = h_ord + W;                                // >= 0: branch turn; else -(parent + 2)
+  int* kidq = h_tag + W;                                 // [64]
+  int* s_misc = kidq + 64;                               // nb, nblocks, hn
+
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  Rec* rec = reinterpret_cast<Rec*>(p.ws + (size_t)n * p.ws_per_utt);
+  int* block_parent = reinterpret_cast<int*>(rec + (1 + (size_t)p.max_blocks * K));
+  int Tn = p.seq_len[n];
+  Tn = Tn < 0 ? 0 : (Tn > p.T ? p.T : Tn);
+
+  if (tid == 0) {
+    // the root: total 0, blank path 0, no label path (decode_host.cpp: beam_one)
+    b_node[0] = 0; b_par[0] = -1;
+    b_ob[0] = 0.0; b_ol[0] = neg_inf(); b_ot[0] = 0.0; b_ot0[0] = 0.0;
+    b_evicted[0] = 0; b_nkids[0] = 0;
+    rec[0] = Rec{-1, 0};
+    s_misc[0] = 1; s_misc[1] = 0; s_misc[2] = 1;
+  }
+  float xnext = (tid < C && Tn > 0) ? p.logits[(size_t)n * C + tid] : 0.f;
+  __syncthreads();
+
+  for (int t = 0; t < Tn; ++t) {
+    // ---- the frame's scores: max-subtracted logits, no log-softmax
+    if (wave == 0) {
+      const float x = lane < C ? xnext : asr_neg_inf();
+      const float mx = asr_wave_max(x);
+      if (lane < C) inp[lane] = (double)x - (double)mx;
+    }
+    if (t + 1 < Tn && tid < C) xnext = p.logits[((size_t)(t + 1) * p.n_pad + n) * C + tid];
+    __syncthreads();
+    const int nb = s_misc[0];
+
+    // ---- phase B: every branch takes the frame (label path fed from the parent if the
+    //      parent is still in the beam)
+    for (int q = tid; q < nb; q += kThreads) {
+      const int node = b_node[q], par = b_par[q];
+      b_child[q] = rec[node].children;
+      int pt = -1;
+      double nl = b_ol[q];
+      if (par >= 0) {
+        const int label = (node - 1) % K;
+        pt = rec[par].turn;
+        if (pt >= 0) {
+          const int plabel = par == 0 ? -1 : (par - 1) % K;
+          nl = lse(nl, label == plabel ? b_ob[pt] : b_ot[pt]);
+          atomicAdd(&b_nkids[pt], 1);
+        }
+        nl += inp[label];
+      }
+      b_pt[q] = pt;
+      const double nbk = b_ot[q] + inp[blank];
+      b_nb[q] = nbk;
+      b_nl[q] = nl;
+      b_nt[q] = lse(nbk, nl);
+    }
+    __syncthreads();
+
+    // ---- phase C: rank the new totals -> the beam array (total descending, id ascending)
+    for (int q = tid; q < nb; q += kThreads) {
+      const double nt = b_nt[q];
+      const int node = b_node[q];
+      int r = 0;
+      for (int j = 0; j < nb; ++j) {
+        const double o = b_nt[j];
+        r += (o > nt || (o == nt && b_node[j] < node)) ? 1 : 0;
+      }
+      h_nt[r] = nt; h_ord[r] = node; h_tag[r] = q;
+    }
+    __syncthreads();
+
+    // ---- phase D: the branches' turns, wave 0, beam in registers
+    if (wave == 0) {
+      double nt[E];
+      int ord[E], tag[E];
+      int hn = nb, nblk = s_misc[1];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = e * 64 + lane;
+        const bool in = j < hn;
+        nt[e] = in ? h_nt[j] : neg_inf();
+        ord[e] = in ? h_ord[j] : INT_MAX;
+        tag[e] = in ? h_tag[j] : -1;
+      }
+      const int eb = (W - 1) >> 6, lb = (W - 1) & 63;      // where the bottom of a full beam sits
+      for (int r = 0; r < nb; ++r) {
+        bool full = hn == W;
+        double theta = neg_inf();
+        if (full) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) if (e == eb) theta = readlane_d(nt[e], lb);
+        }
+        if (full && !(b_ot0[r] > theta)) break;
+        const double ot = b_ot[r];
+        if (!(ot > neg_inf() && (!full || ot > theta))) continue;
+        const double ob = b_ob[r];
+        const int node = b_node[r];
+        int blk = b_child[r];
+        if (blk < 0) {                                     // first expansion: a block of ids
+          blk = nblk++;
+          if (lane == 0) { block_parent[blk] = node; rec[node].children = blk; }
+          if (lane < K) rec[1 + (size_t)blk * K + lane] = Rec{-1, -1};
+        }
+        const int base = 1 + blk * K;
+        const int blabel = node == 0 ? -1 : (node - 1) % K;
+        int q = -1;                                        // the child if it is a branch itself
+        if (b_nkids[r] > 0) {
+          kidq[lane] = -1;
+          wave_sync();
+          for (int j = lane; j < nb; j += 64)
+            if (b_pt[j] == r) kidq[(b_node[j] - 1) % K] = j;
+          wave_sync();
+          q = kidq[lane];
+        }
+        const double prev = lane == blabel ? ob : ot;
+        const double v = (lane < K && prev != neg_inf()) ? inp[lane] + prev : neg_inf();
+        unsigned long long undecided = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
+        while (undecided) {
+          full = hn == W;
+          theta = neg_inf();
+          if (full) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (e == eb) theta = readlane_d(nt[e], lb);
+          }
+          const bool mine = (undecided >> lane) & 1ull;
+          const bool active = q >= 0 && b_evicted[q] == 0;
+          const bool cand = mine && !active && v > neg_inf() && (!full || v > theta);
+          const bool rej = mine && !active && !cand;
+          // TF resets a rejected child's OLD probabilities too: if it is a branch of this
+          // frame (evicted a moment ago) it must not expand when its turn comes
+          if (rej && q >= 0) { b_ob[q] = neg_inf(); b_ol[q] = neg_inf(); b_ot[q] = neg_inf(); }
+          const unsigned long long m = __ballot(cand);
+          undecided &= ~__ballot(rej);
+          if (!m) break;
+          const int cs = __ffsll((long long)m) - 1;
+          undecided &= ~((2ull << cs) - 1ull);             // cs inserted, lower labels decided
+          const double vs = readlane_d(v, cs);
+          const int id = base + cs;
+          if (full) {                                      // evict the bottom
+            int rb = -1;
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (e == eb) rb = readlane_i(tag[e], lb);
+            if (rb >= 0 && lane == 0) b_evicted[rb] = 1;
+            hn = W - 1;
+          }
+          int pos = 0;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int j = e * 64 + lane;
+            const bool better = j < hn && (nt[e] > vs || (nt[e] == vs && ord[e] < id));
+            pos += __popcll(__ballot(better));
+          }
+#pragma unroll
+          for (int e = E - 1; e >= 0; --e) {
+            const int j = e * 64 + lane;
+            const double cn = e > 0 ? readlane_d(nt[e > 0 ? e - 1 : 0], 63) : 0.0;
+            const int co = e > 0 ? readlane_i(ord[e > 0 ? e - 1 : 0], 63) : 0;
+            const int ct = e > 0 ? readlane_i(tag[e > 0 ? e - 1 : 0], 63) : 0;
+            const double pn = shr1_d<DPP>(nt[e], cn);
+            const int po = shr1_i<DPP>(ord[e], co);
+            const int pg = shr1_i<DPP>(tag[e], ct);
+            if (j > pos && j <= hn) { nt[e] = pn; ord[e] = po; tag[e] = pg; }
+            else if (j == pos) { nt[e] = vs; ord[e] = id; tag[e] = -(node + 2); }
+          }
+          ++hn;
+          wave_sync();
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = e * 64 + lane;
+        if (j < hn) { h_nt[j] = nt[e]; h_ord[j] = ord[e]; h_tag[j] = tag[e]; }
+      }
+      if (lane == 0) { s_misc[1] = nblk; s_misc[2] = hn; }
+    }
+    __syncthreads();
+
+    // ---- phase E: the beam is the next frame's branch table, in its sorted order
+    const int hn = s_misc[2];
+    double e_nt[4], e_nb[4], e_nl[4];
+    int e_node[4], e_par[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = tid + k * kThreads;
+      if (j < hn) {
+        const int g = h_tag[j];
+        e_nt[k] = h_nt[j];
+        e_node[k] = h_ord[j];
+        e_par[k] = g >= 0 ? b_par[g] : -(g + 2);
+        e_nb[k] = g >= 0 ? b_nb[g] : neg_inf();
+        e_nl[k] = g >= 0 ? b_nl[g] : e_nt[k];
+      }
+    }
+    for (int q = tid; q < nb; q += kThreads) rec[b_node[q]].turn = -1;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = tid + k * kThreads;
+      if (j < hn) {
+        b_node[j] = e_node[k]; b_par[j] = e_par[k];
+        b_ob[j] = e_nb[k]; b_ol[j] = e_nl[k]; b_ot[j] = e_nt[k]; b_ot0[j] = e_nt[k];
+        b_evicted[j] = 0; b_nkids[j] = 0;
+        rec[e_node[k]].turn = j;
+      }
+    }
+    if (tid == 0) s_misc[0] = hn;
+    __syncthreads();
+  }
+
+  // ---- the best leaf's label sequence (merge_repeated collapses consecutive repeats)
+  int* out = p.decoded + (size_t)n * p.T;
+  __shared__ int s_len;
+  if (tid == 0) {
+    const int best = b_node[0];
+    int L = 0, prev = -1;
+    for (int c = best; c != 0; c = block_parent[(c - 1) / K]) {
+      const int label = (c - 1) % K;
+      if (!p.merge || label != prev) ++L;
+      prev = label;
+    }
+    int w = L;
+    prev = -1;
+    for (int c = best; c != 0; c = block_parent[(c - 1) / K]) {
+      const int label = (c - 1) % K;
+      if (!p.merge || label != prev) out[--w] = label;
+      prev = label;
+    }
+    p.decoded_len[n] = L;
+    if (p.score) p.score[n] = (float)b_ot[0];
+    s_len = L;
+  }
+  __syncthreads();
+  for (int i = s_len + tid; i < p.T; i += kThreads) out[i] = -1;
+}
+
+typedef void (*beam_kern_t)(BeamParams);
+
+beam_kern_t pick(int W, bool dpp) {
+  if (W <= 128) return dpp ? ctc_beam_kernel<2, true> : ctc_beam_kernel<2, false>;
+  if (W <= 448) return dpp ? ctc_beam_kernel<7, true> : ctc_beam_kernel<7, false>;
+  return dpp ? ctc_beam_kernel<16, true> : ctc_beam_kernel<16, false>;
+}
+
+size_t ws_per_utt(int T, int C, int W, int* max_blocks) {
+  // a node expands for the first time at most once, a frame has at most W branches
+  const size_t blocks = (size_t)(T > 0 ? T : 1) * (size_t)W;
+  *max_blocks = (int)blocks;
+  return asr_align_up((1 + blocks * (size_t)(C - 1)) * sizeof(Rec) + blocks * sizeof(int), 256);
+}
+
+}  // namespace
+
+extern "C" size_t asr_ctc_beam_device_workspace_bytes(int T, int N, int C, int beam_width) {
+  if (T < 0 || N <= 0 || C < 2 || beam_width < 1) return 0;
+  int mb;
+  return ws_per_utt(T, C, beam_width, &mb) * (size_t)N;
+}
+
+extern "C" int asr_ctc_beam_device(const float* logits, const int* seq_len, int T, int N, int n_pad,
+                                   int C, int beam_width, int merge_repeated, int* decoded,
+                                   int* decoded_len, float* log_score, void* workspace,
+                                   size_t ws_bytes, asr_stream_t stream) {
+  ASR_CHECK_ARG(logits && seq_len && decoded && decoded_len && workspace, "beam: null pointer");
+  ASR_CHECK_ARG(T > 0 && N > 0 && n_pad >= N && C >= 2, "beam: bad shape");
+  ASR_CHECK_ARG(C <= kMaxC, "beam: at most %d classes", kMaxC);
+  ASR_CHECK_ARG(beam_width >= 1 && beam_width <= 1024, "beam: width must be 1 .. 1024");
+  ASR_CHECK_ARG((size_t)T * (size_t)beam_width * (size_t)(C - 1) < (size_t)INT_MAX,
+                "beam: T * width * labels overflows the node ids");
+  BeamParams p;
+  p.logits = logits; p.seq_len = seq_len; p.T = T; p.n_pad = n_pad; p.C = C; p.W = beam_width;
+  p.merge = merge_repeated ? 1 : 0;
+  p.decoded = decoded; p.decoded_len = decoded_len; p.score = log_score;
+  p.ws = reinterpret_cast<char*>(workspace);
+  p.ws_per_utt = ws_per_utt(T, C, beam_width, &p.max_blocks);
+  ASR_CHECK_ARG(ws_bytes >= p.ws_per_utt * (size_t)N, "beam: workspace too small");
+  static const int use_shfl = [] { const char* v = getenv("ASR_BEAM_SHFL"); return v && *v == '1'; }();
+  beam_kern_t k = pick(beam_width, !use_shfl);
+  const size_t shm = lds_bytes(beam_width);
+  if (shm > 64 * 1024)
+    ASR_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)shm));
+  hipLaunchKernelGGL(k, dim3(N), dim3(kThreads), shm, (hipStream_t)stream, p);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}

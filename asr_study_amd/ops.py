@@ -287,6 +287,30 @@ def ctc_greedy(logits, seq_len, N):
     return dec, dlen
 
 
+def ctc_beam_search(logits, seq_len, N, beam_width=100, merge_repeated=True):
+    """K9 on the device: logits (T, n_pad, C) float32 and seq_len (N,) int32 DEVICE tensors ->
+    (decoded (N, T) int32 padded with -1, decoded_len (N,), log_score (N,)) device tensors; same
+    results as ctc_beam_search_host (asr_ctc_beam_device).  The prefix-tree workspace is sized
+    for the hard bound (T * width child blocks per utterance) and is not initialised."""
+    lib = L.load()
+    T, n_pad, Cc = logits.shape
+    _check_f32(logits)
+    dev = logits.device
+    dec = torch.empty((int(N), T), dtype=torch.int32, device=dev)
+    dlen = torch.empty(int(N), dtype=torch.int32, device=dev)
+    score = torch.empty(int(N), dtype=torch.float32, device=dev)
+    nbytes = lib.asr_ctc_beam_device_workspace_bytes(T, int(N), Cc, int(beam_width))
+    key = ('beam', str(dev))
+    ws = WS.bufs.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = WS.bufs[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+    L.check(lib.asr_ctc_beam_device(_ptr(logits), _ptr(seq_len), T, int(N), n_pad, Cc,
+                                    int(beam_width), int(bool(merge_repeated)), _ptr(dec),
+                                    _ptr(dlen), _ptr(score), _ptr(ws), nbytes, _stream()),
+            'asr_ctc_beam_device')
+    return dec, dlen, score
+
+
 def ctc_beam_search_host(logits_host, seq_len_host, N, beam_width=100, merge_repeated=True):
     """logits_host: (T, n_pad, C) float32 numpy array (already on the host)."""
     lib = L.load()

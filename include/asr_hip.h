@@ -313,6 +313,16 @@ int asr_ctc_beam_search_host(const float* logits_host, const int* seq_len_host,
                              int merge_repeated, int* decoded, int* decoded_len,
                              float* log_score);
 
+/* K9  Beam search on the device (same algorithm, arithmetic and tie-breaking as the host    */
+/* form; logits (T, n_pad, C) and seq_len are DEVICE pointers, as asr_ctc_greedy takes them;  */
+/* decoded (N, T) int32 padded with -1, decoded_len (N), log_score (N) or NULL: device).     */
+/* One workgroup per utterance; C <= 64, beam_width <= 1024.  The workspace holds the prefix  */
+/* tree (its size is the hard bound T * beam_width child blocks per utterance; no init).      */
+size_t asr_ctc_beam_device_workspace_bytes(int T, int N, int C, int beam_width);
+int asr_ctc_beam_device(const float* logits, const int* seq_len, int T, int N, int n_pad, int C,
+                        int beam_width, int merge_repeated, int* decoded, int* decoded_len,
+                        float* log_score, void* workspace, size_t ws_bytes, asr_stream_t stream);
+
 /* K10 Edit distance (host).  Replaces core/metrics.py:8 -> tf.edit_distance */
 /* (normalize=True).  Ragged inputs as (N, max) padded + lengths.            */
 int asr_edit_distance_host(const int* hyp, const int* hyp_len, int hyp_ld,
