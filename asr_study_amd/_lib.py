@@ -149,6 +149,8 @@ SIGNATURES = {
     'asr_ctc_beam_device': (C.c_int, [void_p, void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, void_p, void_p, void_p, void_p,
                                       C.c_size_t, void_p]),
+    'asr_ctc_beam_device_counters': (C.c_int, [void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, void_p, void_p]),
     'asr_edit_distance_host': (C.c_int, [void_p, void_p, C.c_int, void_p, void_p, C.c_int,
                                          C.c_int, void_p]),
     'asr_optim_workspace_bytes': (C.c_size_t, [C.c_int64]),

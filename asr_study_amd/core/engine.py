@@ -1191,11 +1191,13 @@ class Model(object):
 
     def _beam(self, logits, seq_len_dev, N):
         """core/ctc_utils.py:48-50 on the device (K9): the logits stay in HBM; only the decoded
-        labels are copied back.  Widths beyond the kernel's 1024 (or > 64 classes) use the
-        library's host decoder (decode_host.cpp) on a copy of the logits."""
+        labels are copied back.  Widths beyond the kernel's 1024 (or > 64 classes), or
+        ASR_BEAM=host, use the library's host decoder (decode_host.cpp: one utterance per host
+        thread) on a copy of the logits -- same strings either way."""
         width = int(self.decoder.get('beam_width', 100))
         merge = self.decoder.get('merge_repeated', True)
-        if width <= 1024 and logits.shape[2] <= 64:
+        import os as _os
+        if width <= 1024 and logits.shape[2] <= 64 and _os.environ.get('ASR_BEAM', 'device') != 'host':
             dec, dlen, _ = ops.ctc_beam_search(logits, seq_len_dev, N, width, merge)
             return dec, dlen
         lens = seq_len_dev.cpu().numpy()

@@ -311,6 +311,20 @@ def ctc_beam_search(logits, seq_len, N, beam_width=100, merge_repeated=True):
     return dec, dlen, score
 
 
+def ctc_beam_counters(logits_shape, N, beam_width, utterance=0, device='cuda:0'):
+    """Work counters of the last ctc_beam_search call of that shape (see
+    asr_ctc_beam_device_counters): dict of seconds per phase and event counts."""
+    lib = L.load()
+    T, n_pad, Cc = logits_shape
+    ws = WS.bufs[('beam', str(torch.device(device)))]
+    out = (C.c_longlong * 7)()
+    L.check(lib.asr_ctc_beam_device_counters(_ptr(ws), int(T), int(N), int(Cc), int(beam_width),
+                                             int(utterance), out, _stream()),
+            'asr_ctc_beam_device_counters')
+    return dict(update_s=out[0] * 1e-8, rank_s=out[1] * 1e-8, turns_s=out[2] * 1e-8,
+                handover_s=out[3] * 1e-8, turns=out[4], insertions=out[5], blocks=out[6])
+
+
 def ctc_beam_search_host(logits_host, seq_len_host, N, beam_width=100, merge_repeated=True):
     """logits_host: (T, n_pad, C) float32 numpy array (already on the host)."""
     lib = L.load()

@@ -323,6 +323,12 @@ int asr_ctc_beam_device(const float* logits, const int* seq_len, int T, int N, i
                         int beam_width, int merge_repeated, int* decoded, int* decoded_len,
                         float* log_score, void* workspace, size_t ws_bytes, asr_stream_t stream);
 
+/* Work counters of one utterance of the LAST asr_ctc_beam_device call on this workspace     */
+/* (synchronises the stream): out7 = 100 MHz ticks in the four phases of a frame (branch      */
+/* update, ranking, turns, hand-over), expanding turns, insertions, child blocks allocated.   */
+int asr_ctc_beam_device_counters(const void* workspace, int T, int N, int C, int beam_width,
+                                 int utterance, long long* out7, asr_stream_t stream);
+
 /* K10 Edit distance (host).  Replaces core/metrics.py:8 -> tf.edit_distance */
 /* (normalize=True).  Ragged inputs as (N, max) padded + lengths.            */
 int asr_edit_distance_host(const int* hyp, const int* hyp_len, int hyp_ld,

@@ -95,6 +95,7 @@ def test_device_beam_full_length_width_400_and_timing():
         th = time.time() - t1
         print('[beam] width %d, 64 x 999 frames: device %.3f s, host decoder %.3f s (%d threads)'
               % (W, dt, th, min(64, os.cpu_count() or 1)))
+        print('[beam]   utterance 0:', ops.ctc_beam_counters(logits.shape, 64, W, 0, logits.device))
         d = dec.cpu().numpy()
         assert (d[:4] == d[4:8]).all()
 
