@@ -1127,33 +1127,46 @@ gemm_hl256_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int sp
   HlLoader256 la, lb;
   la.init(A, m0, k_begin, k_end);
   lb.init(B, n0, k_begin, k_end);
-  // one register set: the loads of slab kt+1 are issued before slab kt is multiplied and
-  // written to the other LDS buffer after it (48 MFMAs per wave = their latency cover)
+  // One register set, two slabs ahead: at the top of step kt the registers hold slab kt+1
+  // (issued a whole step earlier, so it has landed); it is written to the LDS buffer the
+  // barrier at the end of step kt-1 released, and the loads of slab kt+2 are issued at once --
+  // they fly across this step's 48 MFMAs per wave AND its barrier (plain buffer loads, no
+  // vmcnt wait at the barrier).  The scheduling fence keeps the compiler from sinking the
+  // loads to their use, which would expose the whole L2/HBM latency every step.
   u32x4g ah[2], al[2], bh[2], bl[2];
   const int nk = (k_end - k_begin + HBK - 1) / HBK;
   la.load(0, ah, al);
   lb.load(0, bh, bl);
   HlLoader256::store(ah, al, plane(0, 0), plane(0, 1));
   HlLoader256::store(bh, bl, plane(0, 2), plane(0, 3));
+  la.load(1, ah, al);
+  lb.load(1, bh, bl);
   __syncthreads();
   const int lrow = lane & 31, lhalf = lane >> 5;
+  // Ping-pong: a step is four phases -- read the fragments of one 16-deep half (plus, in the
+  // first, the LDS writes of the next slab and the loads of the one after), 24 MFMAs on them,
+  // and again for the other half -- each closed by a workgroup barrier.  The second row of
+  // waves (wm = 1; waves w and w+4 share a SIMD) runs ONE BARRIER LATE, so on every SIMD one
+  // wave multiplies while the other reads: the matrix pipe no longer idles through the LDS
+  // round trips of two waves in lockstep.  Buffer hazards with the one-phase lag: a slab's
+  // buffer is last read three phases (>= one barrier) before either row rewrites it, and is
+  // first read three phases after the later row wrote it.
+  if (wm == 1) __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
-    // past the last slab every offset is out of range: those loads return zeros, unused
-    la.load(kt + 1, ah, al);
-    lb.load(kt + 1, bh, bl);
     const _Float16* Ah = plane(cur, 0);
     const _Float16* Al = plane(cur, 1);
     const _Float16* Bh = plane(cur, 2);
     const _Float16* Bl = plane(cur, 3);
+    hx8 fah[4], fal[4], fbh[2], fbl[2];
 #pragma unroll
     for (int ks = 0; ks < HBK / 16; ++ks) {
-      hx8 fah[4], fal[4], fbh[2], fbl[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int slot = hl256_slot(wm * 128 + i * 32 + lrow, 2 * ks + lhalf);
-        fah[i] = *reinterpret_cast<const hx8*>(Ah + slot);
-        fal[i] = *reinterpret_cast<const hx8*>(Al + slot);
+      if (ks == 0) {
+        HlLoader256::store(ah, al, plane(nxt, 0), plane(nxt, 1));
+        HlLoader256::store(bh, bl, plane(nxt, 2), plane(nxt, 3));
+        // past the last slab every offset is out of range: those loads return zeros, unused
+        la.load(kt + 2, ah, al);
+        lb.load(kt + 2, bh, bl);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -1161,6 +1174,16 @@ gemm_hl256_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int sp
         fbh[j] = *reinterpret_cast<const hx8*>(Bh + slot);
         fbl[j] = *reinterpret_cast<const hx8*>(Bl + slot);
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int slot = hl256_slot(wm * 128 + i * 32 + lrow, 2 * ks + lhalf);
+        fah[i] = *reinterpret_cast<const hx8*>(Ah + slot);
+        fal[i] = *reinterpret_cast<const hx8*>(Al + slot);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
       // term-major order: consecutive MFMAs go to eight different accumulators
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1177,11 +1200,13 @@ gemm_hl256_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int sp
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], am[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
     }
-    HlLoader256::store(ah, al, plane(nxt, 0), plane(nxt, 1));
-    HlLoader256::store(bh, bl, plane(nxt, 2), plane(nxt, 3));
-    __syncthreads();
   }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
   const float unscale = 1.f / (sa * sb);
   const int lcol = lane & 31;
   const bool interior = m0 + TM2 <= M && n0 + TN2 <= N;
