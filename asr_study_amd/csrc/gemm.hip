@@ -785,7 +785,7 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
 //   "r" planes (rows, ldk_r): K = the source's columns  (A of x@W, A of dz@W^T)
 //   "c" planes (cols, ldk_c): K = the source's rows     (both operands of the weight
 //                                                         gradients x^T dz and h^T dz)
-// rows of a plane are ldk halfs long (ldk % 32 == 0, zero padded).  gemm_hl_kernel is then a
+// rows of a plane are ldk halfs long (ldk % 32 == 0, zero padded).  gemm_hlx_kernel is then a
 // plain fp16 GEMM with three MFMAs per fragment pair and fp32 accumulation: 16-byte global
 // loads -> ds_write_b128 -> ds_read_b128 -> v_mfma_f32_32x32x16_f16, no VALU in the K loop
 // besides addresses.  Tile / LDS image / epilogue are those of the fast kernel.
@@ -870,180 +870,8 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
 
 // One operand's share of a K slab: 128 rows x 32 halfs per plane = 512 16-byte chunks;
 // thread t takes chunks t and t + 256 (row = chunk >> 2, k chunk = chunk & 3) of both planes.
-struct HlLoader {
-  __amdgpu_buffer_rsrc_t rh, rl;
-  unsigned off[2];                 // byte offsets at k_begin (kOob for rows outside)
-  int kq[2];                       // first k of the chunk relative to the slab
-  int k_begin, k_end;
-  __device__ __forceinline__ void init(const HlSrc& s, int row0, int kb, int ke) {
-    const int tid = threadIdx.x;
-    rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.hi), 0, s.extent, 0x00020000);
-    rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.lo), 0, s.extent, 0x00020000);
-    k_begin = kb; k_end = ke;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ch = tid + 256 * i;
-      const int row = row0 + (ch >> 2);
-      kq[i] = 8 * (ch & 3);
-      off[i] = row < s.rows ? (unsigned)(((size_t)row * s.ld + kb + kq[i]) * 2) : kOob;
-    }
-  }
-  __device__ __forceinline__ void load(int kt, u32x4g (&h)[2], u32x4g (&l)[2]) const {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool ok = k_begin + kt * HBK + kq[i] < k_end && off[i] != kOob;
-      const unsigned o = ok ? off[i] + (unsigned)(kt * HBK * 2) : kOob;
-      h[i] = __builtin_amdgcn_raw_buffer_load_b128(rh, o, 0, 0);
-      l[i] = __builtin_amdgcn_raw_buffer_load_b128(rl, o, 0, 0);
-    }
-  }
-  __device__ __forceinline__ static void store(const u32x4g (&h)[2], const u32x4g (&l)[2],
-                                               _Float16 (*Shi)[HLD], _Float16 (*Slo)[HLD]) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ch = tid + 256 * i;
-      *reinterpret_cast<u32x4g*>(&Shi[ch >> 2][8 * (ch & 3)]) = h[i];
-      *reinterpret_cast<u32x4g*>(&Slo[ch >> 2][8 * (ch & 3)]) = l[i];
-    }
-  }
-};
-
-__global__ void __launch_bounds__(256)
-gemm_hl_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int splits, Epilogue ep,
-               const float* __restrict__ a_scale, const float* __restrict__ b_scale) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
-  // [buf 2][A_hi, A_lo, B_hi, B_lo][128][HLD]
-  auto tile = [&](int buf, int which) {
-    return reinterpret_cast<_Float16 (*)[HLD]>(hsm + ((size_t)(buf * 4 + which) * 128) * HLD);
-  };
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const TileId tb = tile_of_block((M + BM - 1) / BM, (N + BN - 1) / BN, splits);
-  const int m0 = tb.tm * BM, n0 = tb.tn * BN;
-  const int k_begin = tb.z * k_per_split;
-  int k_end = k_begin + k_per_split;
-  if (k_end > K) k_end = K;
-  const float sa = a_scale ? *a_scale : 1.f, sb = b_scale ? *b_scale : 1.f;
-
-  f32x16 am[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) am[i][j][e] = 0.f;
-
-  HlLoader la, lb;
-  la.init(A, m0, k_begin, k_end);
-  lb.init(B, n0, k_begin, k_end);
-  // two register sets: slab kt is multiplied out of LDS while slab kt+1 (loaded an iteration
-  // ago) is written into the other LDS buffer and the loads of slab kt+2 are in flight
-  u32x4g ah0[2], al0[2], bh0[2], bl0[2], ah1[2], al1[2], bh1[2], bl1[2];
-  const int nk = (k_end - k_begin + HBK - 1) / HBK;
-  la.load(0, ah0, al0);
-  lb.load(0, bh0, bl0);
-  la.load(1, ah1, al1);
-  lb.load(1, bh1, bl1);
-  HlLoader::store(ah0, al0, tile(0, 0), tile(0, 1));
-  HlLoader::store(bh0, bl0, tile(0, 2), tile(0, 3));
-  __syncthreads();
-  const int lrow = lane & 31, lk = 8 * (lane >> 5);
-  auto slab = [&](int kt, u32x4g (&lah)[2], u32x4g (&lal)[2], u32x4g (&lbh)[2],
-                  u32x4g (&lbl)[2], u32x4g (&sah)[2], u32x4g (&sal)[2], u32x4g (&sbh)[2],
-                  u32x4g (&sbl)[2]) {
-    const int cur = kt & 1, nxt = cur ^ 1;
-    // past the last slab every offset is out of range: those loads return zeros, unused
-    la.load(kt + 2, lah, lal);
-    lb.load(kt + 2, lbh, lbl);
-    _Float16 (*Ah)[HLD] = tile(cur, 0);
-    _Float16 (*Al)[HLD] = tile(cur, 1);
-    _Float16 (*Bh)[HLD] = tile(cur, 2);
-    _Float16 (*Bl)[HLD] = tile(cur, 3);
-#pragma unroll
-    for (int ks = 0; ks < HBK / 16; ++ks) {
-      hx8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const hx8*>(&Ah[wm * 64 + i * 32 + lrow][16 * ks + lk]);
-        al[i] = *reinterpret_cast<const hx8*>(&Al[wm * 64 + i * 32 + lrow][16 * ks + lk]);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bh[j] = *reinterpret_cast<const hx8*>(&Bh[wn * 64 + j * 32 + lrow][16 * ks + lk]);
-        bl[j] = *reinterpret_cast<const hx8*>(&Bl[wn * 64 + j * 32 + lrow][16 * ks + lk]);
-      }
-      // term-major order: consecutive MFMAs go to four different accumulators
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], am[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], am[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], am[i][j], 0, 0, 0);
-    }
-    HlLoader::store(sah, sal, tile(nxt, 0), tile(nxt, 1));
-    HlLoader::store(sbh, sbl, tile(nxt, 2), tile(nxt, 3));
-    __syncthreads();
-  };
-  for (int kt = 0; kt < nk; kt += 2) {
-    slab(kt, ah0, al0, bh0, bl0, ah1, al1, bh1, bl1);     // loads kt+2 -> set 0, stores set 1
-    if (kt + 1 < nk) slab(kt + 1, ah1, al1, bh1, bl1, ah0, al0, bh0, bl0);
-  }
-  const float unscale = 1.f / (sa * sb);
-  const int lcol = lane & 31, lhalf = lane >> 5;
-  const bool interior = m0 + BM <= M && n0 + BN <= N;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + lcol;
-      const int row0 = m0 + wm * 64 + i * 32 + 4 * lhalf;
-      if (!interior && col >= N) continue;
-      if (ep.partial) {
-        float* dst = ep.partial + ((size_t)tb.z * M + row0) * N + col;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int dr = (e & 3) + 8 * (e >> 2);
-          if (interior || row0 + dr < M) dst[(size_t)dr * N] = am[i][j][e] * unscale;
-        }
-        continue;
-      }
-      float* dst = ep.C + (size_t)row0 * ep.ldc + col;
-      const float bias = ep.bias ? ep.bias[col] : 0.f;
-      float old[16], msk[16];
-      const bool use_old = ep.beta != 0.f;
-      const bool use_msk = ep.c_scale != nullptr;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int dr = (e & 3) + 8 * (e >> 2);
-        const bool ok = interior || row0 + dr < M;
-        old[e] = (use_old && ok) ? dst[(size_t)dr * ep.ldc] : 0.f;
-        msk[e] = (use_msk && ok)
-            ? ep.c_scale[(size_t)mod_period(row0 + dr, ep.c_period) * ep.c_ld + col] : 1.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int dr = (e & 3) + 8 * (e >> 2);
-        if (!(interior || row0 + dr < M)) continue;
-        const float v = (am[i][j][e] * unscale * ep.alpha + bias) * msk[e];
-        dst[(size_t)dr * ep.ldc] = use_old ? v + ep.beta * old[e] : v;
-      }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// 256 x 256 x 32 tile variant of gemm_hl_kernel (the default for outputs of at least 256 x 256).
+// The packed-plane kernel.  256 x 256 x 32 tile by default (outputs of at least 256 x 256).
 // With 128 x 128 tiles both split-fp16 GEMMs sit at ~250 TF/s algorithmic whatever the K loop
 // costs: a workgroup moves 32 KB from L2 per 1 MFLOP (32 flop/B), i.e. ~7.5 TB/s at that
 // rate, with an L2 hit rate of ~72 % -- the loop is fed at the L2 / fabric rate.  A 256 x 256
@@ -1052,13 +880,13 @@ gemm_hl_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int split
 // (64-byte rows; 4 planes x 2 buffers = 128 KB) with the 16-byte chunk index XOR-swizzled by
 // (row >> 2) & 3, which makes both the ds_write_b128 of the staging pass and the ds_read_b128
 // of the fragments bank-conflict free (lane groups of MI355X_MICROARCH.md "LDS").
-constexpr int TM2 = 256, TN2 = 256;
 
 __device__ __forceinline__ int hl256_slot(int row, int kc) {      // half index in a plane
   return row * 32 + ((kc ^ ((row >> 2) & 3)) << 3);
 }
 
-struct HlLoader256 {
+template <int NT>
+struct HlLoaderX {
   __amdgpu_buffer_rsrc_t rh, rl;
   unsigned off[2];
   int kq[2];
@@ -1070,7 +898,7 @@ struct HlLoader256 {
     k_begin = kb; k_end = ke;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ch = tid + 512 * i;                // 256 rows x 4 chunks
+      const int ch = tid + NT * i;                 // (2 NT / 4) rows x 4 chunks
       const int row = row0 + (ch >> 2);
       kq[i] = 8 * (ch & 3);
       off[i] = row < s.rows ? (unsigned)(((size_t)row * s.ld + kb + kq[i]) * 2) : kOob;
@@ -1090,7 +918,7 @@ struct HlLoader256 {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ch = tid + 512 * i;
+      const int ch = tid + NT * i;
       const int slot = hl256_slot(ch >> 2, ch & 3);
       *reinterpret_cast<u32x4g*>(Shi + slot) = h[i];
       *reinterpret_cast<u32x4g*>(Slo + slot) = l[i];
@@ -1098,17 +926,26 @@ struct HlLoader256 {
   }
 };
 
-__global__ void __launch_bounds__(512)
-gemm_hl256_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int splits,
-                  Epilogue ep, const float* __restrict__ a_scale,
-                  const float* __restrict__ b_scale) {
+// WN waves across the columns (2 rows of waves), MI x NJ 32 x 32 MFMA tiles per wave: the
+// square tile is 64 MI = 32 NJ WN wide and every thread stages two 16-byte chunks per plane.
+//   <4, 4, 2>: 256 x 256, 512 threads, 128 KB LDS -- the main kernel;
+//   <2, 2, 2>: 128 x 128, 256 threads,  64 KB LDS -- small outputs, and the one that fits on a
+//              CU BESIDE a recurrent workgroup (96 KB + 64 KB of LDS, 2 + 1 waves per SIMD).
+template <int WN, int MI, int NJ>
+__global__ void __launch_bounds__(128 * WN)
+gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int splits,
+                Epilogue ep, const float* __restrict__ a_scale,
+                const float* __restrict__ b_scale) {
+  constexpr int NT = 128 * WN, TM2 = 64 * MI, TN2 = 32 * NJ * WN;
+  static_assert(TM2 == TN2 && TM2 * 4 == 2 * NT, "square tile, two chunks per thread and plane");
+  using HlLoader256 = HlLoaderX<NT>;
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
-  constexpr int kPlane = 256 * 32;                   // halfs per plane
+  constexpr int kPlane = TM2 * 32;                   // halfs per plane
   auto plane = [&](int buf, int which) { return hsm + (size_t)(buf * 4 + which) * kPlane; };
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;           // 2 x 4 waves, 128 x 64 each
+  const int wm = wave / WN, wn = wave % WN;          // 2 x WN waves, (32 MI) x (32 NJ) each
   const TileId tb = tile_of_block((M + TM2 - 1) / TM2, (N + TN2 - 1) / TN2, splits);
   const int m0 = tb.tm * TM2, n0 = tb.tn * TN2;
   const int k_begin = tb.z * k_per_split;
@@ -1116,11 +953,11 @@ gemm_hl256_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int sp
   if (k_end > K) k_end = K;
   const float sa = a_scale ? *a_scale : 1.f, sb = b_scale ? *b_scale : 1.f;
 
-  f32x16 am[4][2];
+  f32x16 am[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) am[i][j][e] = 0.f;
 
@@ -1158,7 +995,7 @@ gemm_hl256_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int sp
     const _Float16* Al = plane(cur, 1);
     const _Float16* Bh = plane(cur, 2);
     const _Float16* Bl = plane(cur, 3);
-    hx8 fah[4], fal[4], fbh[2], fbl[2];
+    hx8 fah[MI], fal[MI], fbh[NJ], fbl[NJ];
 #pragma unroll
     for (int ks = 0; ks < HBK / 16; ++ks) {
       if (ks == 0) {
@@ -1169,14 +1006,14 @@ gemm_hl256_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int sp
         lb.load(kt + 2, bh, bl);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int slot = hl256_slot(wn * 64 + j * 32 + lrow, 2 * ks + lhalf);
+      for (int j = 0; j < NJ; ++j) {
+        const int slot = hl256_slot(wn * (32 * NJ) + j * 32 + lrow, 2 * ks + lhalf);
         fbh[j] = *reinterpret_cast<const hx8*>(Bh + slot);
         fbl[j] = *reinterpret_cast<const hx8*>(Bl + slot);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int slot = hl256_slot(wm * 128 + i * 32 + lrow, 2 * ks + lhalf);
+      for (int i = 0; i < MI; ++i) {
+        const int slot = hl256_slot(wm * (32 * MI) + i * 32 + lrow, 2 * ks + lhalf);
         fah[i] = *reinterpret_cast<const hx8*>(Ah + slot);
         fal[i] = *reinterpret_cast<const hx8*>(Al + slot);
       }
@@ -1186,19 +1023,19 @@ gemm_hl256_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int sp
       __builtin_amdgcn_s_setprio(1);
       // term-major order: consecutive MFMAs go to eight different accumulators
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh[j], am[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], am[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], am[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -1211,11 +1048,11 @@ gemm_hl256_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int sp
   const int lcol = lane & 31;
   const bool interior = m0 + TM2 <= M && n0 + TN2 <= N;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + lcol;
-      const int row0 = m0 + wm * 128 + i * 32 + 4 * lhalf;
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn * (32 * NJ) + j * 32 + lcol;
+      const int row0 = m0 + wm * (32 * MI) + i * 32 + 4 * lhalf;
       if (!interior && col >= N) continue;
       if (ep.partial) {
         float* dst = ep.partial + ((size_t)tb.z * M + row0) * N + col;
@@ -1569,31 +1406,25 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
   A.ld = a->lda; A.rows = a->M; A.extent = (unsigned)ext_a;
   B.hi = reinterpret_cast<const _Float16*>(a->b_hi); B.lo = reinterpret_cast<const _Float16*>(a->b_lo);
   B.ld = a->ldb; B.rows = a->N; B.extent = (unsigned)ext_b;
-  const size_t shm = (size_t)2 * 4 * 128 * HLD * sizeof(_Float16);
-  static bool attr_done = false;
-  if (!attr_done) {
-    ASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hl_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    attr_done = true;
-  }
   // tile: 256 x 256 (512 threads, 128 KB LDS) for outputs of at least that size, else 128 x 128
-  // (ASR_GEMM_HL_TILE=128 forces the small tile)
+  // (256 threads, 64 KB; asr_gemm_hl_args.tile = 128 or ASR_GEMM_HL_TILE=128 force it)
   static const int tile_env = [] { const char* v = getenv("ASR_GEMM_HL_TILE"); return v ? atoi(v) : 256; }();
-  if (tile_env >= 256 && a->tile != 128 && a->M >= TM2 && a->N >= TN2) {
+  if (tile_env >= 256 && a->tile != 128 && a->M >= 256 && a->N >= 256) {
     const size_t shm2 = (size_t)2 * 4 * 256 * 32 * sizeof(_Float16);
     static bool attr2_done = false;
     if (!attr2_done) {
-      ASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hl256_kernel,
+      ASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hlx_kernel<4, 4, 2>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
       attr2_done = true;
     }
-    const int total = ((a->M + TM2 - 1) / TM2) * ((a->N + TN2 - 1) / TN2) * splits;
-    hipLaunchKernelGGL(gemm_hl256_kernel, dim3(total), dim3(512), shm2, stream, A, B, a->M, a->N,
-                       a->K, kps, splits, ep, a->a_scale, a->b_scale);
+    const int total = ((a->M + 255) / 256) * ((a->N + 255) / 256) * splits;
+    hipLaunchKernelGGL((gemm_hlx_kernel<4, 4, 2>), dim3(total), dim3(512), shm2, stream, A, B,
+                       a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
   } else {
-    const int total = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN) * splits;
-    hipLaunchKernelGGL(gemm_hl_kernel, dim3(total), dim3(256), shm, stream, A, B, a->M, a->N,
-                       a->K, kps, splits, ep, a->a_scale, a->b_scale);
+    const size_t shm1 = (size_t)2 * 4 * 128 * 32 * sizeof(_Float16);
+    const int total = ((a->M + 127) / 128) * ((a->N + 127) / 128) * splits;
+    hipLaunchKernelGGL((gemm_hlx_kernel<2, 2, 2>), dim3(total), dim3(256), shm1, stream, A, B,
+                       a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
   }
   ASR_CHECK_LAUNCH();
   if (splits > 1) {

@@ -525,7 +525,7 @@ def main():
             mult, peak = (1, PEAK_F32_MFMA_TFLOPS) if exact else (3, PEAK_F16_MFMA_TFLOPS)
             ach = mult * fl / (tot * 1e-3) / 1e12
             packed = len(lstm_ev['gemm_hl']) > 0
-            return {'kernel': ('gemm_hl256_kernel / gemm_hl_kernel (operands packed once into '
+            return {'kernel': ('gemm_hlx_kernel<4,4,2> (256x256 tile; operands packed once into '
                                'split-fp16 planes)' if packed else
                                'gemm_f32_mfma_kernel' if exact else 'gemm_f16x2_fast_kernel') +
                               ': all GEMMs of the step',

@@ -235,6 +235,31 @@ def test_gemm_hl_matches_float64(M, N, K, sk):
     assert err < 2e-6 * np.abs(A).max() * np.abs(B).max() * K + 2e-5
 
 
+@pytest.mark.parametrize('M,N,K,sk', [(700, 512, 160, 0), (1024, 768, 2048, 4)])
+def test_gemm_hl_small_tile_kernel_on_large_outputs(M, N, K, sk):
+    """asr_gemm_hl_args.tile = 128 (the 256-thread / 64 KB instance of the kernel) against the
+    default 256 x 256 tile: same planes, same products, fp32 sums in the same slab order."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(M + K)
+    A = rs.randn(M, K).astype(np.float32)
+    B = (rs.randn(K, N) * 0.05).astype(np.float32)
+    pa = ops.HlPlanes(M, K, 'cuda:0')
+    pb = ops.HlPlanes(N, K, 'cuda:0')
+    Ad, Bd = to_dev(A), to_dev(B)
+    ops.pack_hl(Ad, M, K, absmax=ops.absmax(Ad), r=pa)
+    ops.pack_hl(Bd, K, N, absmax=ops.absmax(Bd), c=pb)
+    outs = []
+    for tile in (0, 128):
+        Cd = torch.empty((M, N), dtype=torch.float32, device='cuda:0')
+        ops.gemm_hl(pa, pb, Cd, M, N, K, split_k=sk, tile=tile)
+        torch.cuda.synchronize()
+        outs.append(Cd.cpu().numpy())
+    want = A.astype(np.float64) @ B.astype(np.float64)
+    for o in outs:
+        assert np.abs(o - want).max() < 2e-6 * np.abs(A).max() * np.abs(B).max() * K + 2e-5
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_gemm_hl_sub_views_and_k_offsets():
     """Row / reduction-range offsets into packed planes: the dU = h_prev^T dz pattern (A's K
     range shifted by one frame against B's) and a column slice of a wider operand."""
