@@ -980,9 +980,9 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
   lb.load(1, bh, bl);
   __syncthreads();
   const int lrow = lane & 31, lhalf = lane >> 5;
-  // Ping-pong: a step is four phases -- read the fragments of one 16-deep half (plus, in the
-  // first, the LDS writes of the next slab and the loads of the one after), 24 MFMAs on them,
-  // and again for the other half -- each closed by a workgroup barrier.  The second row of
+  // Ping-pong: a step is four phases -- read the fragments of one 16-deep half, 24 MFMAs on
+  // them (with, in the first half, the LDS writes of the next slab and the loads of the one
+  // after interleaved), and again for the other half -- each closed by a workgroup barrier.  The second row of
   // waves (wm = 1; waves w and w+4 share a SIMD) runs ONE BARRIER LATE, so on every SIMD one
   // wave multiplies while the other reads: the matrix pipe no longer idles through the LDS
   // round trips of two waves in lockstep.  Buffer hazards with the one-phase lag: a slab's
@@ -998,13 +998,6 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
     hx8 fah[MI], fal[MI], fbh[NJ], fbl[NJ];
 #pragma unroll
     for (int ks = 0; ks < HBK / 16; ++ks) {
-      if (ks == 0) {
-        HlLoader256::store(ah, al, plane(nxt, 0), plane(nxt, 1));
-        HlLoader256::store(bh, bl, plane(nxt, 2), plane(nxt, 3));
-        // past the last slab every offset is out of range: those loads return zeros, unused
-        la.load(kt + 2, ah, al);
-        lb.load(kt + 2, bh, bl);
-      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int slot = hl256_slot(wn * (32 * NJ) + j * 32 + lrow, 2 * ks + lhalf);
@@ -1021,6 +1014,16 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
+      if (ks == 0) {
+        // the staging traffic rides in the issue gaps of this phase's MFMAs (32 cycles of pipe
+        // per MFMA, ~4 of issue): the 8 LDS writes of slab kt+1 first -- each frees its
+        // registers -- then the 8 loads of slab kt+2 into them; the read phases stay bare
+        HlLoader256::store(ah, al, plane(nxt, 0), plane(nxt, 1));
+        HlLoader256::store(bh, bl, plane(nxt, 2), plane(nxt, 3));
+        // past the last slab every offset is out of range: those loads return zeros, unused
+        la.load(kt + 2, ah, al);
+        lb.load(kt + 2, bh, bl);
+      }
       // term-major order: consecutive MFMAs go to eight different accumulators
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -1037,6 +1040,19 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], am[i][j], 0, 0, 0);
+      if (ks == 0) {
+        constexpr int NM = 3 * MI * NJ;                    // MFMAs of the phase: 24 or 12
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
+        }
+#pragma unroll
+        for (int g = 0; g < (NM - 8) / 2 && g < 8; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NM >= 24 ? 2 : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, NM >= 24 ? 1 : 2, 0);   // VMEM read
+        }
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();

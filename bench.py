@@ -21,6 +21,7 @@ Besides the contract fields the line carries
   cfg2              the same measurement at BASELINE.json configs[1] (its own process),
   exact_fp32        cfg3 again with every product on the exact-fp32 MFMA instructions,
   predict_latency   one 10 s utterance end to end (predict.py's unit of work), ms,
+  eval_beam         eval.py's beam-search decode of the bench batch, device and host, seconds,
   allreduce         bus bandwidth of the gradient all-reduce, N > 1 only.
 """
 import argparse
@@ -206,6 +207,33 @@ def predict_latency(dev):
     for ws in ('lstm_fwd',):
         ops.lstm_status(ops.WS.get(ws, 0, dev))
     out['real_time_factor'] = round(10.0 / (out['n1_kernel_ms'] * 1e-3), 1)
+    return out
+
+
+def eval_beam(dev, model, slab, n_valid, frames):
+    """eval.py's decoder (utils/core_utils.py:67-72: beam search, width 400 by default; README's
+    25.13 % LER used 100) on the bench batch: seconds per batch on the device
+    (asr_ctc_beam_device: logits stay in HBM) and with the library's host decoder (one
+    utterance per host thread, after a D2H copy of the logits)."""
+    import torch
+    from asr_study_amd import ops
+    logits = model.forward(slab, training=False, need_grad=False, n_valid=n_valid)
+    sl = torch.full((n_valid,), int(frames), dtype=torch.int32, device=dev)
+    out = {'utterances': int(n_valid), 'frames': int(frames), 'classes': int(logits.shape[2])}
+    for width in (100, 400):
+        ops.ctc_beam_search(logits, sl, n_valid, width)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec, dlen, _ = ops.ctc_beam_search(logits, sl, n_valid, width)
+        torch.cuda.synchronize()
+        out['device_width_%d_s' % width] = round(time.perf_counter() - t0, 4)
+        t0 = time.perf_counter()
+        host, _ = ops.ctc_beam_search_host(logits.cpu().numpy(), [int(frames)] * n_valid, n_valid, width)
+        out['host_width_%d_s' % width] = round(time.perf_counter() - t0, 4)
+        d, l = dec.cpu().numpy(), dlen.cpu().numpy()
+        out['same_strings_width_%d' % width] = bool(
+            all(d[n, :l[n]].tolist() == host[n] for n in range(n_valid)))
+    out['host_threads'] = min(int(n_valid), os.cpu_count() or 1)
     return out
 
 
@@ -582,6 +610,11 @@ def main():
                 line['predict_latency'] = predict_latency(dev)
             except Exception as e:                # a companion figure never fails the bench
                 line['predict_latency'] = {'error': repr(e)[:300]}
+            try:
+                slab_e, _ = feat.batch_device(audio_d, offs, lens, host_lens)
+                line['eval_beam'] = eval_beam(dev, model, slab_e, N, slab_e.shape[0])
+            except Exception as e:
+                line['eval_beam'] = {'error': repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(line))
