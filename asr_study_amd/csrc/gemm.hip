@@ -1063,30 +1063,91 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
   const float unscale = 1.f / (sa * sb);
   const int lcol = lane & 31;
   const bool interior = m0 + TM2 <= M && n0 + TN2 <= N;
+  // The epilogue is 1/5 of a K = 1024 tile if it is written element by element with its
+  // options tested inside (hipcc branches around every optional load and waits for it): the
+  // variants are separated OUTSIDE the element loops, the interior ones are straight-line code.
+  if (interior && ep.partial) {                 // split-K partial sums
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float* dst = ep.partial + ((size_t)tb.z * M + m0 + wm * (32 * MI) + i * 32 + 4 * lhalf) * N +
+                     n0 + wn * (32 * NJ) + j * 32 + lcol;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          dst[(size_t)((e & 3) + 8 * (e >> 2)) * N] = am[i][j][e] * unscale;
+      }
+    return;
+  }
+  const bool use_old = ep.beta != 0.f;
+  const bool use_msk = ep.c_scale != nullptr;
+  if (interior && !ep.partial && !use_old && !use_msk) {      // C = alpha A B^T + bias
+    const float sc = unscale * ep.alpha;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * (32 * NJ) + j * 32 + lcol;
+        float* dst = ep.C + (size_t)(m0 + wm * (32 * MI) + i * 32 + 4 * lhalf) * ep.ldc + col;
+        const float bias = ep.bias ? ep.bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          dst[(size_t)((e & 3) + 8 * (e >> 2)) * ep.ldc] = am[i][j][e] * sc + bias;
+      }
+    return;
+  }
+  if (interior && !ep.partial) {                 // with old C and / or a row mask: loads first
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * (32 * NJ) + j * 32 + lcol;
+        const int row0 = m0 + wm * (32 * MI) + i * 32 + 4 * lhalf;
+        float* dst = ep.C + (size_t)row0 * ep.ldc + col;
+        const float bias = ep.bias ? ep.bias[col] : 0.f;
+        float old[16], msk[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { old[e] = 0.f; msk[e] = 1.f; }
+        if (use_old) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) old[e] = dst[(size_t)((e & 3) + 8 * (e >> 2)) * ep.ldc];
+        }
+        if (use_msk) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            msk[e] = ep.c_scale[(size_t)mod_period(row0 + (e & 3) + 8 * (e >> 2), ep.c_period) *
+                                ep.c_ld + col];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          dst[(size_t)((e & 3) + 8 * (e >> 2)) * ep.ldc] =
+              (am[i][j][e] * unscale * ep.alpha + bias) * msk[e] + ep.beta * old[e];
+      }
+    return;
+  }
+  // edge tiles: per-element bound checks
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col = n0 + wn * (32 * NJ) + j * 32 + lcol;
       const int row0 = m0 + wm * (32 * MI) + i * 32 + 4 * lhalf;
-      if (!interior && col >= N) continue;
+      if (col >= N) continue;
       if (ep.partial) {
         float* dst = ep.partial + ((size_t)tb.z * M + row0) * N + col;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int dr = (e & 3) + 8 * (e >> 2);
-          if (interior || row0 + dr < M) dst[(size_t)dr * N] = am[i][j][e] * unscale;
+          if (row0 + dr < M) dst[(size_t)dr * N] = am[i][j][e] * unscale;
         }
         continue;
       }
       float* dst = ep.C + (size_t)row0 * ep.ldc + col;
       const float bias = ep.bias ? ep.bias[col] : 0.f;
-      const bool use_old = ep.beta != 0.f;
-      const bool use_msk = ep.c_scale != nullptr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int dr = (e & 3) + 8 * (e >> 2);
-        if (!(interior || row0 + dr < M)) continue;
+        if (row0 + dr >= M) continue;
         float v = am[i][j][e] * unscale * ep.alpha + bias;
         if (use_msk)
           v *= ep.c_scale[(size_t)mod_period(row0 + dr, ep.c_period) * ep.c_ld + col];
