@@ -117,7 +117,13 @@ class Model(object):
         # weight-gradient GEMMs run on a side stream, concurrently with the next
         # layer's persistent BPTT kernel (which occupies only H/16 x chains CUs)
         import os as _os
-        self.overlap = _os.environ.get('ASR_OVERLAP', '1') != '0'
+        # ASR_OVERLAP: 1 = always, 0 = never, auto (default) = unless a layer's recurrence
+        # fills every CU (cfg3: 2 directions x 4 batch tiles x 32 workgroups = 256): its waves
+        # hold 480 of a SIMD's 512 registers, no GEMM wave fits beside them, and a GEMM launched
+        # on the side stream only waits (measured: 51.9 vs 52.5 ms per cfg3 step, but every
+        # GEMM duration in a profile doubled by the wait) -- decided per batch in forward()
+        self._overlap_mode = _os.environ.get('ASR_OVERLAP', 'auto')
+        self.overlap = self._overlap_mode != '0'
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         # the GEMMs either side of a recurrence are pipelined against its last quarter
         # (frames whose both directions are already final), on a third stream
@@ -510,6 +516,8 @@ class Model(object):
         self._acts = []
         drawn = [None]
         nb = 0
+        if self._overlap_mode == 'auto':
+            self.overlap = not self._recurrence_fills_chip(n_pad)
         self._pipe_now = self._pipeline_on(n_pad)
         # (the packed-operand GEMMs take whole slabs: no frame-range pipelining with them)
         pipe = (self._pipe_now and self._pipe is not None and self.lstm_mode == 0 and T >= 16
@@ -622,6 +630,14 @@ class Model(object):
             rec['out'] = a
             self._acts.append(rec)
         return a
+
+    def _recurrence_fills_chip(self, n_pad):
+        if self.device.type != 'cuda':
+            return False
+        if not hasattr(self, '_num_cu'):
+            self._num_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        widest = max([(st.Hp + 15) // 16 for st in self.stages if st.kind == 'bilstm'] + [0])
+        return 2 * (n_pad // 16) * widest >= self._num_cu
 
     def _pipeline_on(self, n_pad):
         if not self.overlap or self._pipeline_mode == '0':
