@@ -370,3 +370,28 @@ def test_brsmv1_packed_operand_gemm_path(use_masks, monkeypatch):
         results[packed] = model.get_weights()
     for a, b in zip(results['1'], results['0']):     # (Adam, lr 1e-2: sign-like early steps)
         assert np.abs(a - b).max() < 1e-4
+
+
+def test_side_stream_is_used_only_where_a_gemm_can_run_beside_the_recurrence():
+    """ASR_OVERLAP=auto (engine.Model._recurrence_fills_chip): 5xBiLSTM(512) at batch 64 puts
+    2 directions x 4 batch tiles x 32 workgroups = 256 recurrent workgroups on the 256 CUs and
+    leaves no registers for a GEMM wave -> no side stream; BiLSTM(256) at batch 32 uses 64 CUs ->
+    side stream on.  Same gradients either way (the switch only moves launches between streams)."""
+    from asr_study_amd.core import models
+    rs = np.random.RandomState(11)
+    for H, N, want in ((512, 64, False), (256, 32, True)):
+        T, F, C = 9, 16, 6
+        model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=2,
+                              dropout=0.0, seed=2)
+        x, labels, lens = _batch(rs, N, T, F, C)
+        slab = model.to_slab(x)
+        model.loss_and_grads(slab, labels, lens, training=True)
+        torch.cuda.synchronize()
+        assert model.overlap is want, (H, N)
+        g_auto = [g.copy() for g in model.get_gradients()]
+        model._overlap_mode = '1' if not want else '0'
+        model.overlap = not want
+        model.loss_and_grads(slab, labels, lens, training=True)
+        torch.cuda.synchronize()
+        for a, b in zip(g_auto, model.get_gradients()):
+            assert np.array_equal(a, b)
