@@ -2838,6 +2838,18 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
 }
 
 constexpr size_t kStatusBytes = 256;
+
+// workspace preparation of a launch that starts a sequence: 16-byte words [0, n_zero) to 0,
+// [n_zero, n_total) to all ones, *absmax (optional) to 0
+__global__ void __launch_bounds__(256)
+lstm_prepare_kernel(uint4* __restrict__ ws, long long n_zero, long long n_total,
+                    unsigned* __restrict__ absmax) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u), f = make_uint4(~0u, ~0u, ~0u, ~0u);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_total;
+       i += (long long)gridDim.x * 256)
+    ws[i] = i < n_zero ? z : f;
+  if (absmax && blockIdx.x == 0 && threadIdx.x == 0) *absmax = 0u;
+}
 constexpr size_t kStickyBytes = kStickyInts * sizeof(int);
 
 size_t xbuf_bytes(const asr_lstm_args* a, bool bwd) {
@@ -2906,10 +2918,15 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
     r_end = a->step_begin + a->step_count;
   }
   if (r_begin == 0) {
-    if (p.dz_absmax) ASR_CHECK_HIP(hipMemsetAsync(p.dz_absmax, 0, sizeof(unsigned), stream));
-    // status words and the (adjacent) XCC table in one fill
-    ASR_CHECK_HIP(hipMemsetAsync(ws, 0, kStatusBytes + cb_, stream));
-    ASR_CHECK_HIP(hipMemsetAsync(ws + kStatusBytes + cb_, 0xFF, xb, stream));
+    // status words + XCC table to 0, exchange slots to 0xFF, the gate-gradient maximum to 0:
+    // ONE launch (three hipMemsetAsync were three fill kernels with a launch gap each, 30 per
+    // training step)
+    const size_t zero_b = kStatusBytes + cb_;
+    const int blocks = (int)((zero_b + xb) / 16 / 256 + 1) < 512 ? (int)((zero_b + xb) / 16 / 256 + 1) : 512;
+    hipLaunchKernelGGL(lstm_prepare_kernel, dim3(blocks), dim3(256), 0, stream,
+                       reinterpret_cast<uint4*>(ws), (long long)(zero_b / 16),
+                       (long long)((zero_b + xb) / 16), reinterpret_cast<unsigned*>(p.dz_absmax));
+    ASR_CHECK_LAUNCH();
   }
   // launch units: chains, or pairs of chains when a workgroup serves two batch tiles
   const int chains = pl.n1 ? 2 : pl.pair ? p.NB : 2 * p.NB;
