@@ -126,3 +126,37 @@ def test_sharded_flow_counts_global_samples_and_weights_uneven_shards():
     assert per_rank[1][1][2][2] == [0.0]
     # an uneven 4-sample batch over 3 ranks: 2 + 1 + 1 samples, all scaled by 1/4
     assert [per_rank[r][1][0][1] for r in range(world)] == [2, 1, 1]
+
+
+def _ar_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import types
+    from asr_study_amd import parallel
+    from asr_study_amd.core import engine
+    parallel.init_from_env(backend='gloo')
+    n = 1000
+    fake = types.SimpleNamespace(n_params=n, grads=torch.arange(n, dtype=torch.float32) * (rank + 1),
+                                 _dist_active=lambda: True)
+    # what backward() does for the layers whose gradients finish early: asynchronous
+    # all-reduces of their slices, in the order the layers finish (top layer first)
+    fake._ar_handles, fake._ar_covered = [], []
+    for lo, hi in ((700, 900), (300, 700), (120, 300)):
+        fake._ar_handles.append(dist.all_reduce(fake.grads[lo:hi], async_op=True))
+        fake._ar_covered.append((lo, hi))
+    w = engine.Model._allreduce(fake)      # waits, then reduces [0,120) and [900,1000)
+    if rank == 0:
+        np.save(out, np.concatenate([fake.grads.numpy(), [w]]))
+    parallel.finalize()
+
+
+def test_engine_allreduce_covers_every_gradient_exactly_once(tmp_path):
+    """engine.Model._allreduce (host bookkeeping of the overlapped per-layer all-reduce): slices
+    reduced asynchronously during BPTT are waited for, the remaining slices of the flat buffer
+    (first layer, Dense head) are reduced in place, nothing twice -- world 2 over gloo."""
+    out = str(tmp_path / 'ar.npy')
+    port = _free_port()
+    mp.spawn(_ar_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    np.testing.assert_array_equal(got[:-1], np.arange(1000, dtype=np.float32) * 3.0)
+    assert got[-1] == 2
