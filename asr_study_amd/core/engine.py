@@ -968,6 +968,14 @@ class Model(object):
                     da = dx
                 if not self.overlap:
                     weight_grads('gemm')
+                    if reduce_now and not first:
+                        # no side stream (a recurrence fills the chip): this layer's gradients
+                        # are final on the main stream; their all-reduce (RCCL orders itself
+                        # after it) runs beside the layers below instead of after them all
+                        import torch.distributed as dist
+                        self._ar_handles.append(
+                            dist.all_reduce(self.grads[s.p_lo:s.p_hi], async_op=True))
+                        self._ar_covered.append((s.p_lo, s.p_hi))
                 elif first:
                     # nothing left to hide behind: share the tail between both streams
                     ready = torch.cuda.Event()

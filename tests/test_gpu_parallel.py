@@ -49,9 +49,10 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from asr_study_amd.core import models, optimizers
 out = {}
-for mode in ("1", "0", "capi"):
-    os.environ["ASR_AR_OVERLAP"] = "0" if mode == "capi" else mode
+for mode in ("1", "0", "capi", "noside", "noside0"):
+    os.environ["ASR_AR_OVERLAP"] = {"capi": "0", "noside": "1", "noside0": "0"}.get(mode, mode)
     os.environ["ASR_COMM"] = "capi" if mode == "capi" else "torch"
+    os.environ["ASR_OVERLAP"] = "0" if mode.startswith("noside") else "auto"
     model = models.brsmv1(num_features=9, num_classes=7, num_hiddens=16, num_layers=3,
                           dropout=0.0, weight_decay=1e-4, seed=1)
     model.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=1.0))
@@ -70,9 +71,9 @@ print("RESULT " + json.dumps(out))
 
 @pytest.mark.timeout(300)
 def test_layerwise_allreduce_overlap_equals_single_allreduce():
-    """The per-layer asynchronous all-reduces issued from the side stream during BPTT
-    (ASR_AR_OVERLAP=1, default) and one all-reduce of the whole buffer after it give the
-    same training trajectory (world size 1 on the box's single GPU: the collective is an
+    """The per-layer asynchronous all-reduces issued during BPTT (ASR_AR_OVERLAP=1, default;
+    from the side stream, or from the main stream when there is none) and one all-reduce of the
+    whole buffer after it give the same training trajectory (world size 1 on the box's single GPU: the collective is an
     identity, what is tested is stream ordering and buffer coverage)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', ASR_FORCE_ALLREDUCE='1',
                ASR_ROOT=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
@@ -83,4 +84,11 @@ def test_layerwise_allreduce_overlap_equals_single_allreduce():
     line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('RESULT ')][0]
     res = json.loads(line[7:])
     assert res['1'] == res['0'] == res['capi']      # capi: asr_comm_* instead of torch
+    # no side stream (cfg3's schedule): per-layer all-reduces from the main stream == one at the
+    # end; against the side-stream schedule only the frame-range pipelining differs (the
+    # gradient GEMMs' power-of-two pre-scale is taken per slice there): last-bit differences
+    assert res['noside'] == res['noside0']
+    assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(res['noside'], res['1']))
     assert res['layers_reduced_during_bptt_1'] == 2 and res['layers_reduced_during_bptt_0'] == 0
+    assert res['layers_reduced_during_bptt_noside'] == 2
+    assert res['layers_reduced_during_bptt_noside0'] == 0
