@@ -466,7 +466,7 @@ def main():
         extra['roofline_gate_gemm'] = {
             'kernel': '%s %dx%dx%d (x@W, one BiLSTM layer)' % (
                 'gemm_f32_mfma_kernel' if exact else
-                'gemm_hl_kernel' if packed else 'gemm_f16x2_fast_kernel', rows, 8 * H, 2 * H),
+                'gemm_hlx_kernel<4,4,2>' if packed else 'gemm_f16x2_fast_kernel', rows, 8 * H, 2 * H),
             'pack_ms': None if t_pack is None else round(t_pack, 4),
             'bound': 'mfma', 'achieved': round(mult * gf / tg / 1e9, 2), 'peak': peak,
             'unit': 'TFLOP/s', 'frac': round(mult * gf / tg / 1e9 / peak, 4),
