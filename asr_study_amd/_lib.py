@@ -125,6 +125,8 @@ SIGNATURES = {
     'asr_stream_create_cu_mask': (C.c_int, [void_p, C.c_int, C.POINTER(void_p)]),
     'asr_stream_destroy': (C.c_int, [void_p]),
     'asr_optim_guard': (C.c_int, [void_p, void_p, void_p, void_p]),
+    'asr_timeout_flags': (C.c_int, [void_p, void_p, void_p, void_p]),
+    'asr_debug_occupy': (C.c_int, [C.c_int, C.c_int, C.c_double, void_p]),
     'asr_colsum_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'asr_colsum': (C.c_int, [void_p, C.c_int, C.c_int, C.c_int, void_p, C.c_float, void_p,
                              C.c_size_t, void_p]),

@@ -108,6 +108,16 @@ class Model(object):
         self.spec = spec
         self.num_features = int(num_features)
         self.lstm_mode = int(os.environ.get('ASR_LSTM_MODE', lstm_mode))   # 1 = stepwise kernels
+        # A persistent recurrent kernel that abandoned a bounded spin demotes the model to the
+        # stepwise kernels only for a while: after `_retry_gap` clean optimisation steps the
+        # persistent kernels are tried again (the gap doubles with every further fallback).
+        # A model that was ASKED for mode 1 stays there.
+        self._mode_pinned = self.lstm_mode == 1
+        self._retry_at = None
+        self._retry_gap = int(os.environ.get('ASR_LSTM_RETRY_STEPS', '64'))
+        self.fallbacks = 0              # timeouts survived (bench.py asserts 0)
+        self.vetoed_steps = 0           # optimisation steps skipped because of them
+        self._fault_gen = 0
         self.optimizer = None
         self.metrics_names = ['loss', 'ctc_loss', 'decoder_loss', 'decoder_ler']
         self.decoder = dict(is_greedy=True)
@@ -153,8 +163,16 @@ class Model(object):
         # training-time noise comes from the library's counter-based streams (ops.dropout_masks
         # ...: Philox-4x32-10 keyed by this seed; stream id = 4 * stage index + kind, step =
         # the optimisation step), so a step's masks are a pure function of (seed, stage, step)
-        self.rng_seed = (int(seed) + 12345) & (2 ** 64 - 1)
+        # ... and, data parallel, of the rank: every rank draws its OWN noise for its shard
+        # (the rank is mixed in when the key is used: the process group may be created later)
+        self._rng_base = (int(seed) + 12345) & (2 ** 64 - 1)
         self._layout(seed)
+
+    @property
+    def rng_seed(self):
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        return (self._rng_base + rank * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
 
     # ------------------------------------------------------------------ params
     def _layout(self, seed):
@@ -256,7 +274,11 @@ class Model(object):
         self.num_classes = f_real
         self.n_params = off
         self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(off, dtype=torch.float32, device=self.device)
+        # gradients + 4 trailing floats: [0:2] carry this rank's recurrent-kernel timeout flags
+        # through the gradient all-reduce (sum > 0 on every rank if ANY rank timed out), so a
+        # veto of the update is collective and costs no collective of its own
+        self._gbuf = torch.zeros(off + 4, dtype=torch.float32, device=self.device)
+        self.grads = self._gbuf[:off]
         self._segments = sorted(segs)
         self._segs_dev, self._nseg = ops.make_segments(self._segments, self.device)
         self._norm = torch.zeros(2, dtype=torch.float64, device=self.device)
@@ -741,8 +763,16 @@ class Model(object):
         if not hasattr(self, '_dz_free'):
             self._dz_free = [None, None]
 
-        reduce_now = (self._dist_active() and os.environ.get('ASR_AR_OVERLAP', '1') != '0'
-                      and os.environ.get('ASR_COMM', 'torch') != 'capi')
+        # ASR_AR_OVERLAP: auto (default) = per-layer asynchronous all-reduces beside the BPTT of
+        # the layers below ONLY while a recurrence leaves CUs free (cfg2: 64 of 256).  Where a
+        # recurrence fills the chip (cfg3) its spin-waiting workgroups must all be resident, and
+        # an RCCL kernel that takes CUs first stalls the whole chain: there the gradients are
+        # reduced by ONE collective over the flat buffer after BPTT (110.6 MB: 0.6-2.5 ms of a
+        # ~50 ms step).  1 = always overlap, 0 = never.
+        ar_mode = os.environ.get('ASR_AR_OVERLAP', 'auto')
+        reduce_now = (self._dist_active() and ar_mode != '0'
+                      and os.environ.get('ASR_COMM', 'torch') != 'capi'
+                      and (ar_mode == '1' or not self._recurrence_fills_chip(n_pad)))
         self._ar_handles, self._ar_covered = [], []
 
         def flush_side():
@@ -1062,6 +1092,7 @@ class Model(object):
         """A full optimisation step with every input resident in HBM and no host
         synchronisation: forward, CTC, BPTT, (RCCL all-reduce), clip + update, greedy
         decode for the LER metric.  Returns device tensors (ctc, decoded, lengths)."""
+        self._maybe_retry_persistent()
         ctc, logits, sl = self.loss_and_grads_device(slab, lab, lab_len, sl, N, training=True,
                                                      n_global=N * world)
         self._allreduce()
@@ -1075,28 +1106,93 @@ class Model(object):
         return dist.is_available() and dist.is_initialized() and (
             dist.get_world_size() > 1 or os.environ.get('ASR_FORCE_ALLREDUCE') == '1')
 
+    # ------------------------------------------------------------------ timeouts
+    def _collect_flags(self):
+        """This rank's recurrent-kernel timeout flags -> the two flag slots behind the
+        gradients (as 0.0 / 1.0), enqueued on the current stream."""
+        ops.collect_timeout_flags(self._gbuf[self.n_params:], self.device)
+
+    def veto_flags(self):
+        """What the optimiser's guard looks at: data parallel, the all-reduced flag slots
+        (non-zero on EVERY rank when any rank timed out, so all ranks skip the same update);
+        single process, None = the workspaces' own sticky words."""
+        return self._gbuf[self.n_params:self.n_params + 2] if self._dist_active() else None
+
+    def _flag_snapshot(self):
+        v = self.veto_flags()
+        return ops.lstm_timeout_flags(self.device) if v is None else v.clone()
+
+    def _maybe_retry_persistent(self):
+        """After a fallback the stepwise kernels run for `_retry_gap` clean steps, then the
+        persistent ones get another chance (every rank takes the same decision: the detection
+        is collective)."""
+        if (self.lstm_mode == 1 and not self._mode_pinned and self._retry_at is not None
+                and self._step >= self._retry_at):
+            self.lstm_mode = 0
+            self._retry_at = None
+
+    def _handle_timeout(self, flags, gen, train=True):
+        """flags: a step's snapshot of the (collective) timeout flags, gen: self._fault_gen
+        when that step was enqueued.  Returns True when the step was vetoed (its update did not
+        happen and its activations are invalid): the caller drops its metrics.  Bookkeeping:
+        the vetoed step is taken back from the optimiser's iteration count (Adam bias
+        correction, decay) and from the noise-stream step."""
+        if not bool(flags.any().item()):
+            return False
+        from .._lib import AsrHipError
+        if train and self.optimizer is not None:
+            self.optimizer.iterations = max(0, self.optimizer.iterations - 1)
+            self._step = max(0, self._step - 1)
+            self.vetoed_steps += 1
+        if gen < self._fault_gen:
+            return True                 # enqueued before the fallback took effect: known
+        if self.lstm_mode == 1:
+            raise AsrHipError('a recurrent LSTM kernel reported a timeout in stepwise mode: '
+                              'device fault')
+        # A persistent kernel abandoned a bounded spin (a peer workgroup was not co-resident).
+        # The update of every step enqueued since was vetoed on the device (ops.optim_guard),
+        # so the weights are intact: clear the flags and go on with the stepwise kernels (one
+        # launch per step, identical arithmetic, no co-residency) for a while.
+        import logging
+        logging.getLogger(__name__).warning(
+            'persistent LSTM kernel timed out waiting for a peer workgroup; the affected '
+            'step(s) were skipped; stepwise kernels (mode 1) for the next %d steps',
+            self._retry_gap)
+        torch.cuda.synchronize(self.device)
+        ops.clear_timeout_flags(self.device)
+        self._gbuf[self.n_params:].zero_()
+        self.lstm_mode = 1
+        self.fallbacks += 1
+        self._fault_gen += 1
+        self._retry_at = self._step + self._retry_gap
+        self._retry_gap = min(2 * self._retry_gap, 1 << 14)
+        return True
+
     def _allreduce(self):
         """Sums the gradients over the ranks (RCCL).  Layers whose weight gradients were
         finished on the side stream during BPTT were already reduced there, asynchronously
-        (backward()); here the current stream waits for those and the remaining slices of
-        the flat buffer (first layer, Dense) are reduced in place."""
+        (backward(), only where a recurrence leaves CUs free); here the current stream waits
+        for those and the rest of the flat buffer -- everything, where BPTT fills the chip --
+        is reduced in place, TOGETHER with the two timeout-flag slots behind it."""
         import torch.distributed as dist
         if not self._dist_active():
             return 1
+        self._collect_flags()
+        total = self.n_params + 4
         if os.environ.get('ASR_COMM', 'torch') == 'capi':
             # the library's own RCCL entry points (asr_comm_*), on the current stream
             from ..parallel import CapiComm
-            CapiComm.get().allreduce_sum_(self.grads)
+            CapiComm.get().allreduce_sum_(self._gbuf)
             return dist.get_world_size()
         handles, covered = getattr(self, '_ar_handles', []), sorted(getattr(self, '_ar_covered', []))
         for h in handles:
             h.wait()                        # the current stream waits for the collective
         pos = 0
-        for lo, hi in covered + [(self.n_params, self.n_params)]:
+        for lo, hi in covered + [(total, total)]:
             if lo > pos:
                 # RCCL orders itself after the kernels already enqueued on the current
                 # stream and the current stream after the collective
-                dist.all_reduce(self.grads[pos:lo])
+                dist.all_reduce(self._gbuf[pos:lo])
             pos = max(pos, hi)
         self._ar_handles, self._ar_covered = [], []
         return dist.get_world_size()
@@ -1107,6 +1203,7 @@ class Model(object):
         Returns [loss, ctc_loss, decoder_loss, decoder_ler] when ``sync`` (like
         Keras), else the device tensors needed to compute them later."""
         assert self.optimizer is not None, 'compile() first'
+        self._maybe_retry_persistent()
         slab, labels, lens = self._unpack_inputs(inputs)
         N = len(labels)
         import torch.distributed as dist
@@ -1116,6 +1213,7 @@ class Model(object):
         n_global = getattr(inputs, 'n_global', N * world)
         if getattr(inputs, 'n_local', N) == 0:
             n_global = 0
+        gen = self._fault_gen
         ctc, logits, sl = self.loss_and_grads(slab, labels, lens, training=True, masks=masks,
                                               n_global=n_global)
         self._allreduce()
@@ -1126,36 +1224,26 @@ class Model(object):
             # snapshots of this step's small result tensors (the buffers behind them are
             # reused by the next step): metrics can then be fetched one step later
             return (ctc.clone(), dec.clone(), dlen.clone(), self._norm[1:2].clone(),
-                    ops.lstm_timeout_flags(self.device))
-        return self._metrics(ctc, dec, dlen, labels)
+                    self._flag_snapshot(), gen)
+        m = self._metrics(ctc, dec, dlen, labels, gen=gen)
+        if m is None:
+            # the step was vetoed (timeout): run it again, on the stepwise kernels
+            return self.train_on_batch(inputs, outputs, masks=masks, sync=True)
+        return m
 
     def _lagged(self, pending):
-        (ctc, dec, dlen, pen, flags), labels, _ = pending
-        return self._metrics(ctc, dec, dlen, labels, pen=pen, flags=flags)
+        """Metrics of a step enqueued earlier, or None if its update was vetoed."""
+        (ctc, dec, dlen, pen, flags, gen), labels, _ = pending
+        return self._metrics(ctc, dec, dlen, labels, pen=pen, flags=flags, gen=gen)
 
-    def _metrics(self, ctc, dec, dlen, labels, hyps=None, pen=None, flags=None):
+    def _metrics(self, ctc, dec, dlen, labels, hyps=None, pen=None, flags=None, gen=None,
+                 train=True):
         ctc_h = ctc.cpu().numpy().astype(np.float64)
         # the persistent recurrent kernels bound every spin; one that gave up has left
-        # invalid activations behind: fail here, at the step's host synchronisation point
-        flags = ops.lstm_timeout_flags(self.device) if flags is None else flags
-        if bool(flags.any().item()):
-            from .._lib import AsrHipError
-            if self.lstm_mode == 1:
-                raise AsrHipError('a recurrent LSTM kernel reported a timeout in stepwise mode: '
-                                  'device fault')
-            # A persistent kernel abandoned a bounded spin (a peer workgroup was not
-            # co-resident).  The update of every step enqueued since was vetoed on the device
-            # (ops.optim_guard), so the weights are intact: clear the flags and go on with the
-            # stepwise kernels (one launch per step, identical arithmetic, no co-residency).
-            import logging
-            logging.getLogger(__name__).warning(
-                'persistent LSTM kernel timed out waiting for a peer workgroup; the affected '
-                'step(s) were skipped; falling back to the stepwise kernels (mode 1)')
-            torch.cuda.synchronize(self.device)
-            for name in ('lstm_fwd', 'lstm_bwd'):
-                ops.WS.get(name, 0, self.device)[:4].zero_()
-            self.lstm_mode = 1
-            self.fallbacks = getattr(self, 'fallbacks', 0) + 1
+        # invalid activations behind: handled here, at the step's host synchronisation point
+        flags = self._flag_snapshot() if flags is None else flags
+        if self._handle_timeout(flags, self._fault_gen if gen is None else gen, train):
+            return None
         if pen is not None:
             pen = float(pen.item())
         else:
@@ -1187,7 +1275,11 @@ class Model(object):
                 if l2:
                     w2 += l2 * float((flat[off:off + n].double() ** 2).sum().item())
             self._norm[1] = w2
-        return self._metrics(ctc, dec, dlen, labels, hyps)
+        m = self._metrics(ctc, dec, dlen, labels, hyps, train=False,
+                          flags=ops.lstm_timeout_flags(self.device))
+        if m is None:       # a forward kernel timed out: evaluate the batch again, stepwise
+            return self.test_on_batch(inputs, outputs)
+        return m
 
     def predict(self, x, inputs_length=None):
         """Decoded label sequences for a batch (greedy or beam, per self.decoder), or the
@@ -1252,6 +1344,15 @@ class Model(object):
                 t0 = time.time()
                 seen, seen_local, sums = 0, 0, np.zeros(4)
                 pending = None              # (device results, labels, n) of the previous step
+
+                def account(pend):
+                    # a step whose update was vetoed (recurrent-kernel timeout) has no valid
+                    # activations: it counts for nothing
+                    m = self._lagged(pend)
+                    if m is None:
+                        return 0
+                    sums[:] += np.array(m) * pend[2]
+                    return pend[2]
                 while seen < samples_per_epoch:
                     inputs, outputs = feeder.get()
                     slab, labels, lens = self._unpack_inputs(inputs)
@@ -1263,13 +1364,15 @@ class Model(object):
                         batch = ShardedBatch(batch, inputs.n_global, inputs.n_local)
                     res = self.train_on_batch(batch, outputs, sync=False)
                     if pending is not None:
-                        sums += np.array(self._lagged(pending)) * pending[2]
+                        seen_local += account(pending)
                     pending = (res, labels, n)
                     seen += getattr(inputs, 'n_global', len(labels))
-                    seen_local += n
                 if pending is not None:
-                    sums += np.array(self._lagged(pending)) * pending[2]
-                logs = dict(zip(self.metrics_names, (sums / max(seen_local, 1)).tolist()))
+                    seen_local += account(pending)
+                # the training-side logs are GLOBAL means: callbacks that monitor them (LR
+                # schedules, early stopping) must take the same decision on every rank
+                from ..parallel import reduce_metrics
+                logs = dict(zip(self.metrics_names, reduce_metrics(sums, seen_local)))
                 if validation_data is not None:
                     val = self.evaluate_generator(validation_data, nb_val_samples)
                     for k, v in zip(self.metrics_names, val):

@@ -42,7 +42,7 @@ class Adam(Optimizer):
         self.iterations += 1
         # norm -> device-side veto if a recurrent kernel flagged a timeout -> clipped update
         ops.grad_norm(model.params, model.grads, model._segs_dev, model._nseg, model._norm)
-        ops.optim_guard(model._norm, model.params.device)
+        ops.optim_guard(model._norm, model.params.device, model.veto_flags())
         ops.adam_step(model.params, model.grads, self.state[0], self.state[1], model._segs_dev,
                       model._nseg, model._norm, self.clipnorm, lr, self.iterations, self.beta_1,
                       self.beta_2, self.epsilon)
@@ -63,7 +63,7 @@ class SGD(Optimizer):
         lr = self.lr / (1.0 + self.decay * self.iterations) if self.decay else self.lr
         self.iterations += 1
         ops.grad_norm(model.params, model.grads, model._segs_dev, model._nseg, model._norm)
-        ops.optim_guard(model._norm, model.params.device)
+        ops.optim_guard(model._norm, model.params.device, model.veto_flags())
         ops.sgd_step(model.params, model.grads, self.state[0], model._segs_dev, model._nseg,
                      model._norm, self.clipnorm, lr, self.momentum)
 

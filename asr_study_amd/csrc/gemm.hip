@@ -800,7 +800,7 @@ struct HlSrc {
 // block rows 4 ty.., columns 4 tx..
 __global__ void __launch_bounds__(256)
 pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
-               const float* __restrict__ mask, int pmask, int mask_ld,
+               const float* __restrict__ mask, int mask_period, int mask_ld,
                const float* __restrict__ absmax, float* __restrict__ scale_out,
                _Float16* __restrict__ r_hi, _Float16* __restrict__ r_lo, int ldk_r,
                _Float16* __restrict__ c_hi, _Float16* __restrict__ c_lo, int ldk_c) {
@@ -826,7 +826,8 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
         for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] = q[e];
       }
       if (mask) {
-        const float* m = mask + (size_t)(r & pmask) * mask_ld + c;
+        // (n_pad is a multiple of 16, not necessarily a power of two: 48, 80, 96 ...)
+        const float* m = mask + (size_t)mod_period(r, mask_period) * mask_ld + c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] *= m[e];
       }
@@ -1418,15 +1419,12 @@ extern "C" int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream_) {
   if (a->c_hi)
     ASR_CHECK_ARG(a->ldk_c % 32 == 0 && a->ldk_c >= a->rows && a->ldk_c < a->rows + 32 &&
                   aligned16(a->c_hi) && aligned16(a->c_lo), "pack_hl: bad column-plane geometry");
-  int pmask = 0;
-  if (a->mask) {
-    ASR_CHECK_ARG(a->mask_period > 0 && (a->mask_period & (a->mask_period - 1)) == 0 &&
-                  a->mask_ld >= a->cols, "pack_hl: mask period must be a power of two");
-    pmask = a->mask_period - 1;
-  }
+  if (a->mask)
+    ASR_CHECK_ARG(a->mask_period > 0 && a->mask_ld >= a->cols,
+                  "pack_hl: a mask needs a positive row period and mask_ld >= cols");
   dim3 grid((a->cols + 63) / 64, (a->rows + 63) / 64);
   hipLaunchKernelGGL(pack_hl_kernel, grid, dim3(256), 0, stream, a->src, a->rows, a->cols, a->ld,
-                     a->mask, pmask, a->mask_ld, a->absmax, a->scale_out,
+                     a->mask, a->mask ? a->mask_period : 1, a->mask_ld, a->absmax, a->scale_out,
                      reinterpret_cast<_Float16*>(a->r_hi), reinterpret_cast<_Float16*>(a->r_lo),
                      a->ldk_r, reinterpret_cast<_Float16*>(a->c_hi),
                      reinterpret_cast<_Float16*>(a->c_lo), a->ldk_c);

@@ -117,6 +117,30 @@ __global__ void optim_guard_kernel(double* __restrict__ norm, const int* __restr
   if ((a && *a != 0) || (b && *b != 0)) norm[0] = -1.0;
 }
 
+// flags of this process' recurrent workspaces as 0.0 / 1.0 floats: the two slots behind the
+// flat gradient buffer, so that the gradient all-reduce (a sum) makes a timeout of ANY rank
+// visible to EVERY rank's guard
+__global__ void timeout_flags_kernel(const int* __restrict__ a, const int* __restrict__ b,
+                                     float* __restrict__ out2) {
+  out2[0] = (a && *a != 0) ? 1.f : 0.f;
+  out2[1] = (b && *b != 0) ? 1.f : 0.f;
+}
+
+// Holds `blocks` workgroups (256 threads, lds_bytes of LDS each) on the device for `ticks`
+// of the 100 MHz wall clock: a stand-in for a foreign kernel (an RCCL collective) that
+// takes compute units away from the persistent recurrent kernels -- tests only.
+__global__ void __launch_bounds__(256)
+occupy_kernel(long long ticks, unsigned* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const long long t0 = wall_clock64();
+  unsigned acc = 0;
+  while (wall_clock64() - t0 < ticks) {
+    acc += (unsigned)threadIdx.x;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (sink && acc == 0xFFFFFFFFu) { lds[threadIdx.x] = 1.f; *sink = acc + (unsigned)lds[0]; }
+}
+
 int grid_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -156,6 +180,28 @@ extern "C" int asr_optim_guard(double* norm_dev, const int* flag_a, const int* f
   ASR_CHECK_ARG(norm_dev, "optim_guard: null norm");
   hipLaunchKernelGGL(optim_guard_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, norm_dev,
                      flag_a, flag_b);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}
+
+extern "C" int asr_timeout_flags(const int* flag_a, const int* flag_b, float* out2,
+                                 asr_stream_t stream_) {
+  ASR_CHECK_ARG(out2, "timeout_flags: null output");
+  hipLaunchKernelGGL(timeout_flags_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, flag_a,
+                     flag_b, out2);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}
+
+extern "C" int asr_debug_occupy(int blocks, int lds_bytes, double seconds, asr_stream_t stream_) {
+  ASR_CHECK_ARG(blocks > 0 && blocks <= 4096 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 &&
+                seconds >= 0.0 && seconds <= 5.0, "debug_occupy: blocks in [1, 4096], LDS <= 160 KB, "
+                "at most 5 s");
+  if (lds_bytes > 64 * 1024)
+    ASR_CHECK_HIP(hipFuncSetAttribute((const void*)occupy_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes,
+                     (hipStream_t)stream_, (long long)(seconds * 1e8), (unsigned*)nullptr);
   ASR_CHECK_LAUNCH();
   return ASR_OK;
 }

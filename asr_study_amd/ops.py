@@ -38,9 +38,12 @@ class _Workspaces(object):
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             # zero-filled: the recurrent kernels keep a sticky timeout flag in the first
-            # bytes of their workspace (asr_lstm_status)
-            buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-            self.bufs[key] = buf
+            # bytes of their workspace (asr_lstm_status); a workspace that grows in the
+            # middle of a step (a wider layer, a larger batch) inherits the flag
+            new = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            if buf is not None:
+                new[:256].copy_(buf[:256])
+            buf = self.bufs[key] = new
         return buf
 
 
@@ -406,12 +409,39 @@ def clip_adam_step(params, grads, m, v, segs, n_seg, norm_out, clipnorm, lr, ste
                                    nbytes, _stream()), 'asr_clip_adam_step')
 
 
-def optim_guard(norm, device):
-    """Vetoes the update that follows if a persistent recurrent kernel has flagged a timeout
-    (the sticky words at the head of the lstm_fwd / lstm_bwd workspaces); device-side only."""
-    L.check(L.load().asr_optim_guard(_ptr(norm), _ptr(WS.get('lstm_fwd', 0, device)),
-                                     _ptr(WS.get('lstm_bwd', 0, device)), _stream()),
-            'asr_optim_guard')
+def optim_guard(norm, device, flags=None):
+    """Vetoes the update that follows if a persistent recurrent kernel has flagged a timeout;
+    device-side only.  flags=None: the sticky words at the head of this process' lstm_fwd /
+    lstm_bwd workspaces; data parallel: a 2-element device tensor holding the all-reduced
+    flags (any non-zero bit pattern vetoes), so every rank skips the same update."""
+    if flags is None:
+        a, b = WS.get('lstm_fwd', 0, device), WS.get('lstm_bwd', 0, device)
+        pa, pb = _ptr(a), _ptr(b)
+    else:
+        assert flags.numel() >= 2 and flags.element_size() == 4 and flags.is_contiguous()
+        pa, pb = C.c_void_p(flags.data_ptr()), C.c_void_p(flags.data_ptr() + 4)
+    L.check(L.load().asr_optim_guard(_ptr(norm), pa, pb, _stream()), 'asr_optim_guard')
+
+
+def collect_timeout_flags(out, device):
+    """out[0:2] (float32, device) <- 1.0 where the forward / BPTT workspace's sticky timeout
+    word is set, else 0.0 (asr_timeout_flags): the form that travels through the gradient
+    all-reduce."""
+    L.check(L.load().asr_timeout_flags(_ptr(WS.get('lstm_fwd', 0, device)),
+                                       _ptr(WS.get('lstm_bwd', 0, device)), _ptr(out), _stream()),
+            'asr_timeout_flags')
+
+
+def debug_occupy(blocks, lds_bytes, seconds):
+    """Tests only: holds `blocks` 256-thread workgroups (lds_bytes of LDS each) on the device
+    for `seconds` on the current stream (asr_debug_occupy)."""
+    L.check(L.load().asr_debug_occupy(int(blocks), int(lds_bytes), float(seconds), _stream()),
+            'asr_debug_occupy')
+
+
+def clear_timeout_flags(device):
+    for name in ('lstm_fwd', 'lstm_bwd'):
+        WS.get(name, 0, device)[:4].zero_()
 
 
 def clip_sgd_step(params, grads, vel, segs, n_seg, norm_out, clipnorm, lr, momentum=0.9):

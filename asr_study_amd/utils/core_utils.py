@@ -87,6 +87,9 @@ def load_model(model_fname, return_meta=False, mode='train', **kwargs):
                                  clipnorm=oc['clipnorm'])
         model.compile(optimizer=opt)
         opt.set_state([np.asarray(s, np.float32) for s in state], it)
+        # the noise streams are keyed by the optimisation step: a resumed run continues the
+        # sequence instead of replaying it from step 0
+        model._step = int(it)
     if mode in ('eval', 'predict'):
         if kwargs.get('decoder', True):
             model.decoder = dict(is_greedy=kwargs.get('is_greedy', False),

@@ -157,7 +157,7 @@ int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes,
 /* ------------------------------------------------------------------------ */
 typedef struct asr_pack_args {
   const float* src; int rows, cols, ld;
-  const float* mask; int mask_period, mask_ld;   /* or NULL; period a power of two    */
+  const float* mask; int mask_period, mask_ld;   /* or NULL; row period (any n_pad)   */
   const float* absmax;                           /* device float, or NULL (scale 1)   */
   float* scale_out;                              /* device float, or NULL             */
   void* r_hi; void* r_lo; int ldk_r;             /* (rows, ldk_r) halfs each, or NULL */
@@ -528,6 +528,16 @@ int asr_edit_distance(const int* hyp, const int* hyp_len, int hyp_ld,
 /* asr_grad_norm and the step; the host sees the flag at its next (lagged) check, switches to   */
 /* the stepwise recurrent kernels (mode 1) and goes on with intact weights.                     */
 int asr_optim_guard(double* norm_dev, const int* flag_a, const int* flag_b, asr_stream_t stream);
+/* Data parallel, the veto has to be collective (a rank that skips an update the others apply   */
+/* diverges): out2[0] / out2[1] <- 1.0f where *flag_a / *flag_b is set, else 0.0f.  The host     */
+/* keeps out2 directly behind the flat gradient buffer, so the gradient all-reduce (C1, a sum)  */
+/* carries the flags of every rank to every rank, and then passes out2, out2 + 1 to              */
+/* asr_optim_guard (which tests for any non-zero bit pattern).                                   */
+int asr_timeout_flags(const int* flag_a, const int* flag_b, float* out2, asr_stream_t stream);
+/* Test / diagnosis only: occupies `blocks` workgroups of 256 threads with lds_bytes of LDS     */
+/* each for `seconds` (<= 5) of wall clock on `stream` -- the stand-in for a foreign kernel (an  */
+/* RCCL collective) that takes compute units while a persistent recurrence needs them all.       */
+int asr_debug_occupy(int blocks, int lds_bytes, double seconds, asr_stream_t stream);
 
 /* K11 one call per optimiser step: global gradient norm (written to norm_out  */
 /* as asr_grad_norm does) followed by the clipped Adam / SGD update, both      */

@@ -395,6 +395,7 @@ def test_lr_callbacks_and_optimizer_decay():
 
         class Fake(object):
             grads = _segs_dev = _nseg = _norm = None
+            veto_flags = staticmethod(lambda: None)
 
             class params(object):
                 device = None

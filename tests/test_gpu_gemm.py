@@ -168,7 +168,8 @@ def _hl_ref(x, s):
 
 @pytest.mark.parametrize('rows,cols,ld,period', [(300, 200, 200, 0), (128, 64, 64, 0),
                                                  (999 * 16, 80, 80, 16), (70, 1024, 1040, 32),
-                                                 (257, 40, 40, 0)])
+                                                 (257, 40, 40, 0), (480, 72, 72, 48),
+                                                 (330, 64, 64, 80)])
 def test_pack_hl_planes_both_orientations(rows, cols, ld, period):
     """asr_pack_hl: hi/lo planes equal the reference split of (src * mask) * scale bit for bit,
     in the row orientation (K = columns) and the transposed one (K = rows); padding is zero;

@@ -314,17 +314,19 @@ def test_brsmv1_layer_normalisation(with_mi):
         assert report('LN grad ' + name, gg, g) < 2e-4 * scale + 1e-6, name
 
 
-@pytest.mark.parametrize('use_masks', [False, True])
-def test_brsmv1_packed_operand_gemm_path(use_masks, monkeypatch):
+@pytest.mark.parametrize('use_masks,N', [(False, 20), (True, 20), (True, 40)])
+def test_brsmv1_packed_operand_gemm_path(use_masks, N, monkeypatch):
     """ASR_GEMM_PACKED=1 (the default from 512 hidden units on): every BiLSTM GEMM runs on
     operands packed once into split-fp16 planes (asr_pack_hl / asr_gemm_hl), dropout masks
     folded into the pack -- logits, loss and all gradients vs the oracle, and the same weights
-    after two optimiser steps as the per-tile path."""
+    after two optimiser steps as the per-tile path.  N = 40 pads to 48 rows: the mask period
+    of the pack is n_pad, a multiple of 16 but not a power of two (batch 48 / 96, the short last
+    batch of an epoch, uneven data-parallel shards)."""
     from asr_study_amd.core import models, optimizers
     rs = np.random.RandomState(21)
-    N, T, F, C, L, H = 20, 37, 16, 7, 3, 24
+    T, F, C, L, H = 37, 16, 7, 3, 24
     x, labels, lens = _batch(rs, N, T, F, C)
-    n_pad = 32
+    n_pad = (N + 15) // 16 * 16
     results = {}
     for packed in ('1', '0'):
         monkeypatch.setenv('ASR_GEMM_PACKED', packed)

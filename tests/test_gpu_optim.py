@@ -50,38 +50,77 @@ def test_adam_and_sgd(clip):
             assert np.abs(p.cpu().numpy() - p_ref[0]).max() < 2e-5
 
 
-def test_timeout_flag_vetoes_the_update_and_the_engine_falls_back_to_stepwise_kernels():
+def test_timeout_flag_vetoes_the_update_and_the_engine_falls_back_to_stepwise_kernels(monkeypatch):
     """A persistent recurrent kernel that abandons a bounded spin sets the sticky word of its
     workspace.  The update enqueued behind it is vetoed ON THE DEVICE (asr_optim_guard: the
     norm becomes -1, the update kernels return), the host sees the flag at its next check,
-    clears it, switches to the stepwise kernels (mode 1) and training goes on with the weights
-    it had -- no exception, no corrupted step."""
+    clears it, switches to the stepwise kernels (mode 1), takes the vetoed step back from the
+    optimiser's iteration count and runs the batch AGAIN -- no exception, no corrupted step,
+    no garbage metrics.  The demotion is temporary: after ASR_LSTM_RETRY_STEPS clean steps the
+    persistent kernels are tried again."""
     import torch
     from asr_study_amd import ops
     from asr_study_amd.core import models, optimizers
+    monkeypatch.setenv('ASR_LSTM_RETRY_STEPS', '3')
     rs = np.random.RandomState(0)
-    model = models.brsmv1(num_features=9, num_classes=7, num_hiddens=16, num_layers=2,
+
+    def fresh():
+        m = models.brsmv1(num_features=9, num_classes=7, num_hiddens=16, num_layers=2,
                           dropout=0.0, weight_decay=1e-4, seed=1)
-    model.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=1.0))
+        m.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=1.0))
+        return m
+    model, ref = fresh(), fresh()
     x = rs.randn(5, 30, 9).astype(np.float32)
     labels = [rs.randint(0, 6, size=4).tolist() for _ in range(5)]
     batch = [x, labels, [30] * 5]
     model.train_on_batch(batch)
-    dev = model.device
-    before = model.params.clone()
-    m_before = model.optimizer.state[0].clone()
-    ops.WS.get('lstm_bwd', 0, dev)[:4].view(torch.int32)[0] = 1      # what mark_timeout() does
-    out = model.train_on_batch(batch)                  # the step runs, its update is vetoed
-    assert np.isfinite(out[1])
-    assert torch.equal(model.params, before) and torch.equal(model.optimizer.state[0], m_before)
-    assert model.lstm_mode == 1 and model.fallbacks == 1
-    assert not ops.lstm_timeout_flags(dev).any().item()
-    out2 = model.train_on_batch(batch)                 # stepwise kernels: the update happens
-    assert not torch.equal(model.params, before) and np.isfinite(out2[0])
-    # the stepwise mode computes the same thing: compare with a fresh model on the persistent path
-    ref = models.brsmv1(num_features=9, num_classes=7, num_hiddens=16, num_layers=2,
-                        dropout=0.0, weight_decay=1e-4, seed=1)
-    ref.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=1.0))
     ref.train_on_batch(batch)
-    # (ref took 1 update, model took 1 + vetoed + 1: same Adam iteration count only for the norm)
-    assert abs(out2[1] - ref.test_on_batch(batch)[1]) < 1e-3 * max(1.0, abs(out2[1]))
+    dev = model.device
+    ops.WS.get('lstm_bwd', 0, dev)[:4].view(torch.int32)[0] = 1      # what mark_timeout() does
+    out = model.train_on_batch(batch)      # vetoed on the device, then run again stepwise
+    want = ref.train_on_batch(batch)       # the same second step on the persistent kernels
+    assert model.lstm_mode == 1 and model.fallbacks == 1 and model.vetoed_steps == 1
+    assert model.optimizer.iterations == 2 == ref.optimizer.iterations and model._step == 2
+    assert not ops.lstm_timeout_flags(dev).any().item()
+    assert np.allclose(out, want, rtol=1e-5, atol=1e-6)
+    assert (model.params - ref.params).abs().max().item() < 1e-6     # same arithmetic either mode
+    # three clean steps later the persistent kernels are back; the next gap would be doubled
+    for _ in range(3):
+        assert model.lstm_mode == 1
+        model.train_on_batch(batch)
+        ref.train_on_batch(batch)
+    model.train_on_batch(batch)
+    ref.train_on_batch(batch)
+    assert model.lstm_mode == 0 and model._retry_gap == 6 and model.fallbacks == 1
+    assert (model.params - ref.params).abs().max().item() < 1e-6
+
+
+def test_lagged_metrics_drop_vetoed_steps_and_take_their_iterations_back():
+    """fit_generator's way of stepping (sync=False, metrics fetched one step later): the step
+    that timed out AND the step already enqueued behind it are both vetoed on the device; both
+    come back as None from the lagged check, both are taken back from the iteration count,
+    the fallback is counted once."""
+    import torch
+    from asr_study_amd import ops
+    from asr_study_amd.core import models, optimizers
+    rs = np.random.RandomState(1)
+    model = models.brsmv1(num_features=9, num_classes=7, num_hiddens=16, num_layers=1,
+                          dropout=0.0, seed=1)
+    model.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=1.0))
+    x = rs.randn(4, 20, 9).astype(np.float32)
+    labels = [rs.randint(0, 6, size=3).tolist() for _ in range(4)]
+    batch = [x, labels, [20] * 4]
+    r0 = model.train_on_batch(batch, sync=False)
+    before = model.params.clone()
+    ops.WS.get('lstm_fwd', 0, model.device)[:4].view(torch.int32)[0] = 1
+    r1 = model.train_on_batch(batch, sync=False)          # times out (flag forced)
+    r2 = model.train_on_batch(batch, sync=False)          # enqueued before the host noticed
+    assert model._lagged((r0, labels, 4)) is not None
+    assert model._lagged((r1, labels, 4)) is None
+    assert model.fallbacks == 1 and model.lstm_mode == 1
+    assert model._lagged((r2, labels, 4)) is None
+    assert model.fallbacks == 1 and model.vetoed_steps == 2
+    assert torch.equal(model.params, before) and model.optimizer.iterations == 1
+    r3 = model.train_on_batch(batch, sync=False)          # stepwise kernels: a real update
+    assert model._lagged((r3, labels, 4)) is not None
+    assert not torch.equal(model.params, before) and model.optimizer.iterations == 2

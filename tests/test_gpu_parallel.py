@@ -64,6 +64,33 @@ for mode in ("1", "0", "capi", "noside", "noside0"):
     out[mode] = [float(np.abs(w).sum()) for w in model.get_weights()] + [m[0]]
     model.loss_and_grads(model.to_slab(x), labels, [40] * 6, training=False)
     out["layers_reduced_during_bptt_" + mode] = len(model._ar_covered)
+# ASR_AR_OVERLAP=auto (the default): per-layer asynchronous all-reduces only while a recurrence
+# leaves CUs free; 2 x 4 batch tiles x 32 workgroups (BiLSTM(512), batch 64) fill the chip
+os.environ.pop("ASR_AR_OVERLAP"); os.environ["ASR_COMM"] = "torch"; os.environ["ASR_OVERLAP"] = "auto"
+out["layers_reduced_during_bptt_auto_small"] = None
+model.loss_and_grads(model.to_slab(x), labels, [40] * 6, training=False)
+out["layers_reduced_during_bptt_auto_small"] = len(model._ar_covered)
+big = models.brsmv1(num_features=16, num_classes=7, num_hiddens=512, num_layers=3, dropout=0.0,
+                    seed=1)
+xb = rs.randn(64, 6, 16).astype(np.float32)
+lb = [rs.randint(0, 6, size=2).tolist() for _ in range(64)]
+big.loss_and_grads(big.to_slab(xb), lb, [6] * 64, training=False)
+out["layers_reduced_during_bptt_auto_chipfill"] = len(big._ar_covered)
+# the veto of an update is collective: the flags travel behind the gradients through the
+# all-reduce and the guard reads the reduced slots
+from asr_study_amd import ops
+model.train_on_batch([x, labels, [40] * 6])
+before = model.params.clone()
+it0 = model.optimizer.iterations
+ops.WS.get("lstm_bwd", 0, model.device)[:4].view(torch.int32)[0] = 1
+r = model.train_on_batch([x, labels, [40] * 6], sync=False)
+torch.cuda.synchronize()
+out["veto_slots"] = model._gbuf[model.n_params:].cpu().tolist()
+out["veto_params_unchanged"] = bool(torch.equal(model.params, before))
+out["veto_metrics_none"] = model._lagged((r, labels, 6)) is None
+out["veto_state"] = [model.fallbacks, model.lstm_mode, model.optimizer.iterations - it0]
+m2 = model.train_on_batch([x, labels, [40] * 6])
+out["veto_recovered"] = bool(np.isfinite(m2[0]) and not torch.equal(model.params, before))
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out))
 '''
@@ -71,8 +98,9 @@ print("RESULT " + json.dumps(out))
 
 @pytest.mark.timeout(300)
 def test_layerwise_allreduce_overlap_equals_single_allreduce():
-    """The per-layer asynchronous all-reduces issued during BPTT (ASR_AR_OVERLAP=1, default;
-    from the side stream, or from the main stream when there is none) and one all-reduce of the
+    """The per-layer asynchronous all-reduces issued during BPTT (ASR_AR_OVERLAP=1; the default
+    `auto` issues them only where a recurrence leaves CUs free; from the side stream, or from the
+    main stream when there is none) and one all-reduce of the
     whole buffer after it give the same training trajectory (world size 1 on the box's single GPU: the collective is an
     identity, what is tested is stream ordering and buffer coverage)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', ASR_FORCE_ALLREDUCE='1',
@@ -92,3 +120,106 @@ def test_layerwise_allreduce_overlap_equals_single_allreduce():
     assert res['layers_reduced_during_bptt_1'] == 2 and res['layers_reduced_during_bptt_0'] == 0
     assert res['layers_reduced_during_bptt_noside'] == 2
     assert res['layers_reduced_during_bptt_noside0'] == 0
+    assert res['layers_reduced_during_bptt_auto_small'] == 2
+    assert res['layers_reduced_during_bptt_auto_chipfill'] == 0
+    assert res['veto_slots'] == [0.0, 1.0, 0.0, 0.0] and res['veto_params_unchanged']
+    assert res['veto_metrics_none'] and res['veto_state'] == [1, 1, 0] and res['veto_recovered']
+
+
+def _cfg3_layer(T, seed=0):
+    import numpy as np
+    import torch
+    rs = np.random.RandomState(seed)
+    H, n_pad = 512, 64
+    dev = torch.device('cuda:0')
+
+    def t(*shape, scale=1.0):
+        return torch.from_numpy((rs.randn(*shape) * scale).astype(np.float32)).to(dev)
+    U = t(2, H, 4 * H, scale=0.04)
+    zx = t(T, n_pad, 2, 4 * H)
+    y = torch.zeros(T, n_pad, 2 * H, device=dev)
+    cell = torch.zeros(T, n_pad, 2, H, device=dev)
+    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    dy = t(T, n_pad, 2 * H, scale=1e-3)
+    return dict(T=T, n_pad=n_pad, H=H, U=U, zx=zx, y=y, cell=cell, gates=gates, dy=dy)
+
+
+@pytest.mark.timeout(120)
+def test_foreign_kernel_holding_cus_delays_a_chip_filling_recurrence_without_a_timeout():
+    """The hazard of a collective beside a cfg3 recurrence: 2 x 4 x 32 spin-waiting workgroups
+    need all 256 CUs.  A foreign kernel (asr_debug_occupy: the stand-in for an RCCL kernel)
+    that holds 64 CUs for 30 ms on another stream when the recurrence starts only DELAYS it --
+    the resident workgroups spin (bounded at 0.6 s) until their peers get a CU: no timeout
+    flag, bit-identical activations and gate gradients."""
+    import torch
+    from asr_study_amd import ops
+    L = _cfg3_layer(T=120)
+    dev = L['zx'].device
+    side = torch.cuda.Stream(device=dev)
+    res = []
+    for hog in (False, True):
+        for k in ('y', 'cell', 'gates'):
+            L[k].zero_()
+        dz = torch.zeros(L['T'], L['n_pad'], 2, 4 * L['H'], device=dev)
+        torch.cuda.synchronize()
+        if hog:
+            with torch.cuda.stream(side):
+                ops.debug_occupy(64, 96 * 1024, 0.03)
+        ops.lstm_seq_fwd(L['zx'], L['U'], L['y'], L['cell'], L['gates'], L['T'], L['n_pad'], L['H'])
+        if hog:
+            with torch.cuda.stream(side):
+                ops.debug_occupy(64, 96 * 1024, 0.03)
+        ops.lstm_seq_bwd(L['dy'], L['U'], L['cell'], L['gates'], dz, L['T'], L['n_pad'], L['H'])
+        torch.cuda.synchronize()
+        assert not ops.lstm_timeout_flags(dev).any().item()
+        res.append((L['y'].clone(), dz))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.timeout(240)
+def test_cu_starved_recurrence_times_out_is_vetoed_and_the_step_is_recovered():
+    """The same foreign kernel holding 64 CUs for LONGER than the spin bound (0.9 s > 0.6 s):
+    the resident workgroups of the chip-filling recurrence give up, the step's update is
+    vetoed on the device, the engine runs the batch again on the stepwise kernels and ends up
+    with the weights of an undisturbed run; the persistent kernels come back afterwards."""
+    import numpy as np
+    import torch
+    from asr_study_amd import ops
+    from asr_study_amd.core import models, optimizers
+    rs = np.random.RandomState(3)
+    N, T, F, C = 64, 24, 16, 7
+    x = rs.randn(N, T, F).astype(np.float32)
+    labels = [rs.randint(0, C - 1, size=3).tolist() for _ in range(N)]
+    batch = [x, labels, [T] * N]
+
+    def fresh():
+        m = models.brsmv1(num_features=F, num_classes=C, num_hiddens=512, num_layers=1,
+                          dropout=0.0, weight_decay=1e-4, seed=4)
+        m.compile(optimizer=optimizers.Adam(lr=1e-3, clipnorm=1.0))
+        return m
+    model, ref = fresh(), fresh()
+    os.environ['ASR_LSTM_RETRY_STEPS'] = '2'
+    try:
+        model._retry_gap = 2
+        model.train_on_batch(batch)
+        ref.train_on_batch(batch)
+        assert model._recurrence_fills_chip(64)
+        side = torch.cuda.Stream(device=model.device)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            ops.debug_occupy(64, 96 * 1024, 0.9)
+        out = model.train_on_batch(batch)
+        want = ref.train_on_batch(batch)
+        torch.cuda.synchronize()
+        assert model.fallbacks == 1 and model.vetoed_steps == 1 and model.lstm_mode == 1
+        assert model.optimizer.iterations == ref.optimizer.iterations == 2
+        assert np.allclose(out, want, rtol=1e-4, atol=1e-5)
+        assert (model.params - ref.params).abs().max().item() < 1e-5
+        for _ in range(3):
+            model.train_on_batch(batch)
+            ref.train_on_batch(batch)
+        assert model.lstm_mode == 0 and model.fallbacks == 1
+        assert (model.params - ref.params).abs().max().item() < 1e-5
+        assert not ops.lstm_timeout_flags(model.device).any().item()
+    finally:
+        os.environ.pop('ASR_LSTM_RETRY_STEPS', None)

@@ -136,7 +136,12 @@ def _ar_worker(rank, world, port, out):
     from asr_study_amd.core import engine
     parallel.init_from_env(backend='gloo')
     n = 1000
-    fake = types.SimpleNamespace(n_params=n, grads=torch.arange(n, dtype=torch.float32) * (rank + 1),
+    gbuf = torch.zeros(n + 4)
+    gbuf[:n] = torch.arange(n, dtype=torch.float32) * (rank + 1)
+
+    def collect():          # rank 1's BPTT kernel "timed out": flag slot 1 of ITS buffer
+        gbuf[n:] = torch.tensor([0.0, 1.0 if rank == 1 else 0.0, 0.0, 0.0])
+    fake = types.SimpleNamespace(n_params=n, _gbuf=gbuf, grads=gbuf[:n], _collect_flags=collect,
                                  _dist_active=lambda: True)
     # what backward() does for the layers whose gradients finish early: asynchronous
     # all-reduces of their slices, in the order the layers finish (top layer first)
@@ -144,7 +149,9 @@ def _ar_worker(rank, world, port, out):
     for lo, hi in ((700, 900), (300, 700), (120, 300)):
         fake._ar_handles.append(dist.all_reduce(fake.grads[lo:hi], async_op=True))
         fake._ar_covered.append((lo, hi))
-    w = engine.Model._allreduce(fake)      # waits, then reduces [0,120) and [900,1000)
+    w = engine.Model._allreduce(fake)      # waits, then reduces [0,120) and [900,1000) + flags
+    # the veto flags arrive on EVERY rank (the guard of rank 0 must see rank 1's timeout)
+    assert engine.Model.veto_flags(fake).tolist() == [0.0, 1.0]
     if rank == 0:
         np.save(out, np.concatenate([fake.grads.numpy(), [w]]))
     parallel.finalize()
@@ -153,7 +160,9 @@ def _ar_worker(rank, world, port, out):
 def test_engine_allreduce_covers_every_gradient_exactly_once(tmp_path):
     """engine.Model._allreduce (host bookkeeping of the overlapped per-layer all-reduce): slices
     reduced asynchronously during BPTT are waited for, the remaining slices of the flat buffer
-    (first layer, Dense head) are reduced in place, nothing twice -- world 2 over gloo."""
+    (first layer, Dense head) are reduced in place, nothing twice; the two timeout-flag slots
+    behind the gradients ride on the last collective, so a timeout on one rank vetoes the update
+    on all of them -- world 2 over gloo."""
     out = str(tmp_path / 'ar.npy')
     port = _free_port()
     mp.spawn(_ar_worker, args=(2, port, out), nprocs=2, join=True)
