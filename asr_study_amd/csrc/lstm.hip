@@ -2592,10 +2592,376 @@ lstm_bwd_kernel_x(LstmParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// backward, split-fp16, fourth generation: TWO-DIMENSIONAL split of dh = dz @ U^T (plain cell,
+// H = 256 / 512, persistent and stepwise mode).
+//
+// bwd_body_x splits the 4H-long reduction over all P = H/16 workgroups of a chain: every
+// workgroup publishes a partial dh tile for ALL H outputs (16 x H words: 32 KB at H = 512) and
+// every consumer adds P partials.  The exchange volume of a chain-step is P^2 KB -- 1 MB at
+// H = 512, 8 GB per layer, all of it written through to HBM (PMC: 8.65 GB of WRITE_SIZE per
+// launch, 3.9 x the algorithmic bytes of the kernel; the write stream, not the MFMAs or the
+// hand-off latency, set the 2.85 us step against the forward kernel's 1.89).
+//
+// Here workgroup (a, b), a < PA = H/64, b < 4, owns the reduction slice KA = gate columns of the
+// 64 units [64 a, 64 a + 64) AND the output block OB = units [OT*64 b, OT*64 (b + 1)), OT =
+// H/256: it multiplies dz[:, KA] (16 x 256) with U[OB, KA]^T and publishes the partial dh of ITS
+// block only (16 x 64 OT words: 8 KB at H = 512).  The published volume is PA partial sums
+// instead of P (4 x less: 2 MB per step at cfg3); the price is that the four workgroups (a, 0..3)
+// each need dz[:, KA], i.e. each runs the gate-gradient arithmetic of the same 64 units (four
+// (sample, unit) pairs per thread instead of one).  Everything of that arithmetic that does not
+// depend on the recurrent gradient (tanh(c), the activation slopes) is computed BEFORE the
+// step's gather is awaited, so it overlaps the hand-off.
+//  * thread (n = tid >> 4, q = tid & 15) owns sample n, units 64 a + 4 q .. + 3; a gathered
+//    16-byte group IS its four recurrent gradients (no cross-lane reduction);
+//  * wave w multiplies output tiles w + 4 i (i < OT) over the 8 K-steps of the slice; the dz tile
+//    (hi / lo halfs, 16 x 256, per-sample power-of-two scale) lives in LDS, B fragments in VGPRs,
+//    the U^T fragments in 64 OT AGPRs for the whole sequence;
+//  * a workgroup's progress depends on its peers only through TWO hops (its producers'
+//    producers are all workgroups), so it can be two steps ahead of a consumer: FOUR exchange
+//    slots (step & 3) and the tag = bit 2 of the absolute step;
+//  * the dz slab row of sample n is written by workgroup b = n & 3, the bias-gradient partials of
+//    unit 4 q + b by workgroup b, dc_state / max|dz| by b = 0.
+// Arithmetic per (sample, unit): the same products as bwd_body_x, summed in a different order
+// (PA partials of 256 columns instead of P of 64), per-sample scale over 256 columns.
+__device__ __forceinline__ void mfma3_first(f32x4& am, f32x4& a1, f32x4& a2, const f32x4& uh,
+                                            const f32x4& ul, const h8& bh, const h8& bl) {
+  asm volatile(
+      "v_mfma_f32_16x16x32_f16 %0, %3, %5, 0\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %3, %6, 0\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %4, %5, 0"
+      : "=&v"(am), "=&v"(a1), "=&v"(a2)
+      : "a"(uh), "a"(ul), "v"(bh), "v"(bl));
+}
+__device__ __forceinline__ void mfma3_acc(f32x4& am, f32x4& a1, f32x4& a2, const f32x4& uh,
+                                          const f32x4& ul, const h8& bh, const h8& bl) {
+  asm volatile(
+      "v_mfma_f32_16x16x32_f16 %0, %3, %5, %0\n\t"
+      "v_mfma_f32_16x16x32_f16 %1, %3, %6, %1\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %4, %5, %2"
+      : "+v"(am), "+v"(a1), "+v"(a2)
+      : "a"(uh), "a"(ul), "v"(bh), "v"(bl));
+}
+// an MFMA's D needs its pass count + 4 wait states before a VALU may read it
+__device__ __forceinline__ void mfma_settle(f32x4& am, f32x4& a1, f32x4& a2) {
+  asm volatile("s_nop 13" : "+v"(am), "+v"(a1), "+v"(a2));
+}
+
+template <int OT, bool FAST>
+__device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw, float* lds) {
+  constexpr int PA = 4 * OT;                       // reduction slices (H / 64)
+  constexpr int KS = 8;                            // K-steps of 32 columns per slice
+  constexpr int NTILE = 4 * OT;                    // output tiles of a workgroup
+  constexpr int DZS = 264;                         // LDS row stride of the dz tile (halfs)
+  constexpr int kBufFloats = 16 + (2 * 16 * DZS) / 2;         // sinv + hi + lo
+  constexpr int kSlotWords = 4 * NTILE * PA * 256;            // one exchange slot of a chain
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, nl = lane & 15;
+  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
+  const int a = cw % PA, b = cw / PA;
+  const int dir = unit / p.NB, bt = unit % p.NB;
+
+  f32x4 ufh[OT][KS], ufl[OT][KS];                  // bit patterns of 8 halfs each (AGPRs)
+#pragma unroll
+  for (int i = 0; i < OT; ++i) {
+    const int orow = 64 * OT * b + 16 * (w + 4 * i) + nl;     // output unit of this lane's A row
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      h8 hv, lv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 256 * a + 32 * kk + 8 * g + e;
+        _Float16 hi, lo;
+        split_f16(p.U[((size_t)(dir * H + orow)) * H4 + j], hi, lo);
+        hv[e] = hi; lv[e] = lo;
+      }
+      ufh[i][kk] = __builtin_bit_cast(f32x4, hv);
+      ufl[i][kk] = __builtin_bit_cast(f32x4, lv);
+      asm volatile("" : "+a"(ufh[i][kk]), "+a"(ufl[i][kk]));   // AGPR-class from here on
+    }
+  }
+  const int n = tid >> 4, q = tid & 15;
+  const int cn = bt * 16 + n;                      // slab row (sample) of this thread
+  const int u0 = 64 * a + 4 * q;                   // its first unit
+  const int s_end = p.s_begin + p.s_count;
+  unsigned* xch = p.xbuf + (size_t)(dir * p.NB + bt) * p.xchain_words;
+  float4 cmask = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (p.mask_u)
+    cmask = *reinterpret_cast<const float4*>(p.mask_u + ((size_t)dir * p.n_pad + cn) * H + u0);
+  float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.s_begin > 0)
+    dc = *reinterpret_cast<const float4*>(p.dc_state + ((size_t)dir * p.n_pad + cn) * H + u0);
+  float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias-gradient partials of unit u0 + b
+  float zmax = 0.f;
+  bool dead = false;
+
+  // slab values of the NEXT step, prefetched one step ahead (c_prev of a step is c of the next)
+  float4 nx_dy, nx_c, nx_cp, nx_g[4];
+  auto slab_row = [&](int ss, bool& has_prev, size_t& row, size_t& prow) {
+    const int sc = ss < s_end ? ss : s_end - 1;    // past the end: a valid, unused row
+    const int tt = dir == 0 ? p.T - 1 - sc : sc;
+    has_prev = sc + 1 < p.T;                       // the sequence's first frame has c_prev = 0
+    const int tcc = has_prev ? (dir == 0 ? tt - 1 : tt + 1) : tt;
+    row = (size_t)tt * p.n_pad + cn;
+    prow = (size_t)tcc * p.n_pad + cn;
+  };
+  auto load_slabs = [&](int ss, bool first) {
+    bool has_prev; size_t row, prow;
+    slab_row(ss, has_prev, row, prow);
+    nx_dy = *reinterpret_cast<const float4*>(p.dy + row * H2 + dir * H + u0);
+    // c of step ss is c_prev of step ss - 1 (already in registers), except at a launch's start
+    if (first) nx_c = *reinterpret_cast<const float4*>(p.cell + (row * 2 + dir) * H + u0);
+    else nx_c = nx_cp;
+    const float4 cp = *reinterpret_cast<const float4*>(p.cell + (prow * 2 + dir) * H + u0);
+    nx_cp = has_prev ? cp : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      nx_g[j] = *reinterpret_cast<const float4*>(p.gates + (row * 2 + dir) * H4 + 4 * (u0 + j));
+  };
+  load_slabs(p.s_begin, true);
+
+  // gather: the 16-byte group (sample n, units 4 q ..) of the partial tiles of the PA producers
+  // (a', a / OT), 1 KB apart (immediates of one offset register)
+  constexpr int NL = PA;
+  const unsigned goff = (unsigned)(((((a / OT) * NTILE + 4 * (a % OT) + (q >> 2)) * PA) * 256 +
+                                    n * 16 + (q & 3) * 4) * 4);
+  u32x4 v[NL];
+  auto rslot = [&](int ss) -> __amdgpu_buffer_rsrc_t {
+    return __builtin_amdgcn_make_buffer_rsrc(xch + (size_t)(ss & 3) * kSlotWords, 0,
+                                             kSlotWords * 4, 0x00020000);
+  };
+  auto load_groups = [&](const __amdgpu_buffer_rsrc_t& rsrc) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff, i * 1024, FAST ? kNt : kSc1);
+  };
+  auto issue = [&](int ss) {
+    for (int i = 0; i < p.prepoll; ++i) __builtin_amdgcn_s_sleep(1);
+    load_groups(rslot(ss));
+  };
+  auto await = [&](int ss) {
+    const unsigned flip = 0u - ((unsigned)(ss >> 2) & 1u);
+    bool stale = !all_tagged<NL>(v, flip);
+    if (__builtin_amdgcn_ballot_w64(stale) == 0ull) return;
+    if (!p.poll || dead) return;
+    const __amdgpu_buffer_rsrc_t rsrc = rslot(ss);
+    const long long t0 = wall_clock64();
+    bool gave_up = false;
+    while (stale) {
+      for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
+      load_groups(rsrc);
+      stale = !all_tagged<NL>(v, flip);
+      if (stale && wall_clock64() - t0 > kSpinTicks) { gave_up = true; break; }
+    }
+    if (__builtin_amdgcn_ballot_w64(gave_up) != 0ull) {
+      dead = true;
+      if (gave_up) mark_timeout(p.status);
+    }
+  };
+
+  // factors of one step that do not depend on the recurrent gradient (computed while the
+  // gather is in flight): dz_o = dh A_o ; dcc = dc + dh B ; dz_{i,f,g} = dcc C_{i,f,g} ; dc' = dcc gf
+  struct Pre { float4 dy, Ao, B, Ci, Cf, Cg, gf; };
+  auto precompute = [&]() -> Pre {
+    Pre r;
+    r.dy = nx_dy;
+    const float cc[4] = {nx_c.x, nx_c.y, nx_c.z, nx_c.w};
+    const float cp[4] = {nx_cp.x, nx_cp.y, nx_cp.z, nx_cp.w};
+    float Ao[4], B[4], Ci[4], Cf[4], Cg[4], gf_[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gi = nx_g[j].x, gf = nx_g[j].y, gg = nx_g[j].z, go = nx_g[j].w;
+      const float tch = fast_tanh(cc[j]);
+      Ao[j] = tch * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
+      B[j] = go * (1.f - tch * tch);
+      Ci[j] = gg * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
+      Cf[j] = cp[j] * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
+      Cg[j] = gi * (1.f - gg * gg);
+      gf_[j] = gf;
+    }
+    r.Ao = make_float4(Ao[0], Ao[1], Ao[2], Ao[3]);
+    r.B = make_float4(B[0], B[1], B[2], B[3]);
+    r.Ci = make_float4(Ci[0], Ci[1], Ci[2], Ci[3]);
+    r.Cf = make_float4(Cf[0], Cf[1], Cf[2], Cf[3]);
+    r.Cg = make_float4(Cg[0], Cg[1], Cg[2], Cg[3]);
+    r.gf = make_float4(gf_[0], gf_[1], gf_[2], gf_[3]);
+    return r;
+  };
+
+  // everything of one step after its recurrent gradient is known: gate gradients of the four
+  // units, dz slab + LDS tile, barrier, partial dh tiles of this block, publish, next gather
+  auto tail = [&](int s, const Pre& pre, const float4& dh_rec, bool do_issue) {
+    float* sinv = lds + (size_t)(s & 1) * kBufFloats;         // [16] 1 / scale
+    _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZS] hi
+    _Float16* dzl = dzh + 16 * DZS;                           // [16][DZS] lo
+    const int t = dir == 0 ? p.T - 1 - s : s;
+    load_slabs(s + 1, false);
+    float z[4][4];
+    {
+      const float dy[4] = {pre.dy.x, pre.dy.y, pre.dy.z, pre.dy.w};
+      const float dr[4] = {dh_rec.x, dh_rec.y, dh_rec.z, dh_rec.w};
+      const float cm[4] = {cmask.x, cmask.y, cmask.z, cmask.w};
+      const float Ao[4] = {pre.Ao.x, pre.Ao.y, pre.Ao.z, pre.Ao.w};
+      const float B[4] = {pre.B.x, pre.B.y, pre.B.z, pre.B.w};
+      const float Ci[4] = {pre.Ci.x, pre.Ci.y, pre.Ci.z, pre.Ci.w};
+      const float Cf[4] = {pre.Cf.x, pre.Cf.y, pre.Cf.z, pre.Cf.w};
+      const float Cg[4] = {pre.Cg.x, pre.Cg.y, pre.Cg.z, pre.Cg.w};
+      const float gf[4] = {pre.gf.x, pre.gf.y, pre.gf.z, pre.gf.w};
+      float dcv[4] = {dc.x, dc.y, dc.z, dc.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dh = dy[j] + cm[j] * dr[j];
+        const float dcc = dcv[j] + dh * B[j];
+        z[j][0] = dcc * Ci[j];
+        z[j][1] = dcc * Cf[j];
+        z[j][2] = dcc * Cg[j];
+        z[j][3] = dh * Ao[j];
+        dcv[j] = dcc * gf[j];
+      }
+      dc = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
+    }
+    if ((n & 3) == b) {                            // this workgroup's rows of the dz slab
+      float* dst = p.dz + (((size_t)t * p.n_pad + cn) * 2 + dir) * H4 + 4 * u0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float4*>(dst + 4 * j) = make_float4(z[j][0], z[j][1], z[j][2], z[j][3]);
+    }
+    // (b is uniform: scalar branches, no indexed access)
+    if (b == 0) { gsum.x += z[0][0]; gsum.y += z[0][1]; gsum.z += z[0][2]; gsum.w += z[0][3]; }
+    else if (b == 1) { gsum.x += z[1][0]; gsum.y += z[1][1]; gsum.z += z[1][2]; gsum.w += z[1][3]; }
+    else if (b == 2) { gsum.x += z[2][0]; gsum.y += z[2][1]; gsum.z += z[2][2]; gsum.w += z[2][3]; }
+    else { gsum.x += z[3][0]; gsum.y += z[3][1]; gsum.z += z[3][2]; gsum.w += z[3][3]; }
+    // power-of-two scale of this sample's 256 columns: max over its 16 threads (one DPP row)
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(z[j][0]), fabsf(z[j][1])), fmaxf(fabsf(z[j][2]), fabsf(z[j][3]))));
+    zmax = fmaxf(zmax, m);
+    m = row16_max(m);
+    int ex = 0;
+    if (m > 0.f) (void)frexpf(m, &ex); else ex = 9;
+    ex = ex < -100 ? -100 : ex;                    // keep 2^(9-ex) finite for denormal maxima
+    const float sc = ldexpf(1.f, 9 - ex);
+    if (q == 0) sinv[n] = ldexpf(1.f, ex - 9);
+    {
+      h8 hi8[2], lo8[2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 x, y;
+          split_f16(z[j][e] * sc, x, y);
+          hi8[j >> 1][4 * (j & 1) + e] = x;
+          lo8[j >> 1][4 * (j & 1) + e] = y;
+        }
+      _Float16* rh = dzh + n * DZS + 16 * q;
+      _Float16* rl = dzl + n * DZS + 16 * q;
+      *reinterpret_cast<h8*>(rh) = hi8[0];
+      *reinterpret_cast<h8*>(rh + 8) = hi8[1];
+      *reinterpret_cast<h8*>(rl) = lo8[0];
+      *reinterpret_cast<h8*>(rl + 8) = lo8[1];
+    }
+    __syncthreads();
+    {
+      h8 bh[KS], bl[KS];
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        bh[kk] = *reinterpret_cast<const h8*>(dzh + nl * DZS + 32 * kk + 8 * g);
+        bl[kk] = *reinterpret_cast<const h8*>(dzl + nl * DZS + 32 * kk + 8 * g);
+      }
+      const float us = sinv[nl];
+      const float usl = us * (1.f / kLoScale);
+      const unsigned wtag = (unsigned)(s >> 2) & 1u;
+      // (the last step's tiles are published too: nobody reads them, and no branch is needed)
+      const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+          xch + (size_t)(s & 3) * kSlotWords, 0, kSlotWords * 4, 0x00020000);
+      const unsigned soff = (unsigned)((((b * NTILE + w) * PA + a) * 256 + nl * 16 + 4 * g) * 4);
+#pragma unroll
+      for (int i = 0; i < OT; ++i) {
+        f32x4 am, a1, a2;
+        mfma3_first(am, a1, a2, ufh[i][0], ufl[i][0], bh[0], bl[0]);
+#pragma unroll
+        for (int kk = 1; kk < KS; ++kk) mfma3_acc(am, a1, a2, ufh[i][kk], ufl[i][kk], bh[kk], bl[kk]);
+        mfma_settle(am, a1, a2);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = tag_word(__builtin_fmaf(a1[e] + a2[e], usl, am[e] * us), wtag);
+        // output tile w + 4 i of this block: 4 PA KB further on
+        __builtin_amdgcn_raw_buffer_store_b128(o, wr, soff, i * (4 * PA * 1024), FAST ? 0 : kSc1);
+      }
+    }
+    if (do_issue) issue(s);
+  };
+
+  int s = p.s_begin;
+  if (s == 0) {
+    // step 0: no recurrent gradient yet, nothing to gather
+    const Pre pre = precompute();
+    tail(0, pre, make_float4(0.f, 0.f, 0.f, 0.f), false);
+    s = 1;
+  }
+  if (s < s_end) {
+    issue(s - 1);
+    for (; s < s_end; ++s) {
+      const Pre pre = precompute();                // overlaps the hand-off
+      await(s - 1);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {               // (the tag bit stays in: <= 1 ulp)
+        acc.x += __uint_as_float(v[i][0]); acc.y += __uint_as_float(v[i][1]);
+        acc.z += __uint_as_float(v[i][2]); acc.w += __uint_as_float(v[i][3]);
+      }
+      tail(s, pre, acc, true);                     // (after the last step a harmless unused read)
+    }
+  }
+  if (b == 0)
+    *reinterpret_cast<float4*>(p.dc_state + ((size_t)dir * p.n_pad + cn) * H + u0) = dc;
+  if (p.db_part) {
+    // sum over the 16 samples of every thread's float4 (unit u0 + b), fixed order
+    float vs[4] = {gsum.x, gsum.y, gsum.z, gsum.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                  // over the wave's four samples (lane >> 4)
+      vs[k] += __shfl_xor(vs[k], 16);
+      vs[k] += __shfl_xor(vs[k], 32);
+    }
+    __syncthreads();
+    if (lane < 16) *reinterpret_cast<float4*>(lds + (w * 16 + lane) * 4) =
+        make_float4(vs[0], vs[1], vs[2], vs[3]);
+    __syncthreads();
+    if (tid < 64) {                                // (unit quad tid >> 2, gate tid & 3)
+      const float tsum = ((lds[tid] + lds[64 + tid]) + lds[128 + tid]) + lds[192 + tid];
+      float* dst = p.db_part + ((size_t)bt * 2 + dir) * H4 + 256 * a + 16 * (tid >> 2) + 4 * b +
+                   (tid & 3);
+      *dst = (p.s_begin > 0 ? *dst : 0.f) + tsum;
+    }
+    __syncthreads();
+  }
+  if (p.dz_absmax && b == 0) {
+    zmax = asr_wave_max(zmax);
+    if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
+  }
+}
+
+template <int OT>
+__global__ void __launch_bounds__(kThreads)
+lstm_bwd_kernel_c(LstmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int unit_local, cw;
+  if (!map_block(p, unit_local, cw)) return;
+  const int unit = p.chain_begin + unit_local;
+  const bool fast = chain_on_one_xcd(p, unit, cw, reinterpret_cast<int*>(lds));
+  if (fast) bwd_body_c<OT, true>(p, unit, cw, lds);
+  else bwd_body_c<OT, false>(p, unit, cw, lds);
+}
+
+// ---------------------------------------------------------------------------
 struct Plan {
   int R, P, TPW, MAXR, NKK, prec;
   int pair;                // 1: a workgroup serves two batch tiles (lstm_fwd_kernel_k2)
   int n1;                  // 1: single-utterance forward kernel (2 chains = 2 directions)
+  int form_c;              // 1: BPTT with the two-dimensional split (lstm_bwd_kernel_c)
   size_t shm;
   size_t xchain_words;
   int chains_per_launch;
@@ -2714,6 +3080,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   pl.NKK = 0;
   pl.pair = 0;
   pl.n1 = 0;
+  pl.form_c = 0;
   if (!bwd && a->n_valid == 1 && a->mode == 0 && (H == 256 || H == 512) &&
       !(a->mi || a->zone_c || a->zone_h || a->uh) && env_int("ASR_LSTM_N1", 1)) {
     // one utterance: the tile-free exact-fp32 kernel (fwd_body_n1); 2 chains = 2 directions
@@ -2787,7 +3154,17 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       const bool even = (a->n_pad / 16) % 2 == 0;
       const int pair_b = env_int("ASR_LSTM_PAIR_B", 0);
       const int place_b = env_int("ASR_LSTM_PAIR_PLACE_B", 1);
-      if (wide && gen >= 3) {
+      // ASR_LSTM_BWD_2D: 1 = the two-dimensional split (bwd_body_c), 0 = bwd_body_x;
+      // default: from H = 512 on, where the partial-tile exchange of bwd_body_x is 1 MB per
+      // chain-step
+      const bool form_c = wide && env_int("ASR_LSTM_BWD_2D", H >= 512 ? 1 : 0) != 0 && gen >= 3;
+      if (form_c) {
+        pl.pair = 0;
+        pl.form_c = 1;
+        pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 264 * 2);
+        pl.xchain_words = (size_t)4 * 4 * (H / 64) * (H / 64) * 256;
+        k = H == 256 ? lstm_bwd_kernel_c<1> : lstm_bwd_kernel_c<2>;
+      } else if (wide && gen >= 3) {
         pl.pair = (pair_b && even) ? 1 : 0;
         k = pick_bwd_x(pl.TPW, pl.pair ? 2 : 1, place_b);
       } else if (wide && gen == 2 && pair_b && even) {

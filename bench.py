@@ -397,17 +397,37 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # the persistent kernels must not have abandoned a spin
+    # the persistent kernels must not have abandoned a spin -- on ANY rank (a timed-out step is
+    # vetoed on every rank through the flag slots of the gradient all-reduce; a run with one is
+    # not a measurement)
+    timeouts = int(ops.lstm_timeout_flags(dev).ne(0).sum().item()) + int(model.fallbacks)
+    ranks_seen = 1
+    if world > 1 or force_dist:
+        t = torch.tensor([float(timeouts), 1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        timeouts, ranks_seen = int(t[0].item()), int(t[1].item())
+        assert ranks_seen == world, 'RCCL saw %d ranks, WORLD_SIZE is %d' % (ranks_seen, world)
+    assert timeouts == 0, ('%d recurrent-kernel timeout(s) / fallback(s) during the timed steps: '
+                           'not a valid measurement' % timeouts)
     for name in ('lstm_fwd', 'lstm_bwd'):
         ops.lstm_status(ops.WS.get(name, 0, dev))
     ctc = out[0].cpu().numpy()
     assert np.all(np.isfinite(ctc)), 'non-finite CTC loss in the benchmark step'
 
-    extra = {}
+    extra = {'fallbacks': timeouts, 'ranks_seen_by_rccl': ranks_seen}
+    # modelled cost of the step's ONE gradient all-reduce over xGMI at 8 ranks (7 links x ~153
+    # GB/s per GPU, point to point): a ring moves 2 (n-1)/n S over one link per direction; a
+    # direct reduce-scatter + all-gather uses all 7
+    gbytes = (model.n_params + 4) * 4
+    extra['allreduce_model'] = {
+        'bytes': gbytes, 'schedule': 'one collective over the flat buffer after BPTT where a '
+        'recurrence fills the chip (ASR_AR_OVERLAP=auto), per-layer async beside BPTT otherwise',
+        'ring_8gpu_ms': round(2.0 * 7 / 8 * gbytes / 77e9 * 1e3, 3),
+        'direct_8gpu_ms': round(2.0 * 7 / 8 * gbytes / (7 * 77e9) * 1e3, 3)}
     if world > 1:
         # ---- bus bandwidth of the gradient all-reduce (outside the timed region): the flat
         # fp32 gradient buffer, as one collective; bus = 2 (n-1)/n * bytes / time
-        g = model.grads
+        g = model._gbuf
         for _ in range(2):
             dist.all_reduce(g)
         torch.cuda.synchronize()
@@ -421,12 +441,13 @@ def main():
         torch.cuda.synchronize()
         ar_ms = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=dev)
         dist.all_reduce(ar_ms, op=dist.ReduceOp.MAX)
+        model._gbuf[model.n_params:].zero_()
         nbytes = g.numel() * 4
         extra['allreduce'] = {
             'bytes': nbytes, 'ms': round(float(ar_ms.item()), 4),
             'bus_GBps': round(2.0 * (world - 1) / world * nbytes / (float(ar_ms.item()) * 1e-3) / 1e9, 2),
             'backend': 'rccl (torch.distributed nccl)', 'note': 'one fp32 all-reduce of the flat '
-            'gradient buffer; in the step it is bucketed per layer and overlapped with BPTT'}
+            'gradient buffer (+ the timeout-flag slots), exactly as the step issues it'}
     if rank == 0:
         # ---- secondary roofline figures (outside the timed region): the gate GEMM of
         # a middle layer and the CTC loss+gradient, each timed with HIP events
@@ -591,6 +612,8 @@ def main():
                                                      'recurrence of one BiLSTM layer)'),
         }
         line.update(extra)
+        line['allreduce_model']['ring_share_of_step'] = round(
+            line['allreduce_model']['ring_8gpu_ms'] / ms, 4)
         # `roofline` is the family with the largest share of the step: the BPTT recurrence, the
         # forward recurrence or the GEMMs (all three stay in the line under their own keys)
         gr = gemm_roof()

@@ -35,6 +35,11 @@ CASES = {
     # BASELINE.json configs[2]'s topology, a 16-utterance slice of its batch
     'cfg3_n16': dict(F=80, H=512, L=5, C=28, N=16, feat=('logfbank', {'num_filt': 80}),
                      ragged=False, masks=False),
+    # BASELINE.json configs[2] at FULL size: the bench's whole batch of 64 x 10 s.  The rows of
+    # a batch are independent (no cross-sample op in the path), so the generator runs the
+    # float64 oracle on four 16-utterance slices and adds their gradients (each scaled 1/64)
+    'cfg3': dict(F=80, H=512, L=5, C=28, N=64, feat=('logfbank', {'num_filt': 80}),
+                 ragged=False, masks=False, slices=4),
 }
 LOGIT_FRAMES = 50          # frames (spread over T) whose logits a fixture keeps
 GRAD_SAMPLES = 1000        # sampled entries per gradient tensor

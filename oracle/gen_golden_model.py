@@ -55,8 +55,33 @@ def run(name):
     x = case['x'].astype(np.float64)
     print('[%s] inputs built in %.0f s; running the float64 oracle ...' % (name, time.time() - t0),
           flush=True)
-    out = OL.loss_and_grads(params, x, case['labels'], case['lens'], weight_decay=0.0,
-                            masks=masks)
+    ns = int(cfg.get('slices', 1))
+    if ns == 1:
+        out = OL.loss_and_grads(params, x, case['labels'], case['lens'], weight_decay=0.0,
+                                masks=masks)
+    else:
+        # independent batch rows: slice the batch, add the gradients (each slice's gradient is
+        # that of ITS mean: weight n_slice / N); states are kept for the first slice only
+        assert masks is None and N % ns == 0 and N // ns >= FC.STATE_UTTS
+        per = N // ns
+        out = None
+        for k in range(ns):
+            sl = slice(k * per, (k + 1) * per)
+            o = OL.loss_and_grads(params, x[:, sl], case['labels'][sl], case['lens'][sl],
+                                  weight_decay=0.0)
+            gl = [(n, np.asarray(g, np.float64) * (per / float(N))) for n, g in OL.flatten(o['grads'])]
+            if out is None:
+                out = dict(ctc=list(o['ctc']), logits=[o['logits']], glist=gl,
+                           caches={'layers': [{d: {k2: lc[d][k2][:, :FC.STATE_UTTS].copy()
+                                                   for k2 in ('hs', 'cs')} for d in ('fwd', 'bwd')}
+                                              for lc in o['caches']['layers']]})
+            else:
+                out['ctc'] += list(o['ctc'])
+                out['logits'].append(o['logits'])
+                out['glist'] = [(n, a + b) for (n, a), (_, b) in zip(out['glist'], gl)]
+            del o
+            print('[%s] slice %d/%d done (%.0f s)' % (name, k + 1, ns, time.time() - t0), flush=True)
+        out['logits'] = np.concatenate(out['logits'], axis=1)
     logits = out['logits']
     fix = {}
     fr = FC.logit_frames(T)
@@ -73,12 +98,13 @@ def run(name):
         dec[n, :len(h)] = h
     fix['greedy'] = dec
     fix['greedy_len'] = np.array([len(h) for h in hyp], np.int32)
-    for i, (gname, g) in enumerate(OL.flatten(out['grads'])):
+    glist = out['glist'] if 'glist' in out else OL.flatten(out['grads'])
+    for i, (gname, g) in enumerate(glist):
         flat = np.asarray(g, np.float64).reshape(-1)
         idx = FC.grad_sample_index(i, flat.size)
         fix['g%02d_samples' % i] = flat[idx]
         fix['g%02d_stats' % i] = np.array([np.sqrt(np.sum(flat ** 2)), np.abs(flat).max()])
-    fix['grad_names'] = np.array([n for n, _ in OL.flatten(out['grads'])])
+    fix['grad_names'] = np.array([n for n, _ in glist])
     sf = FC.state_frames(T)
     for li in (0, L - 1):
         lc = out['caches']['layers'][li]

@@ -485,6 +485,55 @@ def test_recurrent_kernel_generations_agree_and_bptt_emits_bias_gradient(N, H, m
         assert np.array_equal(paired, again)
 
 
+@pytest.mark.parametrize('N,H', [(64, 512), (16, 512), (32, 256), (48, 256)])
+def test_bptt_two_dimensional_split_matches_the_one_dimensional_kernel(N, H, monkeypatch):
+    """lstm_bwd_kernel_c (ASR_LSTM_BWD_2D=1, the default at H = 512: workgroup (a, b) owns the
+    reduction slice of 64 units AND one of four output blocks, publishes H/64 partial sums
+    instead of H/16, four exchange slots) against lstm_bwd_kernel_x on the same activations:
+    the same products summed in another order -> gate gradients to 1e-6 of the largest, max|dz|
+    exact; sliced == whole and both transports bit for bit; db_part == the sums of the dz slab;
+    rows of padding samples stay zero; with a recurrent-dropout mask."""
+    from asr_study_amd import ops
+    T = 53
+    rs = np.random.RandomState(3 * H + N)
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.1).astype(np.float32)).to(dev)
+    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
+    y = torch.zeros(T, n_pad, 2 * H, device=dev)
+    cell = torch.zeros(T, n_pad, 2, H, device=dev)
+    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    ops.lstm_status(ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask))
+
+    def run(ranges):
+        dz = torch.full((T, n_pad, 2, 4 * H), 7.0, device=dev)
+        dbp = torch.full((n_pad // 16, 2, 4 * H), 9.0, device=dev)
+        amax = torch.zeros(1, device=dev)
+        for r in ranges:
+            ws = ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=mask,
+                                  dz_absmax=amax, steps=r, db_part=dbp)
+        ops.lstm_status(ws)
+        want = dz.double().reshape(T, n_pad // 16, 16, 2, 4 * H).sum(dim=(0, 2))
+        err = (dbp.double() - want).abs().max().item()
+        assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+        return dz.cpu().numpy(), amax.cpu().numpy()
+    monkeypatch.setenv('ASR_LSTM_BWD_2D', '0')
+    want, amax0 = run([None])
+    monkeypatch.setenv('ASR_LSTM_BWD_2D', '1')
+    got, amax = run([None])
+    err = report('dz 2-D vs 1-D split N%d H%d' % (N, H), got, want)
+    assert err < 1e-6 * np.abs(want).max()
+    assert np.abs(got).max() == amax[0] and abs(amax[0] - amax0[0]) < 1e-6 * amax0[0]
+    sliced, amax2 = run([(0, 1), (1, 2), (3, 17), (20, 33)])
+    assert np.array_equal(got, sliced) and amax2[0] == amax[0]
+    for transport in ('0', '1'):
+        monkeypatch.setenv('ASR_LSTM_FAST', transport)
+        again, _ = run([None])
+        assert np.array_equal(got, again), transport
+
+
 @pytest.mark.parametrize('H', [256, 512])
 def test_single_utterance_forward_kernel(H):
     """asr_lstm_args.n_valid = 1 (predict.py: one utterance per call): the tile-free exact-fp32

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Reads bench.py JSON lines on stdin and prints the headline figures compactly."""
+"""Reads bench.py JSON lines (file argument or stdin) and prints the headline figures compactly."""
 import json
 import sys
-for ln in sys.stdin:
+for ln in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
     ln = ln.strip()
     if not ln.startswith('{'):
         continue
