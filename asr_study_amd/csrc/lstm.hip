@@ -120,6 +120,34 @@ __device__ __forceinline__ void mark_timeout(int* status) {
   atomicExch(status - kStickyInts, 1);
 }
 
+// Debug (ASR_LSTM_DBG & 32): shader-clock ticks per phase of a step, accumulated over the
+// steps of a launch by the four waves of workgroup 0 of the launch's first chain; six phases
+// per wave at status + 16 ints (asr_lstm_profile).  `on` is wave-uniform.
+struct StepProf {
+  bool on;
+  long long pt[6], last;
+  __device__ __forceinline__ void init(bool enable) {
+    on = enable;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pt[i] = 0;
+    last = on ? (long long)__builtin_readcyclecounter() : 0;
+  }
+  __device__ __forceinline__ void stamp(int i) {
+    if (on) {
+      const long long now = (long long)__builtin_readcyclecounter();
+      pt[i] += now - last;
+      last = now;
+    }
+  }
+  __device__ __forceinline__ void flush(int* status, int w) const {
+    if (on && (threadIdx.x & 63) == 0) {
+      long long* out = reinterpret_cast<long long*>(status + 16) + 6 * w;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) out[i] = pt[i];
+    }
+  }
+};
+
 __device__ __forceinline__ float hard_sigmoid(float x) {
   return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f);
 }
@@ -128,6 +156,12 @@ __device__ __forceinline__ float fast_tanh(float x) {
   const float xc = fminf(fmaxf(x, -15.f), 15.f);
   const float e = __expf(2.f * xc);
   return __fdividef(e - 1.f, e + 1.f);
+}
+// the same with v_rcp_f32 instead of the IEEE division sequence (1 ulp of the quotient)
+__device__ __forceinline__ float fast_tanh_rcp(float x) {
+  const float xc = fminf(fmaxf(x, -15.f), 15.f);
+  const float e = __expf(2.f * xc);
+  return (e - 1.f) * __builtin_amdgcn_rcpf(e + 1.f);
 }
 __device__ __forceinline__ unsigned tag_word(float v, unsigned tag) {
   return (__float_as_uint(v) & ~1u) | tag;
@@ -414,7 +448,7 @@ __device__ __forceinline__ void fwd_body(const LstmParams& p, int chain, int wg,
     }
   }
   if (prof) {
-    long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
+    long long* out = reinterpret_cast<long long*>(p.status + 16) + 6 * w;
     for (int i = 0; i < 4; ++i) out[i] = pt[i];
   }
 }
@@ -628,7 +662,7 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
     }
   }
   if (prof) {
-    long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
+    long long* out = reinterpret_cast<long long*>(p.status + 16) + 6 * w;
     for (int i = 0; i < 4; ++i) out[i] = pt[i];
   }
 }
@@ -864,7 +898,7 @@ __device__ __forceinline__ void fwd_body_k(const LstmParams& p, int chain, int w
     }
   }
   if (prof) {
-    long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
+    long long* out = reinterpret_cast<long long*>(p.status + 16) + 6 * w;
     for (int i = 0; i < 4; ++i) out[i] = pt[i];
   }
 }
@@ -1230,6 +1264,8 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
   const unsigned goff = (unsigned)(((kbase + 8 * g) / 4) * p.xstride + nl * 16);
   const unsigned gstep = (unsigned)p.xstride;      // between the two halves of a kk
   bool dead = false;
+  StepProf prof;
+  prof.init(false);
   u32x4 v[NT][NL];
   // the exchange slot holding h of step `ss` of tile x
   auto slot = [&](int x, int ss) -> __amdgpu_buffer_rsrc_t {
@@ -1287,7 +1323,9 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     constexpr int ox = NT == 2 ? 1 - x : x;
     const int os = (NT == 2 && x == 0) ? s - 1 : s;
     const float4 zx4 = zx_next[x];
+    prof.stamp(0);
     await(x, s - 1, (unsigned)((s - 1) >> 1) & 1u);
+    prof.stamp(1);
     zx_next[x] = load_zx(x, s + 1);
     // exchanged word = fp16 hi << 16 | fp16 lo (tag = LSB of lo, left in place)
     h8 bh[NKW], bl[NKW];
@@ -1322,12 +1360,16 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       mine[j * 64 + lane] = r;
     }
     if (NT == 2 && PLACE == 3) issue(ox, os);
+    prof.stamp(2);
     __syncthreads();
+    prof.stamp(3);
     const f32x4* all = part + (size_t)buf * 4 * 4 * 64 + (size_t)w * 64 + lane;
     const f32x4 a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
     if (NT == 2 && PLACE == 1) issue(ox, os);
     finish_step(x, s, a, zx4);
+    prof.stamp(4);
     if (NT == 1 || PLACE == 2) issue(ox, os);
+    prof.stamp(5);
   };
   using T0 = std::integral_constant<int, 0>;
   using T1 = std::integral_constant<int, 1>;
@@ -1343,6 +1385,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     }
     s = 1;
   }
+  prof.init((p.dbg & 32) && wg == 0 && unit == p.chain_begin);
   if (s < s_end) {
     issue(0, s - 1);
     if constexpr (NT == 2) {
@@ -1356,6 +1399,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       for (; s < s_end; ++s) phase(T0{}, s);
     }
   }
+  prof.flush(p.status, w);
 }
 
 template <int NKW, int NT, int PLACE>
@@ -1698,7 +1742,7 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
     }
   }
   if (prof) {
-    long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
+    long long* out = reinterpret_cast<long long*>(p.status + 16) + 6 * w;
     for (int i = 0; i < 4; ++i) out[i] = pt[i];
   }
   if (cvalid && p.dc_state) p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu] = dc;
@@ -1971,7 +2015,7 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
     }
   }
   if (prof) {
-    long long* out = reinterpret_cast<long long*>(p.status + 16) + 4 * w;
+    long long* out = reinterpret_cast<long long*>(p.status + 16) + 6 * w;
     for (int i = 0; i < 4; ++i) out[i] = pt[i];
   }
   if (cvalid && p.dc_state) {
@@ -2378,6 +2422,8 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
   }
   float zmax = 0.f;
   bool dead = false;
+  StepProf prof;
+  prof.init(false);
 
   // slab values of the NEXT step of each tile, prefetched one step ahead
   float nx_dy[NT], nx_c[NT], nx_cp[NT];
@@ -2489,7 +2535,9 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
       *reinterpret_cast<h4*>(dzl + (tid >> 4) * DZH + 4 * (tid & 15)) = lo4;
     }
     if (ISSUE && NT == 2 && PLACE == 3) issue(ox, os);
+    prof.stamp(2);
     __syncthreads();
+    prof.stamp(3);
     if (ISSUE && NT == 2 && PLACE == 1) issue(ox, os);
     {
       h8 bh[2], bl[2];
@@ -2518,12 +2566,16 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
         __builtin_amdgcn_raw_buffer_store_b128(o, wr, soff, i * (4 * P * 1024), FAST ? 0 : kSc1);
       }
     }
+    prof.stamp(4);
     if (ISSUE && (NT == 1 || PLACE == 2)) issue(ox, os);
+    prof.stamp(5);
   };
   // one phase = one step (s >= 1) of tile x: finish its gather, reduce, then `tail`.
   auto phase = [&](auto xc, int s) {
     constexpr int x = decltype(xc)::value;
+    prof.stamp(0);
     await(x, s - 1, (unsigned)((s - 1) >> 1) & 1u);
+    prof.stamp(1);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -2551,6 +2603,7 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
   }
   // (first phase peeled so that every gather the loop waits for was issued by the same
   // code sequence)
+  prof.init((p.dbg & 32) && cw == 0 && unit == p.chain_begin);
   if (s < s_end) {
     issue(0, s - 1);
     if constexpr (NT == 2) {
@@ -2564,6 +2617,7 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
       for (; s < s_end; ++s) phase(T0{}, s);
     }
   }
+  prof.flush(p.status, w);
 #pragma unroll
   for (int x = 0; x < NT; ++x)
     p.dc_state[((size_t)dir * p.n_pad + cn[x]) * H + cu] = dc[x];
@@ -2695,29 +2749,55 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias-gradient partials of unit u0 + b
   float zmax = 0.f;
   bool dead = false;
+  StepProf prof;
+  prof.init(false);
 
   // slab values of the NEXT step, prefetched one step ahead (c_prev of a step is c of the next)
   float4 nx_dy, nx_c, nx_cp, nx_g[4];
-  auto slab_row = [&](int ss, bool& has_prev, size_t& row, size_t& prow) {
-    const int sc = ss < s_end ? ss : s_end - 1;    // past the end: a valid, unused row
-    const int tt = dir == 0 ? p.T - 1 - sc : sc;
-    has_prev = sc + 1 < p.T;                       // the sequence's first frame has c_prev = 0
-    const int tcc = has_prev ? (dir == 0 ? tt - 1 : tt + 1) : tt;
-    row = (size_t)tt * p.n_pad + cn;
-    prow = (size_t)tcc * p.n_pad + cn;
+  float nx_hp = 0.f;                               // 1 if the step has a previous frame, else 0
+  // Slab accesses as buffer operations: the frame part of an address is wave-uniform (scalar
+  // arithmetic beside the VALU stream, folded into the resource's base), the (sample, unit) part
+  // is a per-lane constant -- no vector address arithmetic in the step.
+  const unsigned vo_dy = (unsigned)(((size_t)cn * H2 + dir * H + u0) * 4);
+  const unsigned vo_c = (unsigned)((((size_t)cn * 2 + dir) * H + u0) * 4);
+  const unsigned vo_g = (unsigned)((((size_t)cn * 2 + dir) * H4 + 4 * u0) * 4);
+  // Frame bases of the step being LOADED (ld_*) and of the step being STORED (st_dz) as running
+  // pointers: one scalar 64-bit add per slab and step.
+  const long long fstep = dir == 0 ? -1 : 1;       // frame increment of a BPTT step
+  const size_t fr_dy = (size_t)p.n_pad * H2, fr_g = (size_t)p.n_pad * 2 * H4;
+  auto rs = [&](const float* base, size_t frame_floats) -> __amdgpu_buffer_rsrc_t {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0,
+                                             (unsigned)(frame_floats * 4), 0x00020000);
   };
+  auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned vo, int imm) -> float4 {
+    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, vo, imm, 0);
+    return make_float4(__uint_as_float(x[0]), __uint_as_float(x[1]), __uint_as_float(x[2]),
+                       __uint_as_float(x[3]));
+  };
+  const int tt0 = dir == 0 ? p.T - 1 - p.s_begin : p.s_begin;      // frame of the first step
+  const float* ld_dy = p.dy + (size_t)tt0 * fr_dy;
+  const float* ld_c = p.cell + (size_t)tt0 * fr_dy;                 // (cell rows are 2 H wide too)
+  const float* ld_g = p.gates + (size_t)tt0 * fr_g;
+  float* st_dz = p.dz + (size_t)tt0 * fr_g;
+  // loads the slab values of step ss (the frame the ld_* bases point at), then advances them
   auto load_slabs = [&](int ss, bool first) {
-    bool has_prev; size_t row, prow;
-    slab_row(ss, has_prev, row, prow);
-    nx_dy = *reinterpret_cast<const float4*>(p.dy + row * H2 + dir * H + u0);
+    const bool has_prev = ss + 1 < p.T;            // the sequence's first frame has c_prev = 0
+    nx_dy = ld4(rs(ld_dy, fr_dy), vo_dy, 0);
     // c of step ss is c_prev of step ss - 1 (already in registers), except at a launch's start
-    if (first) nx_c = *reinterpret_cast<const float4*>(p.cell + (row * 2 + dir) * H + u0);
+    if (first) nx_c = ld4(rs(ld_c, fr_dy), vo_c, 0);
     else nx_c = nx_cp;
-    const float4 cp = *reinterpret_cast<const float4*>(p.cell + (prow * 2 + dir) * H + u0);
-    nx_cp = has_prev ? cp : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (no select on the fresh load: a step without a previous frame reads a valid row and
+    // multiplies it by nx_hp = 0 when the value is USED, one step later)
+    nx_cp = ld4(rs(has_prev ? ld_c + fstep * (long long)fr_dy : ld_c, fr_dy), vo_c, 0);
+    nx_hp = has_prev ? 1.f : 0.f;
+    const __amdgpu_buffer_rsrc_t rg = rs(ld_g, fr_g);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      nx_g[j] = *reinterpret_cast<const float4*>(p.gates + (row * 2 + dir) * H4 + 4 * (u0 + j));
+    for (int j = 0; j < 4; ++j) nx_g[j] = ld4(rg, vo_g, 16 * j);
+    if (ss + 1 < s_end) {                          // (past the launch's end: stay on a valid frame)
+      ld_dy += fstep * (long long)fr_dy;
+      ld_c += fstep * (long long)fr_dy;
+      ld_g += fstep * (long long)fr_g;
+    }
   };
   load_slabs(p.s_begin, true);
 
@@ -2762,30 +2842,27 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
 
   // factors of one step that do not depend on the recurrent gradient (computed while the
   // gather is in flight): dz_o = dh A_o ; dcc = dc + dh B ; dz_{i,f,g} = dcc C_{i,f,g} ; dc' = dcc gf
-  struct Pre { float4 dy, Ao, B, Ci, Cf, Cg, gf; };
+  struct Pre { f32x4 dy, Ao, B, Ci, Cf, Cg, gf; };
   auto precompute = [&]() -> Pre {
     Pre r;
-    r.dy = nx_dy;
+    r.dy = f32x4{nx_dy.x, nx_dy.y, nx_dy.z, nx_dy.w};
     const float cc[4] = {nx_c.x, nx_c.y, nx_c.z, nx_c.w};
-    const float cp[4] = {nx_cp.x, nx_cp.y, nx_cp.z, nx_cp.w};
-    float Ao[4], B[4], Ci[4], Cf[4], Cg[4], gf_[4];
+    const float cp[4] = {nx_cp.x * nx_hp, nx_cp.y * nx_hp, nx_cp.z * nx_hp, nx_cp.w * nx_hp};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gi = nx_g[j].x, gf = nx_g[j].y, gg = nx_g[j].z, go = nx_g[j].w;
-      const float tch = fast_tanh(cc[j]);
-      Ao[j] = tch * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
-      B[j] = go * (1.f - tch * tch);
-      Ci[j] = gg * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
-      Cf[j] = cp[j] * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
-      Cg[j] = gi * (1.f - gg * gg);
-      gf_[j] = gf;
+      const float tch = fast_tanh_rcp(cc[j]);
+      r.Ao[j] = tch * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
+      r.B[j] = go * (1.f - tch * tch);
+      r.Ci[j] = gg * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
+      r.Cf[j] = cp[j] * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
+      r.Cg[j] = gi * (1.f - gg * gg);
+      r.gf[j] = gf;
     }
-    r.Ao = make_float4(Ao[0], Ao[1], Ao[2], Ao[3]);
-    r.B = make_float4(B[0], B[1], B[2], B[3]);
-    r.Ci = make_float4(Ci[0], Ci[1], Ci[2], Ci[3]);
-    r.Cf = make_float4(Cf[0], Cf[1], Cf[2], Cf[3]);
-    r.Cg = make_float4(Cg[0], Cg[1], Cg[2], Cg[3]);
-    r.gf = make_float4(gf_[0], gf_[1], gf_[2], gf_[3]);
+    // keep all of it AHEAD of the await (the compiler would sink it to its uses behind the
+    // polling loop, i.e. onto the critical path)
+    asm volatile("" : "+v"(r.dy), "+v"(r.Ao), "+v"(r.B), "+v"(r.Ci), "+v"(r.Cf), "+v"(r.Cg),
+                 "+v"(r.gf));
     return r;
   };
 
@@ -2795,43 +2872,23 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     float* sinv = lds + (size_t)(s & 1) * kBufFloats;         // [16] 1 / scale
     _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZS] hi
     _Float16* dzl = dzh + 16 * DZS;                           // [16][DZS] lo
-    const int t = dir == 0 ? p.T - 1 - s : s;
-    load_slabs(s + 1, false);
     float z[4][4];
     {
-      const float dy[4] = {pre.dy.x, pre.dy.y, pre.dy.z, pre.dy.w};
       const float dr[4] = {dh_rec.x, dh_rec.y, dh_rec.z, dh_rec.w};
       const float cm[4] = {cmask.x, cmask.y, cmask.z, cmask.w};
-      const float Ao[4] = {pre.Ao.x, pre.Ao.y, pre.Ao.z, pre.Ao.w};
-      const float B[4] = {pre.B.x, pre.B.y, pre.B.z, pre.B.w};
-      const float Ci[4] = {pre.Ci.x, pre.Ci.y, pre.Ci.z, pre.Ci.w};
-      const float Cf[4] = {pre.Cf.x, pre.Cf.y, pre.Cf.z, pre.Cf.w};
-      const float Cg[4] = {pre.Cg.x, pre.Cg.y, pre.Cg.z, pre.Cg.w};
-      const float gf[4] = {pre.gf.x, pre.gf.y, pre.gf.z, pre.gf.w};
       float dcv[4] = {dc.x, dc.y, dc.z, dc.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float dh = dy[j] + cm[j] * dr[j];
-        const float dcc = dcv[j] + dh * B[j];
-        z[j][0] = dcc * Ci[j];
-        z[j][1] = dcc * Cf[j];
-        z[j][2] = dcc * Cg[j];
-        z[j][3] = dh * Ao[j];
-        dcv[j] = dcc * gf[j];
+        const float dh = pre.dy[j] + cm[j] * dr[j];
+        const float dcc = dcv[j] + dh * pre.B[j];
+        z[j][0] = dcc * pre.Ci[j];
+        z[j][1] = dcc * pre.Cf[j];
+        z[j][2] = dcc * pre.Cg[j];
+        z[j][3] = dh * pre.Ao[j];
+        dcv[j] = dcc * pre.gf[j];
       }
       dc = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
     }
-    if ((n & 3) == b) {                            // this workgroup's rows of the dz slab
-      float* dst = p.dz + (((size_t)t * p.n_pad + cn) * 2 + dir) * H4 + 4 * u0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<float4*>(dst + 4 * j) = make_float4(z[j][0], z[j][1], z[j][2], z[j][3]);
-    }
-    // (b is uniform: scalar branches, no indexed access)
-    if (b == 0) { gsum.x += z[0][0]; gsum.y += z[0][1]; gsum.z += z[0][2]; gsum.w += z[0][3]; }
-    else if (b == 1) { gsum.x += z[1][0]; gsum.y += z[1][1]; gsum.z += z[1][2]; gsum.w += z[1][3]; }
-    else if (b == 2) { gsum.x += z[2][0]; gsum.y += z[2][1]; gsum.z += z[2][2]; gsum.w += z[2][3]; }
-    else { gsum.x += z[3][0]; gsum.y += z[3][1]; gsum.z += z[3][2]; gsum.w += z[3][3]; }
     // power-of-two scale of this sample's 256 columns: max over its 16 threads (one DPP row)
     float m = 0.f;
 #pragma unroll
@@ -2862,7 +2919,28 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       *reinterpret_cast<h8*>(rl) = lo8[0];
       *reinterpret_cast<h8*>(rl + 8) = lo8[1];
     }
+    // off the dependent path (the other waves are still on their way to the barrier): the
+    // next step's slab values, and this workgroup's rows of the dz slab
+    // (unconditional: values loaded under a branch are waited for at its end; past the
+    // launch's last step the bases stay on a valid frame and the values are never used)
+    load_slabs(s + 1, false);
+    if ((n & 3) == b) {
+      const __amdgpu_buffer_rsrc_t rz = rs(st_dz, fr_g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 zz = {z[j][0], z[j][1], z[j][2], z[j][3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rz, vo_g, 16 * j, 0);
+      }
+    }
+    st_dz += fstep * (long long)fr_g;
+    // (b is uniform: scalar branches, no indexed access)
+    if (b == 0) { gsum.x += z[0][0]; gsum.y += z[0][1]; gsum.z += z[0][2]; gsum.w += z[0][3]; }
+    else if (b == 1) { gsum.x += z[1][0]; gsum.y += z[1][1]; gsum.z += z[1][2]; gsum.w += z[1][3]; }
+    else if (b == 2) { gsum.x += z[2][0]; gsum.y += z[2][1]; gsum.z += z[2][2]; gsum.w += z[2][3]; }
+    else { gsum.x += z[3][0]; gsum.y += z[3][1]; gsum.z += z[3][2]; gsum.w += z[3][3]; }
+    prof.stamp(2);
     __syncthreads();
+    prof.stamp(3);
     {
       h8 bh[KS], bl[KS];
 #pragma unroll
@@ -2877,21 +2955,35 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)(s & 3) * kSlotWords, 0, kSlotWords * 4, 0x00020000);
       const unsigned soff = (unsigned)((((b * NTILE + w) * PA + a) * 256 + nl * 16 + 4 * g) * 4);
-#pragma unroll
-      for (int i = 0; i < OT; ++i) {
-        f32x4 am, a1, a2;
-        mfma3_first(am, a1, a2, ufh[i][0], ufl[i][0], bh[0], bl[0]);
-#pragma unroll
-        for (int kk = 1; kk < KS; ++kk) mfma3_acc(am, a1, a2, ufh[i][kk], ufl[i][kk], bh[kk], bl[kk]);
-        mfma_settle(am, a1, a2);
+      auto finish = [&](int i, f32x4& am, f32x4& a1, f32x4& a2) {
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           o[e] = tag_word(__builtin_fmaf(a1[e] + a2[e], usl, am[e] * us), wtag);
         // output tile w + 4 i of this block: 4 PA KB further on
         __builtin_amdgcn_raw_buffer_store_b128(o, wr, soff, i * (4 * PA * 1024), FAST ? 0 : kSc1);
+      };
+      f32x4 am[OT], a1[OT], a2[OT];
+#pragma unroll
+      for (int i = 0; i < OT; ++i) {
+        mfma3_first(am[i], a1[i], a2[i], ufh[i][0], ufl[i][0], bh[0], bl[0]);
+#pragma unroll
+        for (int kk = 1; kk < KS; ++kk) {
+          mfma3_acc(am[i], a1[i], a2[i], ufh[i][kk], ufl[i][kk], bh[kk], bl[kk]);
+          // the previous tile's results have left the pipe by now: combine and publish them in
+          // the issue slots between this tile's MFMAs
+          if (i > 0 && kk == KS / 2) {
+            // (pins the reads behind this point of the MFMA stream: >= 12 MFMAs after the last
+            // write of these accumulators)
+            asm volatile("s_nop 3" : "+v"(am[i - 1]), "+v"(a1[i - 1]), "+v"(a2[i - 1]));
+            finish(i - 1, am[i - 1], a1[i - 1], a2[i - 1]);
+          }
+        }
       }
+      mfma_settle(am[OT - 1], a1[OT - 1], a2[OT - 1]);
+      finish(OT - 1, am[OT - 1], a1[OT - 1], a2[OT - 1]);
     }
+    prof.stamp(4);
     if (do_issue) issue(s);
   };
 
@@ -2902,11 +2994,15 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     tail(0, pre, make_float4(0.f, 0.f, 0.f, 0.f), false);
     s = 1;
   }
+  prof.init((p.dbg & 32) && cw == 0 && unit == p.chain_begin);
   if (s < s_end) {
     issue(s - 1);
     for (; s < s_end; ++s) {
+      prof.stamp(5);
       const Pre pre = precompute();                // overlaps the hand-off
+      prof.stamp(0);
       await(s - 1);
+      prof.stamp(1);
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int i = 0; i < NL; ++i) {               // (the tag bit stays in: <= 1 ulp)
@@ -2916,6 +3012,7 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       tail(s, pre, acc, true);                     // (after the last step a harmless unused read)
     }
   }
+  prof.flush(p.status, w);
   if (b == 0)
     *reinterpret_cast<float4*>(p.dc_state + ((size_t)dir * p.n_pad + cn) * H + u0) = dc;
   if (p.db_part) {
@@ -3313,7 +3410,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.dbg = env_int("ASR_LSTM_DBG", 0);
   // measured optimum on MI355X (tools/sweep_poll.sh, tools/sweep_r2c.sh): forward 8-16 naps
   // (~0.4 us; flat in that range), BPTT 4
-  p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.pair ? 0 : 4)
+  p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.pair ? 0 : pl.form_c ? 2 : 4)
                   : env_int("ASR_LSTM_PREPOLL_F", pl.pair ? 0 : pl.P <= 16 ? 12 : 16);
   p.repoll = bwd ? env_int("ASR_LSTM_REPOLL_B", 1) : env_int("ASR_LSTM_REPOLL_F", 1);
   p.xstride = fwd_xstride();
@@ -3383,12 +3480,14 @@ extern "C" int asr_lstm_plan(const asr_lstm_args* a, int backward, int* ks, int*
   return ASR_OK;
 }
 
-// Debug (ASR_LSTM_DBG & 32): per-phase wall-clock ticks (100 MHz) of workgroup 0,
-// 4 phases x 4 waves, accumulated over the steps of the last call.
-extern "C" int asr_lstm_profile(const void* workspace, asr_stream_t stream_, long long* out16) {
+// Debug (ASR_LSTM_DBG & 32): per-phase ticks of workgroup 0 of the first chain, 4 waves x 6
+// phases, accumulated over the steps of the last call (shader clocks in the current kernels:
+// 0 pre-gather arithmetic, 1 waiting for the gather, 2 arithmetic behind it up to the
+// barrier, 3 barrier, 4 products + publish, 5 issuing the next gather).
+extern "C" int asr_lstm_profile(const void* workspace, asr_stream_t stream_, long long* out24) {
   hipStream_t stream = (hipStream_t)stream_;
-  ASR_CHECK_HIP(hipMemcpyAsync(out16, reinterpret_cast<const char*>(workspace) + kStickyBytes + 64,
-                               16 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+  ASR_CHECK_HIP(hipMemcpyAsync(out24, reinterpret_cast<const char*>(workspace) + kStickyBytes + 64,
+                               24 * sizeof(long long), hipMemcpyDeviceToHost, stream));
   ASR_CHECK_HIP(hipStreamSynchronize(stream));
   return ASR_OK;
 }

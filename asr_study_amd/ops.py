@@ -245,9 +245,9 @@ def lstm_fast_chains(ws):
 
 
 def lstm_profile(ws):
-    out = (C.c_longlong * 16)()
+    out = (C.c_longlong * 24)()
     L.check(L.load().asr_lstm_profile(_ptr(ws), _stream(), out), 'asr_lstm_profile')
-    return [[out[4 * w + i] for i in range(4)] for w in range(4)]
+    return [[out[6 * w + i] for i in range(6)] for w in range(4)]
 
 
 def lstm_plan(T, n_pad, H, backward):

@@ -278,9 +278,11 @@ int asr_lstm_plan(const asr_lstm_args* a, int backward, int* k_split,
 /* Synchronises `stream`; number of chains of the last call on this workspace
  * that ran on the same-XCD (L2) transport (diagnostic), or a negative status. */
 int asr_lstm_fast_chains(const void* workspace, asr_stream_t stream);
-/* Debug (env ASR_LSTM_DBG & 32): per-phase 100 MHz wall-clock ticks of workgroup
- * 0 of the last call, 4 waves x {wait, barrier, compute-A, compute-B}.         */
-int asr_lstm_profile(const void* workspace, asr_stream_t stream, long long* out16);
+/* Debug (env ASR_LSTM_DBG & 32): per-phase shader-clock ticks of workgroup 0 of the
+ * last call's first chain, summed over its steps: 4 waves x 6 phases {arithmetic
+ * before the gather, waiting for it, arithmetic behind it, barrier, products +
+ * publish, issuing the next gather}.                                           */
+int asr_lstm_profile(const void* workspace, asr_stream_t stream, long long* out24);
 
 /* ------------------------------------------------------------------------ */
 /* K7  CTC loss + gradient.  Replaces core/ctc_utils.py:60-70 ->             */
