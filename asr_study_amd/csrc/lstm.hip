@@ -80,6 +80,7 @@ struct LstmParams {
   int prepoll;             // 64-clock naps before a step's first poll (see gather_groups)
   int repoll;              // 64-clock naps between poll rounds
   int xstride;             // fwd: bytes between consecutive unit-group tiles in a slot
+  long long spin;          // bound of every spin, ticks of the 100 MHz wall clock
   const float* U;
   const float* mask_u;
   const float* zx;
@@ -107,7 +108,7 @@ struct LstmParams {
   int* status;             // [0] timeout flag, [1] chains on the fast transport
 };
 
-constexpr long long kSpinTicks = 60LL * 1000 * 1000;   // 0.6 s of the 100 MHz wall clock
+constexpr long long kSpinTicks = 60LL * 1000 * 1000;   // default bound: 0.6 s (100 MHz wall clock)
 
 // Workspace layout: [sticky block][status block][XCC table][exchange buffer][dc_state].
 // status[0] is the timeout flag of the LAST call (the library clears it at the start of
@@ -223,7 +224,7 @@ __device__ __forceinline__ void gather_groups(__amdgpu_buffer_rsrc_t rsrc,
                                               const unsigned (&off)[NL], const bool (&use)[NL],
                                               unsigned tag, int poll, bool& dead, int* status,
                                               u32x4 (&v)[NL], int nosleep = 0, int prepoll = 0,
-                                              int repoll = 1) {
+                                              int repoll = 1, long long spin = kSpinTicks) {
   // A poll that reaches the L2 before the producers' stores costs a whole extra round
   // trip, and a step waits for the SLOWEST of its waves: napping a little before the
   // first poll trades a small fixed delay for far fewer second rounds.
@@ -241,7 +242,7 @@ __device__ __forceinline__ void gather_groups(__amdgpu_buffer_rsrc_t rsrc,
       if (use[i] && !tags_ok(v[i], tag)) all_ok = false;
     if (all_ok) return;
     if (!timing) { t0 = wall_clock64(); timing = true; }
-    else if (wall_clock64() - t0 > kSpinTicks) {
+    else if (wall_clock64() - t0 > spin) {
       dead = true;
       mark_timeout(status);
       return;
@@ -271,7 +272,7 @@ __device__ bool chain_on_one_xcd(const LstmParams& p, int chain, int wg, int* ld
     for (;;) {
       v = __hip_atomic_load(tab + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (v != 0) break;
-      if (wall_clock64() - t0 > kSpinTicks) { ok = false; break; }
+      if (wall_clock64() - t0 > p.spin) { ok = false; break; }
       __builtin_amdgcn_s_sleep(2);
     }
     lds_i[i] = ok ? v : -1;
@@ -368,7 +369,7 @@ __device__ __forceinline__ void fwd_body(const LstmParams& p, int chain, int wg,
         off[i] = (unsigned)grp * 16u;
       }
       gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
-                              p.prepoll, p.repoll);
+                              p.prepoll, p.repoll, p.spin);
       if (prof) tk1 = wall_clock64();
       // next step's input projection: issued behind the poll (so the poll's in-order
       // wait never includes its HBM latency), consumed one whole compute phase later
@@ -560,7 +561,7 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
         off[i] = (unsigned)((grp >> 4) * p.xstride + (grp & 15) * 16);
       }
       gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
-                              p.prepoll, p.repoll);
+                              p.prepoll, p.repoll, p.spin);
       if (prof) tk1 = wall_clock64();
       zx_next = load_zx(s + 1);
       kc_next = load_zone(p.zone_c, s + 1); kh_next = load_zone(p.zone_h, s + 1);
@@ -748,399 +749,6 @@ __device__ __forceinline__ unsigned packed_word(float hm, unsigned tag) {
            (unsigned)__builtin_bit_cast(unsigned short, pl)) & ~1u) | tag;
 }
 
-// forward, split-fp16, K split over the waves.  Wave w multiplies ALL 64 gate columns
-// of the workgroup (4 tiles of 16) with ITS quarter of h (32*NKW units): its MFMA
-// B-operand comes straight from its own gather (registers; no LDS staging of h, and a
-// wave whose producers are early starts multiplying while the others still wait); the
-// four partial gate tiles then meet in LDS (one barrier per step, double-buffered by step
-// parity) and wave w finishes unit group w as before.  LDS traffic per step drops from
-// 16 KB written + 64 KB read to 16 KB + 16 KB.
-template <int NKW, bool FAST>
-__device__ __forceinline__ void fwd_body_k(const LstmParams& p, int chain, int wg, float* lds) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, nl = lane & 15;
-  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
-  const int UG = H >> 2;
-  const int dir = chain / p.NB, bt = chain % p.NB;
-  const int ug = wg * 4 + w;                       // the unit group this wave FINISHES
-  const bool ug_ok = ug < UG;
-  const int n = bt * 16 + nl;
-  const int u = 4 * ug + g;
-  const int kbase = 32 * NKW * w;                  // first unit of this wave's K slice
-  f32x4* part = reinterpret_cast<f32x4*>(lds);     // [2 parity][4 waves][4 tiles][64 lanes]
-
-  // stationary A fragments: tile j = gate columns of unit group wg*4+j, this wave's K slice
-  h8 ufh[4][NKW], ufl[4][NKW];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ugj = wg * 4 + j;
-#pragma unroll
-    for (int kk = 0; kk < NKW; ++kk) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = kbase + 32 * kk + 8 * g + e;
-        const float x = (ugj < UG && k < H) ? p.U[((size_t)(dir * H + k)) * H4 + 16 * ugj + nl] : 0.f;
-        _Float16 hi, lo;
-        split_f16(x, hi, lo);
-        ufh[j][kk][e] = hi; ufl[j][kk][e] = lo;
-      }
-    }
-  }
-  float mask = 1.f;
-  if (ug_ok && p.mask_u) mask = p.mask_u[((size_t)dir * p.n_pad + n) * H + u];
-  float c = 0.f;
-  bool dead = false;
-  unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;    // [2][UG][16][4]
-  const int slot_words = UG * (p.xstride / 4);
-  const int s_end = p.s_begin + p.s_count;
-  if (ug_ok && p.s_begin > 0) {
-    const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
-    c = p.cell[(((size_t)tpp * p.n_pad + n) * 2 + dir) * H + u];
-  }
-  auto load_zx = [&](int ss) -> float4 {
-    if (!ug_ok || ss >= s_end) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const int tt = dir == 0 ? ss : p.T - 1 - ss;
-    return *reinterpret_cast<const float4*>(
-        p.zx + (((size_t)tt * p.n_pad + n) * 2 + dir) * H4 + 4 * u);
-  };
-  float4 zx_next = load_zx(p.s_begin);
-  constexpr int NL = 2 * NKW;                      // 16-byte groups per lane
-  // group i = (kk, half): units kbase + 32kk + 8g + 4*half .. +3 of sample nl
-  unsigned off[NL];
-  bool use[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    const int gu = (kbase + 32 * (i >> 1) + 8 * g) / 4 + (i & 1);
-    use[i] = gu < UG;
-    off[i] = (unsigned)(gu * p.xstride + nl * 16);
-  }
-  const bool prof = (p.dbg & 32) && wg == 0 && chain == p.chain_begin && lane == 0;
-  long long pt[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
-  for (int s = p.s_begin; s < s_end; ++s) {
-    if (prof) tk0 = wall_clock64();
-    const int t = dir == 0 ? s : p.T - 1 - s;
-    const float4 zx4 = zx_next;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    if (s > 0) {
-      const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
-      __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          xch + (size_t)((s - 1) & 1) * slot_words, 0, slot_words * 4, 0x00020000);
-      u32x4 v[NL];
-      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
-                              p.prepoll, p.repoll);
-      if (prof) tk1 = wall_clock64();
-      zx_next = load_zx(s + 1);
-      // exchanged word = fp16 hi << 16 | fp16 lo; tag bit (lo's LSB) cleared
-      h8 bh[NKW], bl[NKW];
-#pragma unroll
-      for (int kk = 0; kk < NKW; ++kk) {
-        u32x4 q0 = v[2 * kk], q1 = v[2 * kk + 1];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          q0[e] = use[2 * kk] ? (q0[e] & ~1u) : 0u;
-          q1[e] = use[2 * kk + 1] ? (q1[e] & ~1u) : 0u;
-        }
-        u32x4 hi, lo;
-        hi[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x07060302u);
-        hi[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x07060302u);
-        hi[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x07060302u);
-        hi[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x07060302u);
-        lo[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x05040100u);
-        lo[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x05040100u);
-        lo[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x05040100u);
-        lo[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x05040100u);
-        bh[kk] = __builtin_bit_cast(h8, hi);
-        bl[kk] = __builtin_bit_cast(h8, lo);
-      }
-      f32x4* mine = part + ((size_t)(s & 1) * 4 + w) * 4 * 64;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac0 = am, ac1 = am;
-#pragma unroll
-        for (int kk = 0; kk < NKW; ++kk) {
-          am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[j][kk], bh[kk], am, 0, 0, 0);
-          ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[j][kk], bl[kk], ac0, 0, 0, 0);
-          ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[j][kk], bh[kk], ac1, 0, 0, 0);
-        }
-        mine[j * 64 + lane] = combine_split(am, ac0, ac1);
-      }
-      __syncthreads();
-      if (prof) tk2 = wall_clock64();
-      const f32x4* all = part + (size_t)(s & 1) * 4 * 4 * 64 + (size_t)w * 64 + lane;
-      a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
-    } else {
-      zx_next = load_zx(s + 1);
-    }
-    if (prof) { asm volatile("" :: "v"(a[0])); tk3 = wall_clock64(); }
-    if (ug_ok) {
-      const CellFwd o = cell_forward(a, zx4, c, mask);
-      c = o.c;
-      if (s + 1 < p.T) {
-        const unsigned w0 = packed_word(o.hm, (unsigned)(s >> 1) & 1u);
-        // every lane stores its own word: [ug][sample][unit g] -- the four words of a
-        // 16-byte group carry their own tags, so no cross-row shuffle is needed
-        __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-            xch + (size_t)(s & 1) * slot_words, 0, slot_words * 4, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b32(w0, wr, (unsigned)(ug * p.xstride + nl * 16 + g * 4),
-                                              0, FAST ? 0 : kSc1);
-      }
-      const size_t row = (size_t)t * p.n_pad + n;
-      p.y[row * H2 + dir * H + u] = o.h;
-      p.cell[(row * 2 + dir) * H + u] = c;
-      *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
-          make_float4(o.gi, o.gf, o.gg, o.go);
-    }
-    if (prof && s > 0) {
-      const long long tk4 = wall_clock64();
-      pt[0] += tk1 - tk0; pt[1] += tk2 - tk1; pt[2] += tk3 - tk2; pt[3] += tk4 - tk3;
-    }
-  }
-  if (prof) {
-    long long* out = reinterpret_cast<long long*>(p.status + 16) + 6 * w;
-    for (int i = 0; i < 4; ++i) out[i] = pt[i];
-  }
-}
-
-template <int NKW>
-__global__ void __launch_bounds__(kThreads)
-lstm_fwd_kernel_k(LstmParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int chain_local, wg;
-  if (!map_block(p, chain_local, wg)) return;
-  const int chain = p.chain_begin + chain_local;
-  const bool fast = chain_on_one_xcd(p, chain, wg, reinterpret_cast<int*>(lds));
-  if (fast) fwd_body_k<NKW, true>(p, chain, wg, lds);
-  else fwd_body_k<NKW, false>(p, chain, wg, lds);
-}
-
-// ---------------------------------------------------------------------------
-// forward, split-fp16, K split over the waves, TWO batch tiles per workgroup (default for
-// H = 256 / 512 and an even number of batch tiles; ASR_LSTM_PAIR=0 disables).  The two
-// 16-sample tiles (2q, 2q+1) of a direction multiply with the same U slice, so one
-// workgroup can serve both chains with the same stationary operand registers and
-// alternate between them: while tile A's published h travels to its consumers, the
-// workgroup computes tile B, and the gather loads of a tile are issued in the middle of
-// the OTHER tile's phase (PLACE: 0 = before its MFMAs, 3 = after them, 1 = after its
-// partial-tile barrier (default, measured best), 2 = at its very end, i.e. no overlap --
-// the control).  The chain protocol (tags, parity slots, one exchange buffer per chain)
-// is that of fwd_body_k; half as many CUs are occupied.
-template <int NKW, bool FAST, int PLACE>
-__device__ __forceinline__ void fwd_body_k2(const LstmParams& p, int pair, int wg, float* lds) {
-  // Requires H == 128 * NKW (every lane's gather groups and units exist): the steady loop
-  // below has NO branch around a vector-memory instruction, so the compiler can count the
-  // younger operations exactly and a tile's gather is awaited with s_waitcnt vmcnt(N > 0)
-  // while the other tile's slab stores are still in flight.
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, nl = lane & 15;
-  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
-  const int UG = H >> 2;
-  const int NBH = p.NB >> 1;
-  const int dir = pair / NBH, q = pair % NBH;
-  const int ug = wg * 4 + w;                       // the unit group this wave FINISHES
-  const int u = 4 * ug + g;
-  const int kbase = 32 * NKW * w;                  // first unit of this wave's K slice
-  f32x4* part = reinterpret_cast<f32x4*>(lds);     // [2 tiles][4 waves][4 gate tiles][64 lanes]
-
-  h8 ufh[4][NKW], ufl[4][NKW];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ugj = wg * 4 + j;
-#pragma unroll
-    for (int kk = 0; kk < NKW; ++kk) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = kbase + 32 * kk + 8 * g + e;
-        const float x = p.U[((size_t)(dir * H + k)) * H4 + 16 * ugj + nl];
-        _Float16 hi, lo;
-        split_f16(x, hi, lo);
-        ufh[j][kk][e] = hi; ufl[j][kk][e] = lo;
-      }
-    }
-  }
-  const int slot_words = UG * (p.xstride / 4);
-  const int s_end = p.s_begin + p.s_count;
-  int n[2];
-  float mask[2], c[2];
-  unsigned* xch[2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    const int bt = 2 * q + x;
-    n[x] = bt * 16 + nl;
-    mask[x] = p.mask_u ? p.mask_u[((size_t)dir * p.n_pad + n[x]) * H + u] : 1.f;
-    c[x] = 0.f;
-    xch[x] = p.xbuf + (size_t)(dir * p.NB + bt) * p.xchain_words;
-    if (p.s_begin > 0) {
-      const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
-      c[x] = p.cell[(((size_t)tpp * p.n_pad + n[x]) * 2 + dir) * H + u];
-    }
-  }
-  auto load_zx = [&](int x, int ss) -> float4 {
-    const int sc = ss < s_end ? ss : s_end - 1;    // past the end: a valid, unused row
-    const int tt = dir == 0 ? sc : p.T - 1 - sc;
-    return *reinterpret_cast<const float4*>(
-        p.zx + (((size_t)tt * p.n_pad + n[x]) * 2 + dir) * H4 + 4 * u);
-  };
-  float4 zx_next[2] = {load_zx(0, p.s_begin), load_zx(1, p.s_begin)};
-  constexpr int NL = 2 * NKW;
-  unsigned off[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i)
-    off[i] = (unsigned)(((kbase + 32 * (i >> 1) + 8 * g) / 4 + (i & 1)) * p.xstride + nl * 16);
-  bool dead = false;
-  u32x4 v[2][NL];
-  // the exchange slot holding h of step `ss` of tile x
-  auto slot = [&](int x, int ss) -> __amdgpu_buffer_rsrc_t {
-    return __builtin_amdgcn_make_buffer_rsrc(xch[x] + (size_t)(ss & 1) * slot_words, 0,
-                                             slot_words * 4, 0x00020000);
-  };
-  auto issue = [&](int x, int ss) {
-    for (int i = 0; i < p.prepoll; ++i) __builtin_amdgcn_s_sleep(1);
-    const __amdgpu_buffer_rsrc_t rsrc = slot(x, ss);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) v[x][i] = xload<FAST>(rsrc, off[i]);
-  };
-  auto all_fresh = [&](int x, unsigned tag) -> bool {
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) ok = ok && tags_ok(v[x][i], tag);
-    return ok;
-  };
-  // rare path: some word of the gather was stale -- poll until every word carries the tag
-  auto repoll = [&](int x, int ss, unsigned tag) {
-    const __amdgpu_buffer_rsrc_t rsrc = slot(x, ss);
-    const long long t0 = wall_clock64();
-    while (!dead) {
-      for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-      for (int i = 0; i < NL; ++i)
-        if (!tags_ok(v[x][i], tag)) v[x][i] = xload<FAST>(rsrc, off[i]);
-      if (all_fresh(x, tag)) return;
-      if (wall_clock64() - t0 > kSpinTicks) {
-        dead = true;
-        mark_timeout(p.status);
-      }
-    }
-  };
-  // cell update of tile x at step s from the recurrent contribution `a`; publishes h
-  auto finish_step = [&](int x, int s, const f32x4& a, const float4& zx4) {
-    const int t = dir == 0 ? s : p.T - 1 - s;
-    const CellFwd o = cell_forward(a, zx4, c[x], mask[x]);
-    c[x] = o.c;
-    const float gi = o.gi, gf = o.gf, gg = o.gg, go = o.go, h = o.h;
-    const unsigned w0 = packed_word(o.hm, (unsigned)(s >> 1) & 1u);
-    // (the last step's word is published too: nobody reads it, and no branch is needed)
-    __builtin_amdgcn_raw_buffer_store_b32(w0, slot(x, s),
-                                          (unsigned)(ug * p.xstride + nl * 16 + g * 4), 0,
-                                          FAST ? 0 : kSc1);
-    const size_t row = (size_t)t * p.n_pad + n[x];
-    p.y[row * H2 + dir * H + u] = h;
-    p.cell[(row * 2 + dir) * H + u] = c[x];
-    *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
-        make_float4(gi, gf, gg, go);
-  };
-
-  int s = p.s_begin;
-  if (s == 0) {
-    // step 0 of both tiles: h_prev = 0, nothing to gather
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      const float4 zx4 = zx_next[x];
-      zx_next[x] = load_zx(x, 1);
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      finish_step(x, 0, zero, zx4);
-    }
-    s = 1;
-  }
-  // one phase = one step of tile X.  The gather issued during the phase is the OTHER
-  // tile's next input: phase 0 -> tile 1, h of step s-1 (consumed later in this iteration);
-  // phase 1 -> tile 0, h of step s (consumed by the next iteration; after the last one it
-  // is a harmless unused read).
-  auto phase = [&](auto xc, int s) {
-    constexpr int x = decltype(xc)::value;
-    constexpr int ox = 1 - x;
-    const int os = x == 0 ? s - 1 : s;
-    const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
-    const float4 zx4 = zx_next[x];
-    if (!all_fresh(x, tag)) repoll(x, s - 1, tag);
-    zx_next[x] = load_zx(x, s + 1);
-    h8 bh[NKW], bl[NKW];
-#pragma unroll
-    for (int kk = 0; kk < NKW; ++kk) {
-      u32x4 q0 = v[x][2 * kk], q1 = v[x][2 * kk + 1];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        q0[e] &= ~1u;
-        q1[e] &= ~1u;
-      }
-      u32x4 hi, lo;
-      hi[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x07060302u);
-      hi[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x07060302u);
-      hi[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x07060302u);
-      hi[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x07060302u);
-      lo[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x05040100u);
-      lo[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x05040100u);
-      lo[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x05040100u);
-      lo[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x05040100u);
-      bh[kk] = __builtin_bit_cast(h8, hi);
-      bl[kk] = __builtin_bit_cast(h8, lo);
-    }
-    if (PLACE == 0) issue(ox, os);
-    // one LDS buffer per tile: a wave that writes tile x again has passed the other
-    // tile's barrier, which every wave reaches only after its reads of this buffer
-    f32x4* mine = part + ((size_t)x * 4 + w) * 4 * 64;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac0 = am, ac1 = am;
-#pragma unroll
-      for (int kk = 0; kk < NKW; ++kk) {
-        am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[j][kk], bh[kk], am, 0, 0, 0);
-        ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[j][kk], bl[kk], ac0, 0, 0, 0);
-        ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[j][kk], bh[kk], ac1, 0, 0, 0);
-      }
-      mine[j * 64 + lane] = combine_split(am, ac0, ac1);
-    }
-    if (PLACE == 3) issue(ox, os);
-    __syncthreads();
-    const f32x4* all = part + (size_t)x * 4 * 4 * 64 + (size_t)w * 64 + lane;
-    const f32x4 a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
-    if (PLACE == 1) issue(ox, os);
-    finish_step(x, s, a, zx4);
-    if (PLACE == 2) issue(ox, os);
-  };
-  using T0 = std::integral_constant<int, 0>;
-  using T1 = std::integral_constant<int, 1>;
-  // The first phase is peeled so that EVERY gather the loop waits for was issued by the
-  // same code sequence (followed by the same four stores): the compiler then awaits it
-  // with an exact s_waitcnt vmcnt(N) instead of a conservative vmcnt(0) that would also
-  // wait for the other tile's stores to be acknowledged.
-  if (s < s_end) {
-    issue(0, s - 1);
-    phase(T0{}, s);
-    for (;;) {
-      phase(T1{}, s);
-      if (++s >= s_end) break;
-      phase(T0{}, s);
-    }
-  }
-}
-
-template <int NKW, int PLACE>
-__global__ void __launch_bounds__(kThreads)
-lstm_fwd_kernel_k2(LstmParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int pair_local, wg;
-  if (!map_block(p, pair_local, wg)) return;
-  const int pair = p.chain_begin + pair_local;
-  const bool fast = chain_on_one_xcd(p, pair, wg, reinterpret_cast<int*>(lds));
-  if (fast) fwd_body_k2<NKW, true, PLACE>(p, pair, wg, lds);
-  else fwd_body_k2<NKW, false, PLACE>(p, pair, wg, lds);
-}
-
-// ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
 // forward, split-fp16, K split over the waves, third generation (plain cell, H = 256 / 512,
 // persistent mode): the default forward kernel.  NT = 2: two batch tiles per workgroup as
@@ -1197,17 +805,17 @@ template <> struct FwdMfma<4> {
   }
 };
 
-template <int NKW, bool FAST, int NT, int PLACE>
+template <int NKW, bool FAST>
 __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg, float* lds) {
   // Requires H == 128 * NKW (every lane's gather groups and units exist)
+  constexpr int NT = 1;                            // batch tiles per workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, nl = lane & 15;
   const int H = p.H, H4 = 4 * H, H2 = 2 * H;
   const int UG = H >> 2;
-  const int per_dir = NT == 2 ? (p.NB >> 1) : p.NB;
-  const int dir = unit / per_dir, bt0 = NT * (unit % per_dir);
+  const int dir = unit / p.NB, bt0 = unit % p.NB;
   const int ug = wg * 4 + w;                       // the unit group this wave FINISHES
   const int u = 4 * ug + g;
   const int kbase = 32 * NKW * w;                  // first unit of this wave's K slice
@@ -1294,7 +902,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
       load_groups(x, rsrc);
       stale = !all_tagged<NL>(v[x], flip);
-      if (stale && wall_clock64() - t0 > kSpinTicks) { gave_up = true; break; }
+      if (stale && wall_clock64() - t0 > p.spin) { gave_up = true; break; }
     }
     if (__builtin_amdgcn_ballot_w64(gave_up) != 0ull) {
       dead = true;
@@ -1320,8 +928,6 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
   // one phase = one step (s >= 1) of tile x
   auto phase = [&](auto xc, int s) {
     constexpr int x = decltype(xc)::value;
-    constexpr int ox = NT == 2 ? 1 - x : x;
-    const int os = (NT == 2 && x == 0) ? s - 1 : s;
     const float4 zx4 = zx_next[x];
     prof.stamp(0);
     await(x, s - 1, (unsigned)((s - 1) >> 1) & 1u);
@@ -1344,11 +950,9 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       bh[kk] = __builtin_bit_cast(h8, hi);
       bl[kk] = __builtin_bit_cast(h8, lo);
     }
-    if (NT == 2 && PLACE == 0) issue(ox, os);
-    // NT = 2: one LDS buffer per tile (a wave that writes tile x again has passed the other
-    // tile's barrier, which every wave reaches only after its reads of this buffer); NT = 1:
-    // two buffers by step parity
-    const int buf = NT == 2 ? x : (s & 1);
+    // two LDS buffers by step parity (the one barrier per step keeps the waves at most one
+    // step apart)
+    const int buf = s & 1;
     f32x4* mine = part + ((size_t)buf * 4 + w) * 4 * 64;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1359,20 +963,17 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(ac[e], 1.f / kLoScale, am[e]);
       mine[j * 64 + lane] = r;
     }
-    if (NT == 2 && PLACE == 3) issue(ox, os);
     prof.stamp(2);
     __syncthreads();
     prof.stamp(3);
     const f32x4* all = part + (size_t)buf * 4 * 4 * 64 + (size_t)w * 64 + lane;
     const f32x4 a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
-    if (NT == 2 && PLACE == 1) issue(ox, os);
     finish_step(x, s, a, zx4);
     prof.stamp(4);
-    if (NT == 1 || PLACE == 2) issue(ox, os);
+    issue(x, s);                                   // this tile's h of step s, for step s + 1
     prof.stamp(5);
   };
   using T0 = std::integral_constant<int, 0>;
-  using T1 = std::integral_constant<int, 1>;
   int s = p.s_begin;
   if (s == 0) {
     // step 0: h_prev = 0, nothing to gather
@@ -1388,21 +989,12 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
   prof.init((p.dbg & 32) && wg == 0 && unit == p.chain_begin);
   if (s < s_end) {
     issue(0, s - 1);
-    if constexpr (NT == 2) {
-      phase(T0{}, s);
-      for (;;) {
-        phase(T1{}, s);
-        if (++s >= s_end) break;
-        phase(T0{}, s);
-      }
-    } else {
-      for (; s < s_end; ++s) phase(T0{}, s);
-    }
+    for (; s < s_end; ++s) phase(T0{}, s);
   }
   prof.flush(p.status, w);
 }
 
-template <int NKW, int NT, int PLACE>
+template <int NKW>
 __global__ void __launch_bounds__(kThreads)
 lstm_fwd_kernel_x(LstmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1410,8 +1002,8 @@ lstm_fwd_kernel_x(LstmParams p) {
   if (!map_block(p, unit_local, wg)) return;
   const int unit = p.chain_begin + unit_local;
   const bool fast = chain_on_one_xcd(p, unit, wg, reinterpret_cast<int*>(lds));
-  if (fast) fwd_body_x<NKW, true, NT, PLACE>(p, unit, wg, lds);
-  else fwd_body_x<NKW, false, NT, PLACE>(p, unit, wg, lds);
+  if (fast) fwd_body_x<NKW, true>(p, unit, wg, lds);
+  else fwd_body_x<NKW, false>(p, unit, wg, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -1462,7 +1054,7 @@ __device__ __forceinline__ void fwd_body_n1(const LstmParams& p, int dir, int wg
           bool timing = false;
           while ((((v[0] ^ flip) | (v[1] ^ flip)) | ((v[2] ^ flip) | (v[3] ^ flip))) & 1u) {
             if (!timing) { t0 = wall_clock64(); timing = true; }
-            else if (wall_clock64() - t0 > kSpinTicks) { dead = true; mark_timeout(p.status); break; }
+            else if (wall_clock64() - t0 > p.spin) { dead = true; mark_timeout(p.status); break; }
             __builtin_amdgcn_s_sleep(1);
             v = xload<FAST>(rsrc, (unsigned)tid * 16);
           }
@@ -1655,7 +1247,7 @@ __device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw,
         off[i] = (unsigned)grp * 16u;
       }
       gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
-                              p.prepoll, p.repoll);
+                              p.prepoll, p.repoll, p.spin);
       if (prof) tk1 = wall_clock64();
       load_slabs(s + 1);
 #pragma unroll
@@ -1893,7 +1485,7 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
         off[i] = (unsigned)((pr * 64 + grp_in_tile) * 16);
       }
       gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
-                              p.prepoll, p.repoll);
+                              p.prepoll, p.repoll, p.spin);
       if (prof) tk1 = wall_clock64();
       load_slabs(s + 1);
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2081,272 +1673,6 @@ lstm_bwd_kernel_hv(LstmParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// backward, split-fp16, TWO batch tiles per workgroup (plain cell, H = 256 / 512, an even
-// number of batch tiles; ASR_LSTM_PAIR_B).  Same idea as fwd_body_k2: both tiles of a
-// direction multiply with the same U^T slice, the workgroup alternates between them and
-// issues a tile's gather during the other tile's phase (PLACE: 3 = before that phase's
-// barrier, 1 = after it, 2 = at its end, i.e. no overlap).  As there, the steady loop has no
-// branch around a vector-memory instruction so that the gather is awaited with an exact
-// s_waitcnt vmcnt(N).  Chain protocol and exchange layout are those of bwd_body_h.
-template <int TPW, bool FAST, int PLACE>
-__device__ __forceinline__ void bwd_body_h2(const LstmParams& p, int pair, int cw, float* lds) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, nl = lane & 15;
-  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
-  const int P = p.P;                               // == 4 * TPW here
-  const int NBH = p.NB >> 1;
-  const int dir = pair / NBH, q = pair % NBH;
-  constexpr int DZH = 72;                         // LDS row stride of the dz tiles (halfs)
-  constexpr int kTileFloats = 16 + (2 * 16 * DZH) / 2;        // sinv + hi + lo, in floats
-  // one dz tile per batch tile: a wave that rewrites tile x's buffer has passed the other
-  // tile's barrier, which every wave reaches only after its MFMA reads of this buffer
-
-  h8 ufh[TPW][2], ufl[TPW][2];
-#pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int krow = 16 * (w + 4 * i) + nl;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int j = 64 * cw + 32 * kk + 8 * g + e;
-        _Float16 hi, lo;
-        split_f16(p.U[((size_t)(dir * H + krow)) * H4 + j], hi, lo);
-        ufh[i][kk][e] = hi; ufl[i][kk][e] = lo;
-      }
-    }
-  }
-  const int cu = 16 * cw + (tid & 15);
-  const int s_end = p.s_begin + p.s_count;
-  const size_t slot_words = (size_t)P * P * 256;
-  int cn[2];
-  float cmask[2], dc[2];
-  unsigned* xch[2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    const int bt = 2 * q + x;
-    cn[x] = bt * 16 + (tid >> 4);
-    cmask[x] = p.mask_u ? p.mask_u[((size_t)dir * p.n_pad + cn[x]) * H + cu] : 1.f;
-    dc[x] = p.s_begin > 0 ? p.dc_state[((size_t)dir * p.n_pad + cn[x]) * H + cu] : 0.f;
-    xch[x] = p.xbuf + (size_t)(dir * p.NB + bt) * p.xchain_words;
-  }
-  float4 gsum[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-  float zmax = 0.f;
-  bool dead = false;
-
-  // slab values of the NEXT step of each tile, prefetched one step ahead
-  float nx_dy[2], nx_c[2], nx_cp[2];
-  float4 nx_g[2];
-  auto load_slabs = [&](int x, int ss) {
-    const int sc = ss < s_end ? ss : s_end - 1;    // past the end: a valid, unused row
-    const int tt = dir == 0 ? p.T - 1 - sc : sc;
-    const bool has_prev = sc + 1 < p.T;            // the sequence's first frame has c_prev = 0
-    const int tcc = has_prev ? (dir == 0 ? tt - 1 : tt + 1) : tt;
-    const size_t row = (size_t)tt * p.n_pad + cn[x];
-    nx_dy[x] = p.dy[row * H2 + dir * H + cu];
-    nx_c[x] = p.cell[(row * 2 + dir) * H + cu];
-    const float cp = p.cell[(((size_t)tcc * p.n_pad + cn[x]) * 2 + dir) * H + cu];
-    nx_cp[x] = has_prev ? cp : 0.f;
-    nx_g[x] = *reinterpret_cast<const float4*>(p.gates + (row * 2 + dir) * H4 + 4 * cu);
-  };
-  load_slabs(0, p.s_begin);
-  load_slabs(1, p.s_begin);
-
-  // Lane (sample = lane>>4 of this wave's four, unit quad = (lane>>2)&3, sub = lane&3)
-  // gathers the 16-byte group (sample, quad) of the partial dh tiles of producers
-  // sub*TPW+i; summed in registers, then over the four `sub` lanes with DPP quad permutes.
-  constexpr int NL = TPW;
-  const int sub = lane & 3;
-  const int grp_in_tile = (4 * w + (lane >> 4)) * 4 + ((lane >> 2) & 3);
-  unsigned off[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) off[i] = (unsigned)(((sub * TPW + i) * 64 + grp_in_tile) * 16);
-  u32x4 v[2][NL];
-  // this workgroup's region of the slot that holds the partial tiles of step `ss`, tile x
-  auto rslot = [&](int x, int ss) -> __amdgpu_buffer_rsrc_t {
-    return __builtin_amdgcn_make_buffer_rsrc(
-        xch[x] + (size_t)(ss & 1) * slot_words + (size_t)cw * P * 256, 0, P * 256 * 4, 0x00020000);
-  };
-  auto issue = [&](int x, int ss) {
-    for (int i = 0; i < p.prepoll; ++i) __builtin_amdgcn_s_sleep(1);
-    const __amdgpu_buffer_rsrc_t rsrc = rslot(x, ss);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) v[x][i] = xload<FAST>(rsrc, off[i]);
-  };
-  auto all_fresh = [&](int x, unsigned tag) -> bool {
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) ok = ok && tags_ok(v[x][i], tag);
-    return ok;
-  };
-  auto repoll = [&](int x, int ss, unsigned tag) {
-    const __amdgpu_buffer_rsrc_t rsrc = rslot(x, ss);
-    const long long t0 = wall_clock64();
-    while (!dead) {
-      for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-      for (int i = 0; i < NL; ++i)
-        if (!tags_ok(v[x][i], tag)) v[x][i] = xload<FAST>(rsrc, off[i]);
-      if (all_fresh(x, tag)) return;
-      if (wall_clock64() - t0 > kSpinTicks) {
-        dead = true;
-        mark_timeout(p.status);
-      }
-    }
-  };
-
-  // everything of one step of tile x after its recurrent gradient dh_rec is known: cell
-  // gradient, dz slab + LDS tile, barrier, partial dh tiles = U^T-slice x dz, publish.
-  // ISSUE: whether the other tile's gather (tile ox, step os) is issued on the way.
-  auto tail = [&](auto xc, auto issue_c, int s, float dh_rec, int os) {
-    constexpr int x = decltype(xc)::value;
-    constexpr int ox = 1 - x;
-    constexpr bool ISSUE = decltype(issue_c)::value;
-    float* sinv = lds + (size_t)x * kTileFloats;              // [16] 1/scale per batch column
-    _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZH] hi
-    _Float16* dzl = dzh + 16 * DZH;                           // [16][DZH] lo
-    const int t = dir == 0 ? p.T - 1 - s : s;
-    {
-      const float4 gt = nx_g[x];
-      const float dyv = nx_dy[x], cv = nx_c[x], cpv = nx_cp[x];
-      load_slabs(x, s + 1);
-      const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
-      const float dh = dyv + cmask[x] * dh_rec;
-      const float tch = fast_tanh(cv);
-      const float d_o = dh * tch;
-      const float dcc = dc[x] + dh * go * (1.f - tch * tch);
-      const float d_i = dcc * gg, d_g = dcc * gi, d_f = dcc * cpv;
-      dc[x] = dcc * gf;
-      float4 z4;
-      z4.x = d_i * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
-      z4.y = d_f * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
-      z4.z = d_g * (1.f - gg * gg);
-      z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
-      *reinterpret_cast<float4*>(p.dz + (((size_t)t * p.n_pad + cn[x]) * 2 + dir) * H4 + 4 * cu) = z4;
-      gsum[x].x += z4.x; gsum[x].y += z4.y; gsum[x].z += z4.z; gsum[x].w += z4.w;
-      // power-of-two scale of this batch column: max over its 16 threads (one DPP row)
-      float m = fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w)));
-      zmax = fmaxf(zmax, m);
-      m = row16_max(m);
-      int ex = 0;
-      if (m > 0.f) (void)frexpf(m, &ex); else ex = 9;
-      ex = ex < -100 ? -100 : ex;                 // keep 2^(9-ex) finite for denormal maxima
-      const float sc = ldexpf(1.f, 9 - ex);
-      if ((tid & 15) == 0) sinv[tid >> 4] = ldexpf(1.f, ex - 9);
-      h4 hi4, lo4;
-      _Float16 a, b;
-      split_f16(z4.x * sc, a, b); hi4[0] = a; lo4[0] = b;
-      split_f16(z4.y * sc, a, b); hi4[1] = a; lo4[1] = b;
-      split_f16(z4.z * sc, a, b); hi4[2] = a; lo4[2] = b;
-      split_f16(z4.w * sc, a, b); hi4[3] = a; lo4[3] = b;
-      *reinterpret_cast<h4*>(dzh + (tid >> 4) * DZH + 4 * (tid & 15)) = hi4;
-      *reinterpret_cast<h4*>(dzl + (tid >> 4) * DZH + 4 * (tid & 15)) = lo4;
-    }
-    if (ISSUE && PLACE == 3) issue(ox, os);
-    __syncthreads();
-    if (ISSUE && PLACE == 1) issue(ox, os);
-    {
-      h8 bh[2], bl[2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bh[kk] = *reinterpret_cast<const h8*>(dzh + nl * DZH + 32 * kk + 8 * g);
-        bl[kk] = *reinterpret_cast<const h8*>(dzl + nl * DZH + 32 * kk + 8 * g);
-      }
-      const float us = sinv[nl];
-      const unsigned wtag = (unsigned)(s >> 1) & 1u;
-      // (the last step's tiles are published too: nobody reads them, and no branch is needed)
-      const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-          xch[x] + (size_t)(s & 1) * slot_words, 0, (unsigned)(slot_words * 4), 0x00020000);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int mt = w + 4 * i;
-        f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac0 = am, ac1 = am;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[i][kk], bh[kk], am, 0, 0, 0);
-          ac0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufh[i][kk], bl[kk], ac0, 0, 0, 0);
-          ac1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ufl[i][kk], bh[kk], ac1, 0, 0, 0);
-        }
-        const f32x4 a = (am + (ac0 + ac1) * (1.f / kLoScale)) * us;
-        u32x4 o;
-        o[0] = tag_word(a[0], wtag); o[1] = tag_word(a[1], wtag);
-        o[2] = tag_word(a[2], wtag); o[3] = tag_word(a[3], wtag);
-        xstore<FAST>(o, wr, (unsigned)((((size_t)mt * P + cw) * 256 + nl * 16 + 4 * g) * 4));
-      }
-    }
-    if (ISSUE && PLACE == 2) issue(ox, os);
-  };
-  // one phase = one step (s >= 1) of tile x: finish its gather, reduce, then `tail`.  The
-  // gather issued on the way is the OTHER tile's next input: phase 0 -> tile 1, partial
-  // tiles of step s-1 (consumed later in this iteration); phase 1 -> tile 0, step s
-  // (consumed by the next iteration; after the last one a harmless unused read).
-  auto phase = [&](auto xc, int s) {
-    constexpr int x = decltype(xc)::value;
-    const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
-    if (!all_fresh(x, tag)) repoll(x, s - 1, tag);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      acc.x += __uint_as_float(v[x][i][0] & ~1u); acc.y += __uint_as_float(v[x][i][1] & ~1u);
-      acc.z += __uint_as_float(v[x][i][2] & ~1u); acc.w += __uint_as_float(v[x][i][3] & ~1u);
-    }
-    acc.x += quad_swap1(acc.x); acc.y += quad_swap1(acc.y);
-    acc.z += quad_swap1(acc.z); acc.w += quad_swap1(acc.w);
-    acc.x += quad_swap2(acc.x); acc.y += quad_swap2(acc.y);
-    acc.z += quad_swap2(acc.z); acc.w += quad_swap2(acc.w);
-    const float dh_rec = sub == 0 ? acc.x : sub == 1 ? acc.y : sub == 2 ? acc.z : acc.w;
-    tail(xc, std::true_type{}, s, dh_rec, x == 0 ? s - 1 : s);
-  };
-  using T0 = std::integral_constant<int, 0>;
-  using T1 = std::integral_constant<int, 1>;
-  int s = p.s_begin;
-  if (s == 0) {
-    // step 0 of both tiles: no recurrent gradient yet, nothing to gather
-    tail(T0{}, std::false_type{}, 0, 0.f, 0);
-    tail(T1{}, std::false_type{}, 0, 0.f, 0);
-    s = 1;
-  }
-  // (first phase peeled, as in fwd_body_k2, so that every gather the loop waits for was
-  // issued by the same code sequence)
-  if (s < s_end) {
-    issue(0, s - 1);
-    phase(T0{}, s);
-    for (;;) {
-      phase(T1{}, s);
-      if (++s >= s_end) break;
-      phase(T0{}, s);
-    }
-  }
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-    p.dc_state[((size_t)dir * p.n_pad + cn[x]) * H + cu] = dc[x];
-  if (p.db_part) {
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-      tile_gate_sums(gsum[x], lds, p.db_part + ((size_t)(2 * q + x) * 2 + dir) * H4 + 64 * cw,
-                     p.s_begin > 0);
-  }
-  if (p.dz_absmax) {
-    zmax = asr_wave_max(zmax);
-    if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
-  }
-}
-
-template <int TPW, int PLACE>
-__global__ void __launch_bounds__(kThreads)
-lstm_bwd_kernel_h2(LstmParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int pair_local, cw;
-  if (!map_block(p, pair_local, cw)) return;
-  const int pair = p.chain_begin + pair_local;
-  const bool fast = chain_on_one_xcd(p, pair, cw, reinterpret_cast<int*>(lds));
-  if (fast) bwd_body_h2<TPW, true, PLACE>(p, pair, cw, lds);
-  else bwd_body_h2<TPW, false, PLACE>(p, pair, cw, lds);
-}
-
-// ---------------------------------------------------------------------------
 // backward, split-fp16, third generation (plain cell, H = 256 / 512, persistent mode): the
 // default BPTT kernel.  NT = 2: two batch tiles per workgroup as bwd_body_h2 (a tile's gather
 // is in flight during the other tile's phase); NT = 1: one tile, gather issued right after the
@@ -2366,22 +1692,20 @@ lstm_bwd_kernel_h2(LstmParams p) {
 //    leaves as per-tile partial sums (LstmParams::db_part): no pass over the dz slab after it.
 // Arithmetic: products and summation order of a (sample, unit) are the same for NT = 1 and 2,
 // for sliced and whole sequences and for both transports.
-template <int TPW, bool FAST, int NT, int PLACE>
+template <int TPW, bool FAST>
 __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw, float* lds) {
+  constexpr int NT = 1;                            // batch tiles per workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, nl = lane & 15;
   const int H = p.H, H4 = 4 * H, H2 = 2 * H;
   const int P = p.P;                               // == 4 * TPW here
-  const int per_dir = NT == 2 ? (p.NB >> 1) : p.NB;
-  const int dir = unit / per_dir, bt0 = NT * (unit % per_dir);
+  const int dir = unit / p.NB, bt0 = unit % p.NB;
   constexpr int DZH = 72;                         // LDS row stride of the dz tiles (halfs)
   constexpr int kTileFloats = 16 + (2 * 16 * DZH) / 2;        // sinv + hi + lo, in floats
-  // NT = 2: one dz tile buffer per batch tile (a wave that rewrites tile x's buffer has passed
-  // the other tile's barrier, which every wave reaches only after its MFMA reads of this
-  // buffer); NT = 1: two buffers by step parity (the one barrier per step keeps the waves at
-  // most one step apart)
+  // two dz tile buffers by step parity (the one barrier per step keeps the waves at most one
+  // step apart)
 
   f32x4 ufh[TPW][2], ufl[TPW][2];                  // bit patterns of 8 halfs each (AGPRs)
 #pragma unroll
@@ -2479,7 +1803,7 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
       for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
       load_groups(x, rsrc);
       stale = !all_tagged<NL>(v[x], flip);
-      if (stale && wall_clock64() - t0 > kSpinTicks) { gave_up = true; break; }
+      if (stale && wall_clock64() - t0 > p.spin) { gave_up = true; break; }
     }
     if (__builtin_amdgcn_ballot_w64(gave_up) != 0ull) {
       dead = true;
@@ -2489,12 +1813,11 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
 
   // everything of one step of tile x after its recurrent gradient dh_rec is known: cell
   // gradient, dz slab + LDS tile, barrier, partial dh tiles = U^T-slice x dz, publish.
-  // ISSUE: whether a gather (tile ox, tiles of step os) is issued on the way.
+  // ISSUE: whether the gather of this tile's partial tiles of step os is issued on the way.
   auto tail = [&](auto xc, auto issue_c, int s, float dh_rec, int os) {
     constexpr int x = decltype(xc)::value;
-    constexpr int ox = NT == 2 ? 1 - x : x;
     constexpr bool ISSUE = decltype(issue_c)::value;
-    float* sinv = lds + (size_t)(NT == 2 ? x : (s & 1)) * kTileFloats;   // [16] 1/scale
+    float* sinv = lds + (size_t)(s & 1) * kTileFloats;        // [16] 1/scale
     _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZH] hi
     _Float16* dzl = dzh + 16 * DZH;                           // [16][DZH] lo
     const int t = dir == 0 ? p.T - 1 - s : s;
@@ -2534,11 +1857,9 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
       *reinterpret_cast<h4*>(dzh + (tid >> 4) * DZH + 4 * (tid & 15)) = hi4;
       *reinterpret_cast<h4*>(dzl + (tid >> 4) * DZH + 4 * (tid & 15)) = lo4;
     }
-    if (ISSUE && NT == 2 && PLACE == 3) issue(ox, os);
     prof.stamp(2);
     __syncthreads();
     prof.stamp(3);
-    if (ISSUE && NT == 2 && PLACE == 1) issue(ox, os);
     {
       h8 bh[2], bl[2];
 #pragma unroll
@@ -2567,7 +1888,7 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
       }
     }
     prof.stamp(4);
-    if (ISSUE && (NT == 1 || PLACE == 2)) issue(ox, os);
+    if (ISSUE) issue(x, os);
     prof.stamp(5);
   };
   // one phase = one step (s >= 1) of tile x: finish its gather, reduce, then `tail`.
@@ -2587,18 +1908,15 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
     acc.x += quad_swap2(acc.x); acc.y += quad_swap2(acc.y);
     acc.z += quad_swap2(acc.z); acc.w += quad_swap2(acc.w);
     const float dh_rec = sub == 0 ? acc.x : sub == 1 ? acc.y : sub == 2 ? acc.z : acc.w;
-    // the gather issued on the way: NT = 2: phase of tile 0 -> tile 1's tiles of step s-1
-    // (consumed later in this iteration), phase of tile 1 -> tile 0's of step s; NT = 1: this
-    // tile's of step s (after the last step a harmless unused read)
-    tail(xc, std::true_type{}, s, dh_rec, (NT == 2 && x == 0) ? s - 1 : s);
+    // the gather issued on the way: this tile's partial tiles of step s (after the last step a
+    // harmless unused read)
+    tail(xc, std::true_type{}, s, dh_rec, s);
   };
   using T0 = std::integral_constant<int, 0>;
-  using T1 = std::integral_constant<int, 1>;
   int s = p.s_begin;
   if (s == 0) {
     // step 0: no recurrent gradient yet, nothing to gather
     tail(T0{}, std::false_type{}, 0, 0.f, 0);
-    if constexpr (NT == 2) tail(T1{}, std::false_type{}, 0, 0.f, 0);
     s = 1;
   }
   // (first phase peeled so that every gather the loop waits for was issued by the same
@@ -2606,16 +1924,7 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
   prof.init((p.dbg & 32) && cw == 0 && unit == p.chain_begin);
   if (s < s_end) {
     issue(0, s - 1);
-    if constexpr (NT == 2) {
-      phase(T0{}, s);
-      for (;;) {
-        phase(T1{}, s);
-        if (++s >= s_end) break;
-        phase(T0{}, s);
-      }
-    } else {
-      for (; s < s_end; ++s) phase(T0{}, s);
-    }
+    for (; s < s_end; ++s) phase(T0{}, s);
   }
   prof.flush(p.status, w);
 #pragma unroll
@@ -2633,7 +1942,7 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
   }
 }
 
-template <int TPW, int NT, int PLACE>
+template <int TPW>
 __global__ void __launch_bounds__(kThreads)
 lstm_bwd_kernel_x(LstmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2641,8 +1950,8 @@ lstm_bwd_kernel_x(LstmParams p) {
   if (!map_block(p, unit_local, cw)) return;
   const int unit = p.chain_begin + unit_local;
   const bool fast = chain_on_one_xcd(p, unit, cw, reinterpret_cast<int*>(lds));
-  if (fast) bwd_body_x<TPW, true, NT, PLACE>(p, unit, cw, lds);
-  else bwd_body_x<TPW, false, NT, PLACE>(p, unit, cw, lds);
+  if (fast) bwd_body_x<TPW, true>(p, unit, cw, lds);
+  else bwd_body_x<TPW, false>(p, unit, cw, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -2832,7 +2141,7 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
       load_groups(rsrc);
       stale = !all_tagged<NL>(v, flip);
-      if (stale && wall_clock64() - t0 > kSpinTicks) { gave_up = true; break; }
+      if (stale && wall_clock64() - t0 > p.spin) { gave_up = true; break; }
     }
     if (__builtin_amdgcn_ballot_w64(gave_up) != 0ull) {
       dead = true;
@@ -3056,7 +2365,6 @@ lstm_bwd_kernel_c(LstmParams p) {
 // ---------------------------------------------------------------------------
 struct Plan {
   int R, P, TPW, MAXR, NKK, prec;
-  int pair;                // 1: a workgroup serves two batch tiles (lstm_fwd_kernel_k2)
   int n1;                  // 1: single-utterance forward kernel (2 chains = 2 directions)
   int form_c;              // 1: BPTT with the two-dimensional split (lstm_bwd_kernel_c)
   size_t shm;
@@ -3096,41 +2404,6 @@ kern_t pick_bwd_hv(int tpw) {
     case 4: return lstm_bwd_kernel_hv<4>;
     default: return lstm_bwd_kernel_hv<8>;
   }
-}
-kern_t pick_fwd_k(int nkk) {
-  switch (nkk) {
-    case 4: return lstm_fwd_kernel_k<1>;
-    case 8: return lstm_fwd_kernel_k<2>;
-    default: return lstm_fwd_kernel_k<4>;
-  }
-}
-kern_t pick_fwd_k2(int nkk, int place) {
-  if (nkk <= 8) return place == 0 ? lstm_fwd_kernel_k2<2, 0>
-                     : place == 1 ? lstm_fwd_kernel_k2<2, 1>
-                     : place == 3 ? lstm_fwd_kernel_k2<2, 3> : lstm_fwd_kernel_k2<2, 2>;
-  return place == 0 ? lstm_fwd_kernel_k2<4, 0>
-       : place == 1 ? lstm_fwd_kernel_k2<4, 1>
-       : place == 3 ? lstm_fwd_kernel_k2<4, 3> : lstm_fwd_kernel_k2<4, 2>;
-}
-kern_t pick_fwd_x(int nkk, int nt, int place) {
-  if (nkk <= 8) return nt == 1 ? lstm_fwd_kernel_x<2, 1, 1>
-                     : place == 0 ? lstm_fwd_kernel_x<2, 2, 0>
-                     : place == 3 ? lstm_fwd_kernel_x<2, 2, 3> : lstm_fwd_kernel_x<2, 2, 1>;
-  return nt == 1 ? lstm_fwd_kernel_x<4, 1, 1>
-       : place == 0 ? lstm_fwd_kernel_x<4, 2, 0>
-       : place == 3 ? lstm_fwd_kernel_x<4, 2, 3> : lstm_fwd_kernel_x<4, 2, 1>;
-}
-kern_t pick_bwd_h2(int tpw, int place) {
-  if (tpw <= 4) return place == 3 ? lstm_bwd_kernel_h2<4, 3>
-                     : place == 2 ? lstm_bwd_kernel_h2<4, 2> : lstm_bwd_kernel_h2<4, 1>;
-  return place == 3 ? lstm_bwd_kernel_h2<8, 3>
-       : place == 2 ? lstm_bwd_kernel_h2<8, 2> : lstm_bwd_kernel_h2<8, 1>;
-}
-kern_t pick_bwd_x(int tpw, int nt, int place) {
-  if (tpw <= 4) return nt == 1 ? lstm_bwd_kernel_x<4, 1, 1>
-                     : place == 3 ? lstm_bwd_kernel_x<4, 2, 3> : lstm_bwd_kernel_x<4, 2, 1>;
-  return nt == 1 ? lstm_bwd_kernel_x<8, 1, 1>
-       : place == 3 ? lstm_bwd_kernel_x<8, 2, 3> : lstm_bwd_kernel_x<8, 2, 1>;
 }
 kern_t pick_bwd_h(int tpw) {
   switch (tpw) {
@@ -3175,7 +2448,6 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   // 0 = exact fp32 MFMA
   pl.prec = env_int("ASR_LSTM_PREC", 1) ? 1 : 0;
   pl.NKK = 0;
-  pl.pair = 0;
   pl.n1 = 0;
   pl.form_c = 0;
   if (!bwd && a->n_valid == 1 && a->mode == 0 && (H == 256 || H == 512) &&
@@ -3200,31 +2472,19 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       pl.xchain_words = (size_t)2 * (H / 4) * (size_t)(fwd_xstride() / 4);
       const int nkk = (H + 31) / 32;
       pl.NKK = nkk <= 4 ? 4 : nkk <= 8 ? 8 : 16;
-      pl.shm = (size_t)4 * 16 * (32 * pl.NKK + 8) * 2;
-      k = pick_fwd_h(pl.NKK);
-      // K split over the waves (fwd_body_k): wins from H = 256 up, not for narrow layers
-      const bool variants = a->mi || a->zone_c || a->zone_h || a->uh;   // fwd_body_h only
-      if (variants) k = pick_fwd_hv(pl.NKK);
-      if (!variants && env_int("ASR_LSTM_KSPLIT", pl.NKK >= 8 ? 1 : 0)) {
+      const bool variants = a->mi || a->zone_c || a->zone_h || a->uh;
+      // ASR_LSTM_GENERIC=1: the any-H kernels (lstm_*_kernel_h) also where the specialised
+      // ones apply (tests compare the two)
+      const bool generic = env_int("ASR_LSTM_GENERIC", 0) != 0;
+      if (!variants && !generic && a->mode == 0 && (H == 256 || H == 512)) {
+        // plain cell, persistent mode, H = 128 NKW: K split over the waves, U fragments in
+        // AGPRs (fwd_body_x)
         pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
-        k = pick_fwd_k(pl.NKK);
-        // two batch tiles per workgroup (ASR_LSTM_PAIR=0 disables): persistent mode, an
-        // even number of tiles, every lane's gather groups and units present
-        // ASR_LSTM_FWD_GEN: 3 = fwd_body_x (default; one batch tile per workgroup, ASR_LSTM_PAIR=1:
-        // two -- measured slower with this generation: 1.88 vs 1.58 us per step at H = 256,
-        // 2.70 vs 1.91 at H = 512), 2 = fwd_body_k2 when paired, 1 = fwd_body_k
-        const int gen = env_int("ASR_LSTM_FWD_GEN", 3);
-        const bool wide = a->mode == 0 && (H == 256 || H == 512);
-        const bool even = (a->n_pad / 16) % 2 == 0;
-        const int pair_f = env_int("ASR_LSTM_PAIR", gen >= 3 ? 0 : 1);
-        const int place_f = env_int("ASR_LSTM_PAIR_PLACE", 1);
-        if (wide && gen >= 3) {
-          pl.pair = (pair_f && even) ? 1 : 0;
-          k = pick_fwd_x(pl.NKK, pl.pair ? 2 : 1, place_f);
-        } else if (wide && gen == 2 && pair_f && even) {
-          pl.pair = 1;
-          k = pick_fwd_k2(pl.NKK, place_f);
-        }
+        k = H == 256 ? lstm_fwd_kernel_x<2> : lstm_fwd_kernel_x<4>;
+      } else {
+        // any H, the cell variants, stepwise mode: h staged in LDS once per step (fwd_body_h)
+        pl.shm = (size_t)4 * 16 * (32 * pl.NKK + 8) * 2;
+        k = variants ? pick_fwd_hv(pl.NKK) : pick_fwd_h(pl.NKK);
       }
     }
   } else {
@@ -3241,32 +2501,21 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     if (pl.prec == 1) {
       pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 72 * 2);
       const bool variants = a->mi || a->zone_c || a->zone_h;
-      k = variants ? pick_bwd_hv(pl.TPW) : pick_bwd_h(pl.TPW);
-      // plain cell, persistent mode, H = 256 / 512: the third-generation kernel
-      // (ASR_LSTM_BWD_GEN: 3 = bwd_body_x (default), 2 = bwd_body_h2 when paired, 1 = bwd_body_h),
-      // one batch tile per workgroup; ASR_LSTM_PAIR_B=1: two when the tile count is even
-      // (measured slower: 2.70 vs 1.75 us per step at H = 256, 5.5 vs 3.35 at H = 512)
-      const int gen = env_int("ASR_LSTM_BWD_GEN", 3);
-      const bool wide = !variants && a->mode == 0 && (H == 256 || H == 512);
-      const bool even = (a->n_pad / 16) % 2 == 0;
-      const int pair_b = env_int("ASR_LSTM_PAIR_B", 0);
-      const int place_b = env_int("ASR_LSTM_PAIR_PLACE_B", 1);
-      // ASR_LSTM_BWD_2D: 1 = the two-dimensional split (bwd_body_c), 0 = bwd_body_x;
-      // default: from H = 512 on, where the partial-tile exchange of bwd_body_x is 1 MB per
-      // chain-step
-      const bool form_c = wide && env_int("ASR_LSTM_BWD_2D", H >= 512 ? 1 : 0) != 0 && gen >= 3;
+      const bool generic = env_int("ASR_LSTM_GENERIC", 0) != 0;
+      const bool wide = !variants && !generic && a->mode == 0 && (H == 256 || H == 512);
+      // ASR_LSTM_BWD_2D: 1 = the two-dimensional split (bwd_body_c), 0 = bwd_body_x; default:
+      // from H = 512 on, where the partial-tile exchange of bwd_body_x is 1 MB per chain-step
+      // (measured at H = 256: 1.89 us per step against 1.60)
+      const bool form_c = wide && env_int("ASR_LSTM_BWD_2D", H >= 512 ? 1 : 0) != 0;
       if (form_c) {
-        pl.pair = 0;
         pl.form_c = 1;
         pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 264 * 2);
         pl.xchain_words = (size_t)4 * 4 * (H / 64) * (H / 64) * 256;
         k = H == 256 ? lstm_bwd_kernel_c<1> : lstm_bwd_kernel_c<2>;
-      } else if (wide && gen >= 3) {
-        pl.pair = (pair_b && even) ? 1 : 0;
-        k = pick_bwd_x(pl.TPW, pl.pair ? 2 : 1, place_b);
-      } else if (wide && gen == 2 && pair_b && even) {
-        pl.pair = 1;
-        k = pick_bwd_h2(pl.TPW, place_b);
+      } else if (wide) {
+        k = H == 256 ? lstm_bwd_kernel_x<4> : lstm_bwd_kernel_x<8>;
+      } else {
+        k = variants ? pick_bwd_hv(pl.TPW) : pick_bwd_h(pl.TPW);
       }
     }
   }
@@ -3304,7 +2553,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     return ASR_ERR_RESIDENCY;
   }
   long cpl = cap / pl.P;
-  if (cpl > chains) cpl = chains;      // (in pair mode: counted in pairs by run())
+  if (cpl > chains) cpl = chains;
   pl.chains_per_launch = (int)cpl;
   *out = pl;
   if (kout) *kout = k;
@@ -3402,18 +2651,19 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
                        (long long)((zero_b + xb) / 16), reinterpret_cast<unsigned*>(p.dz_absmax));
     ASR_CHECK_LAUNCH();
   }
-  // launch units: chains, or pairs of chains when a workgroup serves two batch tiles
-  const int chains = pl.n1 ? 2 : pl.pair ? p.NB : 2 * p.NB;
+  const int chains = pl.n1 ? 2 : 2 * p.NB;
   const bool stepwise = a->mode == 1;
   p.poll = stepwise ? 0 : 1;
   p.allow_fast = env_int("ASR_LSTM_FAST", 1);
   p.dbg = env_int("ASR_LSTM_DBG", 0);
   // measured optimum on MI355X (tools/sweep_poll.sh, tools/sweep_r2c.sh): forward 8-16 naps
   // (~0.4 us; flat in that range), BPTT 4
-  p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.pair ? 0 : pl.form_c ? 2 : 4)
-                  : env_int("ASR_LSTM_PREPOLL_F", pl.pair ? 0 : pl.P <= 16 ? 12 : 16);
+  p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.form_c ? 2 : 4)
+                  : env_int("ASR_LSTM_PREPOLL_F", pl.P <= 16 ? 12 : 16);
   p.repoll = bwd ? env_int("ASR_LSTM_REPOLL_B", 1) : env_int("ASR_LSTM_REPOLL_F", 1);
   p.xstride = fwd_xstride();
+  // ASR_LSTM_SPIN_MS: bound of a persistent kernel's spins in milliseconds (default 600)
+  p.spin = (long long)env_int("ASR_LSTM_SPIN_MS", 600) * 100000LL;
   const int steps_per_launch = stepwise ? 1 : (r_end - r_begin);
   for (int s0 = r_begin; s0 < r_end; s0 += steps_per_launch) {
     // the XCC table is rebuilt by every persistent launch (placement may differ)

@@ -158,84 +158,6 @@ def test_sticky_timeout_flag_survives_later_calls_and_is_reported_once():
     assert not ops.lstm_timeout_flags(dev).any().item()
 
 
-@pytest.mark.parametrize('N,H,place', [(32, 256, 0), (32, 256, 1), (32, 256, 2), (32, 256, 3), (64, 512, 1),
-                                       (20, 256, 1)])
-def test_paired_forward_kernel_matches_the_default_one(N, H, place, monkeypatch):
-    """ASR_LSTM_PAIR=1 (lstm_fwd_kernel_k2: one workgroup alternates between the two batch
-    tiles of a direction, gathers prefetched during the other tile's phase) performs the same
-    arithmetic as the default forward kernel (same products and summation order, the cell
-    update shared with contraction off): identical bits, whole sequence and sliced, with a
-    recurrent-dropout mask -- so a batch row's result does not depend on which of the two
-    kernels processed it."""
-    from asr_study_amd import ops
-    T = 61
-    rs = np.random.RandomState(H + N + place)
-    n_pad = ops.pad16(N)
-    dev = 'cuda:0'
-    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
-    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
-    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
-
-    def run(ranges):
-        y = torch.zeros(T, n_pad, 2 * H, device=dev)
-        cell = torch.zeros(T, n_pad, 2, H, device=dev)
-        gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
-        for r in ranges:
-            ws = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask, steps=r)
-        ops.lstm_status(ws)
-        return [t.cpu().numpy() for t in (y, cell, gates)]
-    monkeypatch.setenv('ASR_LSTM_PAIR', '0')
-    want = run([None])
-    monkeypatch.setenv('ASR_LSTM_PAIR', '1')
-    monkeypatch.setenv('ASR_LSTM_PAIR_PLACE', str(place))
-    whole = run([None])
-    for name, a, b in zip(('y', 'cell', 'gates'), want, whole):
-        assert np.array_equal(a, b), name
-    sliced = run([(0, 17), (17, 30), (47, 14)])
-    for name, a, b in zip(('y', 'cell', 'gates'), whole, sliced):
-        assert np.array_equal(a, b), name
-
-
-@pytest.mark.parametrize('N,H,place', [(32, 256, 1), (32, 256, 3), (32, 256, 2), (64, 512, 1),
-                                       (20, 256, 1)])
-def test_paired_bptt_kernel_matches_the_default_one(N, H, place, monkeypatch):
-    """ASR_LSTM_PAIR_B=1 (lstm_bwd_kernel_h2: two batch tiles per workgroup in BPTT) against
-    the default BPTT kernel on the same forward activations: same products and summation
-    order, cell gradient evaluated by separately compiled code (1e-6 of the largest
-    gradient); sliced == whole bit for bit; max|dz| exact; with a recurrent-dropout mask."""
-    from asr_study_amd import ops
-    T = 61
-    rs = np.random.RandomState(H + N + place)
-    n_pad = ops.pad16(N)
-    dev = 'cuda:0'
-    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
-    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
-    dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.1).astype(np.float32)).to(dev)
-    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
-    y = torch.zeros(T, n_pad, 2 * H, device=dev)
-    cell = torch.zeros(T, n_pad, 2, H, device=dev)
-    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
-    ops.lstm_status(ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask))
-
-    def run(ranges):
-        dz = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
-        amax = torch.zeros(1, device=dev)
-        for r in ranges:
-            ws = ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=mask,
-                                  dz_absmax=amax, steps=r)
-        ops.lstm_status(ws)
-        return dz.cpu().numpy(), amax.cpu().numpy()
-    monkeypatch.setenv('ASR_LSTM_PAIR_B', '0')
-    want, _ = run([None])
-    monkeypatch.setenv('ASR_LSTM_PAIR_B', '1')
-    monkeypatch.setenv('ASR_LSTM_PAIR_PLACE_B', str(place))
-    whole, amax = run([None])
-    assert np.abs(whole - want).max() < 1e-6 * np.abs(want).max()
-    assert np.abs(whole).max() == amax[0]
-    sliced, amax2 = run([(0, 17), (17, 30), (47, 14)])
-    assert np.array_equal(whole, sliced) and amax2[0] == amax[0]
-
-
 @pytest.mark.parametrize('T,N,H,use_mi,use_zone', [
     (23, 5, 16, True, False),
     (23, 5, 16, False, True),
@@ -404,14 +326,14 @@ def test_layer_normalised_cell(T, N, H, use_mi, use_zone, use_mask):
 
 
 @pytest.mark.parametrize('N,H', [(32, 256), (64, 512), (16, 512), (48, 256)])
-def test_recurrent_kernel_generations_agree_and_bptt_emits_bias_gradient(N, H, monkeypatch):
-    """Forward: the default kernel (lstm_fwd_kernel_x) against the first-generation one, one
-    tile per workgroup == two, sliced == whole, both transports, bit for bit.  The default BPTT kernel (lstm_bwd_kernel_x: MFMA operands in AGPRs, integer tag test,
-    bias gradient accumulated in registers) against the first-generation one
-    (ASR_LSTM_BWD_GEN=1) on the same activations: gate gradients to 1e-6 of the largest;
-    one tile per workgroup == two tiles per workgroup, sliced == whole, bit for bit;
-    db_part (per-batch-tile sums of dz over samples and steps) == the sums of the dz slab it
-    wrote, from every generation, also when the sequence is processed in slices."""
+def test_specialised_kernels_agree_with_the_generic_ones_and_bptt_emits_bias_gradient(N, H, monkeypatch):
+    """H = 256 / 512 run on specialised kernels (forward lstm_fwd_kernel_x: K split over the
+    waves, U fragments in AGPRs; BPTT lstm_bwd_kernel_x / _c); ASR_LSTM_GENERIC=1 forces the
+    any-H kernels (lstm_*_kernel_h) on the same problem.  Forward: activations to 2e-6;
+    sliced == whole and both transports bit for bit.  BPTT (one-dimensional split, the
+    two-dimensional one has its own test): gate gradients to 1e-6 of the largest, sliced ==
+    whole and both transports bit for bit; db_part (per-batch-tile sums of dz over samples and
+    steps) == the sums of the dz slab it wrote, from either kernel, also in slices."""
     from asr_study_amd import ops
     T = 45
     rs = np.random.RandomState(H + N)
@@ -421,6 +343,7 @@ def test_recurrent_kernel_generations_agree_and_bptt_emits_bias_gradient(N, H, m
     U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
     dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.1).astype(np.float32)).to(dev)
     mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
+
     def fwd(ranges):
         y = torch.full((T, n_pad, 2 * H), 3.0, device=dev)
         cell = torch.full((T, n_pad, 2, H), 3.0, device=dev)
@@ -429,23 +352,18 @@ def test_recurrent_kernel_generations_agree_and_bptt_emits_bias_gradient(N, H, m
             ws = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask, steps=r)
         ops.lstm_status(ws)
         return y, cell, gates
-    # forward: first generation vs the default kernel (lstm_fwd_kernel_x), one / two tiles per
-    # workgroup, sliced, both transports
-    monkeypatch.setenv('ASR_LSTM_FWD_GEN', '1')
+    monkeypatch.setenv('ASR_LSTM_GENERIC', '1')
     want_f = [t.cpu().numpy() for t in fwd([None])]
-    monkeypatch.setenv('ASR_LSTM_FWD_GEN', '3')
-    monkeypatch.setenv('ASR_LSTM_PAIR', '0')
+    monkeypatch.setenv('ASR_LSTM_GENERIC', '0')
     y, cell, gates = fwd([None])
     got_f = [t.cpu().numpy() for t in (y, cell, gates)]
     for a, b in zip(got_f, want_f):
         assert np.abs(a - b).max() < 2e-6 * max(1.0, np.abs(b).max())
-    for pair, ranges, transport in (('0', [(0, 1), (1, 16), (17, 28)], '1'), ('1', [None], '1'),
-                                    ('1', [(0, 30), (30, 15)], '0'), ('0', [None], '0')):
-        monkeypatch.setenv('ASR_LSTM_PAIR', pair)
+    for ranges, transport in (([(0, 1), (1, 16), (17, 28)], '1'), ([(0, 30), (30, 15)], '0'),
+                              ([None], '0')):
         monkeypatch.setenv('ASR_LSTM_FAST', transport)
         for a, b in zip([t.cpu().numpy() for t in fwd(ranges)], got_f):
-            assert np.array_equal(a, b), (pair, ranges, transport)
-    monkeypatch.delenv('ASR_LSTM_PAIR')
+            assert np.array_equal(a, b), (ranges, transport)
     monkeypatch.delenv('ASR_LSTM_FAST')
 
     def run(ranges):
@@ -460,29 +378,20 @@ def test_recurrent_kernel_generations_agree_and_bptt_emits_bias_gradient(N, H, m
         err = (dbp.double() - want).abs().max().item()
         assert err < 2e-5 * max(1.0, want.abs().max().item()), err
         return dz.cpu().numpy(), amax.cpu().numpy()
-    monkeypatch.setenv('ASR_LSTM_BWD_GEN', '1')
+    monkeypatch.setenv('ASR_LSTM_BWD_2D', '0')
+    monkeypatch.setenv('ASR_LSTM_GENERIC', '1')
     want, _ = run([None])
     run([(0, 20), (20, 25)])
-    if (n_pad // 16) % 2 == 0:
-        monkeypatch.setenv('ASR_LSTM_BWD_GEN', '2')
-        monkeypatch.setenv('ASR_LSTM_PAIR_B', '1')
-        run([(0, 20), (20, 25)])
-    monkeypatch.setenv('ASR_LSTM_BWD_GEN', '3')
-    monkeypatch.setenv('ASR_LSTM_PAIR_B', '0')
+    monkeypatch.setenv('ASR_LSTM_GENERIC', '0')
     single, amax = run([None])
     assert np.abs(single - want).max() < 1e-6 * np.abs(want).max()
     assert np.abs(single).max() == amax[0]
     sliced, amax2 = run([(0, 1), (1, 16), (17, 28)])
     assert np.array_equal(single, sliced) and amax2[0] == amax[0]
-    monkeypatch.setenv('ASR_LSTM_PAIR_B', '1')
-    paired, amax3 = run([None])
-    assert np.array_equal(single, paired) and amax3[0] == amax[0]
-    sliced2, _ = run([(0, 30), (30, 15)])
-    assert np.array_equal(paired, sliced2)
     for transport in ('0', '1'):
         monkeypatch.setenv('ASR_LSTM_FAST', transport)
         again, _ = run([None])
-        assert np.array_equal(paired, again)
+        assert np.array_equal(single, again)
 
 
 @pytest.mark.parametrize('N,H', [(64, 512), (16, 512), (32, 256), (48, 256)])

@@ -148,9 +148,10 @@ def _cfg3_layer(T, seed=0):
 def test_foreign_kernel_holding_cus_delays_a_chip_filling_recurrence_without_a_timeout():
     """The hazard of a collective beside a cfg3 recurrence: 2 x 4 x 32 spin-waiting workgroups
     need all 256 CUs.  A foreign kernel (asr_debug_occupy: the stand-in for an RCCL kernel)
-    that holds 64 CUs for 30 ms on another stream when the recurrence starts only DELAYS it --
-    the resident workgroups spin (bounded at 0.6 s) until their peers get a CU: no timeout
-    flag, bit-identical activations and gate gradients."""
+    that holds 64 CUs for 30 ms on another stream when the recurrence starts only DELAYS it
+    (measured on MI355X: the dispatcher does not start the 256-workgroup grid piecemeal beside
+    the foreign kernel; the recurrence ends when that kernel does): no timeout flag,
+    bit-identical activations and gate gradients."""
     import torch
     from asr_study_amd import ops
     L = _cfg3_layer(T=120)
@@ -177,15 +178,19 @@ def test_foreign_kernel_holding_cus_delays_a_chip_filling_recurrence_without_a_t
 
 
 @pytest.mark.timeout(240)
-def test_cu_starved_recurrence_times_out_is_vetoed_and_the_step_is_recovered():
-    """The same foreign kernel holding 64 CUs for LONGER than the spin bound (0.9 s > 0.6 s):
-    the resident workgroups of the chip-filling recurrence give up, the step's update is
-    vetoed on the device, the engine runs the batch again on the stepwise kernels and ends up
-    with the weights of an undisturbed run; the persistent kernels come back afterwards."""
+def test_cu_starved_recurrence_times_out_is_vetoed_and_the_step_is_recovered(monkeypatch):
+    """A chip-filling recurrence that does NOT get all its workgroups resident: the whole step
+    runs on a stream confined to 64 of the 256 CUs (asr_stream_create_cu_mask), so only a
+    quarter of the 2 x 4 x 32 spin-waiting workgroups are resident at a time and their bounded
+    spins (shortened to 30 ms for the test) give up -- a REAL timeout, not a flag set by hand.
+    The step's update is vetoed on the device, the engine runs the batch again on the stepwise
+    kernels (no co-residency needed) and ends up with the weights of an undisturbed run; the
+    persistent kernels come back after the retry gap."""
     import numpy as np
     import torch
     from asr_study_amd import ops
     from asr_study_amd.core import models, optimizers
+    monkeypatch.setenv('ASR_LSTM_SPIN_MS', '30')
     rs = np.random.RandomState(3)
     N, T, F, C = 64, 24, 16, 7
     x = rs.randn(N, T, F).astype(np.float32)
@@ -198,28 +203,25 @@ def test_cu_starved_recurrence_times_out_is_vetoed_and_the_step_is_recovered():
         m.compile(optimizer=optimizers.Adam(lr=1e-3, clipnorm=1.0))
         return m
     model, ref = fresh(), fresh()
-    os.environ['ASR_LSTM_RETRY_STEPS'] = '2'
-    try:
-        model._retry_gap = 2
+    model._retry_gap = 2
+    model.train_on_batch(batch)
+    ref.train_on_batch(batch)
+    assert model._recurrence_fills_chip(64)
+    dev = model.device
+    total = torch.cuda.get_device_properties(dev).multi_processor_count
+    masked = ops.cu_masked_stream(dev, 64, total)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(masked):
+        out = model.train_on_batch(batch)
+    torch.cuda.synchronize()
+    want = ref.train_on_batch(batch)
+    assert model.fallbacks == 1 and model.vetoed_steps == 1 and model.lstm_mode == 1
+    assert model.optimizer.iterations == ref.optimizer.iterations == 2
+    assert np.allclose(out, want, rtol=1e-4, atol=1e-5)
+    assert (model.params - ref.params).abs().max().item() < 1e-5
+    for _ in range(3):
         model.train_on_batch(batch)
         ref.train_on_batch(batch)
-        assert model._recurrence_fills_chip(64)
-        side = torch.cuda.Stream(device=model.device)
-        torch.cuda.synchronize()
-        with torch.cuda.stream(side):
-            ops.debug_occupy(64, 96 * 1024, 0.9)
-        out = model.train_on_batch(batch)
-        want = ref.train_on_batch(batch)
-        torch.cuda.synchronize()
-        assert model.fallbacks == 1 and model.vetoed_steps == 1 and model.lstm_mode == 1
-        assert model.optimizer.iterations == ref.optimizer.iterations == 2
-        assert np.allclose(out, want, rtol=1e-4, atol=1e-5)
-        assert (model.params - ref.params).abs().max().item() < 1e-5
-        for _ in range(3):
-            model.train_on_batch(batch)
-            ref.train_on_batch(batch)
-        assert model.lstm_mode == 0 and model.fallbacks == 1
-        assert (model.params - ref.params).abs().max().item() < 1e-5
-        assert not ops.lstm_timeout_flags(model.device).any().item()
-    finally:
-        os.environ.pop('ASR_LSTM_RETRY_STEPS', None)
+    assert model.lstm_mode == 0 and model.fallbacks == 1
+    assert (model.params - ref.params).abs().max().item() < 1e-5
+    assert not ops.lstm_timeout_flags(dev).any().item()
