@@ -43,11 +43,12 @@ class DatasetParser(object):
                 sigs = [np.asarray(r['input']) for r in recs[i:i + chunk]]
                 if input_parser is not None and str(input_parser) != 'raw':
                     slab, frames = input_parser.batch(sigs)
-                    slab = slab.cpu().numpy()
+                    # utterance-major on the device (one strided copy kernel), ONE D2H copy per
+                    # chunk, then contiguous (T_j * F) host slices
+                    host = slab.transpose(0, 1).contiguous().cpu().numpy()
                     frames = frames.cpu().numpy()
-                    nf = slab.shape[2]
-                    feats += [slab[:frames[j], j].reshape(-1).astype(np.float32)
-                              for j in range(len(sigs))]
+                    nf = host.shape[2]
+                    feats += [host[j, :frames[j]].reshape(-1) for j in range(len(sigs))]
                 else:
                     feats += [s.astype(np.float32).reshape(-1) for s in sigs]
             store[key] = dict(inputs=feats, num_feats=nf,

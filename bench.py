@@ -22,6 +22,7 @@ Besides the contract fields the line carries
   exact_fp32        cfg3 again with every product on the exact-fp32 MFMA instructions,
   predict_latency   one 10 s utterance end to end (predict.py's unit of work), ms,
   eval_beam         eval.py's beam-search decode of the bench batch, device and host, seconds,
+  dataset_build     make_dataset.py end to end on 2048 x 10 s through the GPU front-end,
   allreduce         bus bandwidth of the gradient all-reduce, N > 1 only.
 """
 import argparse
@@ -94,14 +95,14 @@ def cpu_baseline(cfg):
     except Exception:
         threads = os.cpu_count() or 1
 
-    def timed(fn, min_s, max_s):
+    def timed(fn, min_s, max_s, min_reps=1):
         fn()                                              # warm caches / BLAS threads
         t0 = time.time()
         reps = 0
-        while reps < 1 or time.time() - t0 < min_s:
+        while reps < min_reps or time.time() - t0 < min_s:
             fn()
             reps += 1
-            if time.time() - t0 > max_s:
+            if reps >= min_reps and time.time() - t0 > max_s:
                 break
         return (time.time() - t0) / reps, reps
 
@@ -121,13 +122,14 @@ def cpu_baseline(cfg):
             opt.step([a for _, a in OL.flatten(params)], [a for _, a in OL.flatten(out['grads'])])
         return step
 
-    # (1) the benchmarked topology, batch N x 1 s (T = 99)
-    n, secs = cfg['N'], 1.0
+    # (1) the benchmarked topology on a bounded sample: 16 utterances x 1 s (T = 99), at least
+    # three timed steps after a warm-up step
+    n, secs = 16, 1.0
     dt, reps = timed(train_step_fn(cfg['F'], cfg['H'], cfg['L'], cfg['C'], n, secs, kind, kw),
-                     8.0, 25.0)
+                     10.0, 25.0, min_reps=3)
     out = {'value': round(n * secs / dt, 2), 'unit': 'audio-seconds/s', 'cores': int(threads),
            'kind': 'port',
-           'sample': '%d utterances x %.0f s (T=99), same topology, %d step(s) of %.2f s: NumPy/'
+           'sample': '%d utterances x %.0f s (T=99), same topology, mean of %d steps of %.2f s: NumPy/'
                      'BLAS float32 oracle port incl. float64 front-end, CTC, BPTT, clip+Adam'
                      % (n, secs, reps, dt)}
     # (2) front-end alone, 10 s utterances: one core, then all cores (process pool)
@@ -234,6 +236,41 @@ def eval_beam(dev, model, slab, n_valid, frames):
         out['same_strings_width_%d' % width] = bool(
             all(d[n, :l[n]].tolist() == host[n] for n in range(n_valid)))
     out['host_threads'] = min(int(n_valid), os.cpu_count() or 1)
+    return out
+
+
+def dataset_build(dev, feat, utterances=2048, pool=32, chunk=64):
+    """N1 (extras/make_dataset.py:31-48 -> DatasetParser.to_h5, datasets/dataset_parser.py:
+    87-177): a synthetic corpus of `utterances` x 10 s through the GPU front-end into the
+    reference's HDF5 layout, END TO END -- host concatenation, H2D, the feature kernels, D2H,
+    slicing and the HDF5 write (ctypes libhdf5) -- in audio-seconds per second.  The samples
+    come from a pool of `pool` distinct N(0,1) signals (generating 2048 x 160000 normals would
+    time the host RNG, not the path)."""
+    import tempfile
+    from asr_study_amd.datasets.dataset_parser import DatasetParser
+    rs = np.random.RandomState(11)
+    sigs = [rs.randn(SAMPLES).astype(np.float32) for _ in range(pool)]
+
+    class Synth(DatasetParser):
+        def _iter(self):
+            for i in range(utterances):
+                yield {'input': sigs[i % pool], 'label': 'abc', 'duration': 10.0}
+    out = {'utterances': utterances, 'utterance_seconds': 10.0, 'chunk': chunk,
+           'features': str(feat) + str(feat.num_feats)}
+    with tempfile.TemporaryDirectory() as tmp:
+        for fmt in ('h5', 'npz'):
+            try:
+                path = os.path.join(tmp, 'corpus.' + fmt)
+                t0 = time.perf_counter()
+                Synth(name='synth').to_h5(path, input_parser=feat, split_sets=False,
+                                          chunk=chunk, fmt=fmt)
+                dt = time.perf_counter() - t0
+                out.update(value=round(utterances * 10.0 / dt, 1), unit='audio-seconds/s',
+                           seconds=round(dt, 3), format=fmt,
+                           file_MB=round(os.path.getsize(path) / 1e6, 1))
+                break
+            except Exception as e:                     # no libhdf5 on this host: npz layout
+                out['%s_error' % fmt] = repr(e)[:200]
     return out
 
 
@@ -638,6 +675,10 @@ def main():
                 line['eval_beam'] = eval_beam(dev, model, slab_e, N, slab_e.shape[0])
             except Exception as e:
                 line['eval_beam'] = {'error': repr(e)[:300]}
+            try:
+                line['dataset_build'] = dataset_build(dev, feat)
+            except Exception as e:
+                line['dataset_build'] = {'error': repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(line))
