@@ -211,6 +211,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    LIB_PATH = os.environ.get('ASR_LIB_PATH', LIB_PATH)      # (A/B runs of two builds)
     if not os.path.exists(LIB_PATH):
         raise AsrHipError(
             'libasr_hip.so not found at %s -- build it with '

@@ -2049,27 +2049,33 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   const int u0 = 64 * a + 4 * q;                   // its first unit
   const int s_end = p.s_begin + p.s_count;
   unsigned* xch = p.xbuf + (size_t)(dir * p.NB + bt) * p.xchain_words;
-  float4 cmask = make_float4(1.f, 1.f, 1.f, 1.f);
+  f32x4 cmask = {1.f, 1.f, 1.f, 1.f};
   if (p.mask_u)
-    cmask = *reinterpret_cast<const float4*>(p.mask_u + ((size_t)dir * p.n_pad + cn) * H + u0);
-  float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
+    cmask = *reinterpret_cast<const f32x4*>(p.mask_u + ((size_t)dir * p.n_pad + cn) * H + u0);
+  f32x4 dc = {0.f, 0.f, 0.f, 0.f};
   if (p.s_begin > 0)
-    dc = *reinterpret_cast<const float4*>(p.dc_state + ((size_t)dir * p.n_pad + cn) * H + u0);
+    dc = *reinterpret_cast<const f32x4*>(p.dc_state + ((size_t)dir * p.n_pad + cn) * H + u0);
+  // (waited for HERE, once: left pending, the first use inside the loop would be a vmcnt(0) in
+  // every iteration -- the compiler cannot know on which entry path they have landed)
+  asm volatile("" : "+v"(cmask), "+v"(dc));
   float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias-gradient partials of unit u0 + b
   float zmax = 0.f;
   bool dead = false;
   StepProf prof;
   prof.init(false);
 
-  // slab values of the NEXT step, prefetched one step ahead (c_prev of a step is c of the next)
-  float4 nx_dy, nx_c, nx_cp, nx_g[4];
-  float nx_hp = 0.f;                               // 1 if the step has a previous frame, else 0
+  // Slab values of the next TWO steps (sets A / B, used alternately, so that no register holding
+  // a value still in flight is ever copied -- a copy is waited for on the spot): a step's values
+  // are loaded two steps ahead, into the set the loading step has just consumed.
+  struct Slabs { f32x4 dy, c, cp, g[4]; float hp; };    // hp: 1 if the step has a previous frame
+  Slabs SA, SB;
   // Slab accesses as buffer operations: the frame part of an address is wave-uniform (scalar
   // arithmetic beside the VALU stream, folded into the resource's base), the (sample, unit) part
   // is a per-lane constant -- no vector address arithmetic in the step.
   const unsigned vo_dy = (unsigned)(((size_t)cn * H2 + dir * H + u0) * 4);
   const unsigned vo_c = (unsigned)((((size_t)cn * 2 + dir) * H + u0) * 4);
   const unsigned vo_g = (unsigned)((((size_t)cn * 2 + dir) * H4 + 4 * u0) * 4);
+  const unsigned vo_z = (n & 3) == b ? vo_g : 0xC0000000u;   // dz rows: owner lanes only
   // Frame bases of the step being LOADED (ld_*) and of the step being STORED (st_dz) as running
   // pointers: one scalar 64-bit add per slab and step.
   const long long fstep = dir == 0 ? -1 : 1;       // frame increment of a BPTT step
@@ -2078,10 +2084,8 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0,
                                              (unsigned)(frame_floats * 4), 0x00020000);
   };
-  auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned vo, int imm) -> float4 {
-    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, vo, imm, 0);
-    return make_float4(__uint_as_float(x[0]), __uint_as_float(x[1]), __uint_as_float(x[2]),
-                       __uint_as_float(x[3]));
+  auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned vo, int imm) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vo, imm, 0));
   };
   const int tt0 = dir == 0 ? p.T - 1 - p.s_begin : p.s_begin;      // frame of the first step
   const float* ld_dy = p.dy + (size_t)tt0 * fr_dy;
@@ -2089,26 +2093,23 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   const float* ld_g = p.gates + (size_t)tt0 * fr_g;
   float* st_dz = p.dz + (size_t)tt0 * fr_g;
   // loads the slab values of step ss (the frame the ld_* bases point at), then advances them
-  auto load_slabs = [&](int ss, bool first) {
+  auto load_slabs = [&](int ss, Slabs& S) {
     const bool has_prev = ss + 1 < p.T;            // the sequence's first frame has c_prev = 0
-    nx_dy = ld4(rs(ld_dy, fr_dy), vo_dy, 0);
-    // c of step ss is c_prev of step ss - 1 (already in registers), except at a launch's start
-    if (first) nx_c = ld4(rs(ld_c, fr_dy), vo_c, 0);
-    else nx_c = nx_cp;
+    S.dy = ld4(rs(ld_dy, fr_dy), vo_dy, 0);
+    S.c = ld4(rs(ld_c, fr_dy), vo_c, 0);
     // (no select on the fresh load: a step without a previous frame reads a valid row and
-    // multiplies it by nx_hp = 0 when the value is USED, one step later)
-    nx_cp = ld4(rs(has_prev ? ld_c + fstep * (long long)fr_dy : ld_c, fr_dy), vo_c, 0);
-    nx_hp = has_prev ? 1.f : 0.f;
+    // multiplies it by hp = 0 when the value is USED)
+    S.cp = ld4(rs(has_prev ? ld_c + fstep * (long long)fr_dy : ld_c, fr_dy), vo_c, 0);
+    S.hp = has_prev ? 1.f : 0.f;
     const __amdgpu_buffer_rsrc_t rg = rs(ld_g, fr_g);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) nx_g[j] = ld4(rg, vo_g, 16 * j);
+    for (int j = 0; j < 4; ++j) S.g[j] = ld4(rg, vo_g, 16 * j);
     if (ss + 1 < s_end) {                          // (past the launch's end: stay on a valid frame)
       ld_dy += fstep * (long long)fr_dy;
       ld_c += fstep * (long long)fr_dy;
       ld_g += fstep * (long long)fr_g;
     }
   };
-  load_slabs(p.s_begin, true);
 
   // gather: the 16-byte group (sample n, units 4 q ..) of the partial tiles of the PA producers
   // (a', a / OT), 1 KB apart (immediates of one offset register)
@@ -2152,20 +2153,28 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   // factors of one step that do not depend on the recurrent gradient (computed while the
   // gather is in flight): dz_o = dh A_o ; dcc = dc + dh B ; dz_{i,f,g} = dcc C_{i,f,g} ; dc' = dcc gf
   struct Pre { f32x4 dy, Ao, B, Ci, Cf, Cg, gf; };
-  auto precompute = [&]() -> Pre {
+  auto precompute = [&](Slabs& S) -> Pre {
+#pragma clang fp contract(off)
+    // The loaded registers pass through here untouched until NOW: whatever regrouping of them
+    // the compiler wants (operand pairs of packed instructions) happens behind this point, a
+    // whole step after the loads, not right behind them (where it would be waited for).
+    asm volatile("" : "+v"(S.dy), "+v"(S.c), "+v"(S.cp), "+v"(S.g[0]), "+v"(S.g[1]), "+v"(S.g[2]),
+                 "+v"(S.g[3]));
     Pre r;
-    r.dy = f32x4{nx_dy.x, nx_dy.y, nx_dy.z, nx_dy.w};
-    const float cc[4] = {nx_c.x, nx_c.y, nx_c.z, nx_c.w};
-    const float cp[4] = {nx_cp.x * nx_hp, nx_cp.y * nx_hp, nx_cp.z * nx_hp, nx_cp.w * nx_hp};
+    r.dy = S.dy;
+    const float cc[4] = {S.c[0], S.c[1], S.c[2], S.c[3]};
+    const float cp[4] = {S.cp[0] * S.hp, S.cp[1] * S.hp, S.cp[2] * S.hp, S.cp[3] * S.hp};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float gi = nx_g[j].x, gf = nx_g[j].y, gg = nx_g[j].z, go = nx_g[j].w;
+      const float gi = S.g[j][0], gf = S.g[j][1], gg = S.g[j][2], go = S.g[j][3];
       const float tch = fast_tanh_rcp(cc[j]);
+      // (explicit FMAs, contraction off: the two copies of a phase in the unrolled loop must
+      // round identically, or a step's result would depend on which of them processed it)
       r.Ao[j] = tch * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
-      r.B[j] = go * (1.f - tch * tch);
+      r.B[j] = go * __builtin_fmaf(-tch, tch, 1.f);
       r.Ci[j] = gg * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
       r.Cf[j] = cp[j] * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
-      r.Cg[j] = gi * (1.f - gg * gg);
+      r.Cg[j] = gi * __builtin_fmaf(-gg, gg, 1.f);
       r.gf[j] = gf;
     }
     // keep all of it AHEAD of the await (the compiler would sink it to its uses behind the
@@ -2177,26 +2186,27 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
 
   // everything of one step after its recurrent gradient is known: gate gradients of the four
   // units, dz slab + LDS tile, barrier, partial dh tiles of this block, publish, next gather
-  auto tail = [&](int s, const Pre& pre, const float4& dh_rec, bool do_issue) {
+  auto tail = [&](int s, const Pre& pre, const float4& dh_rec, bool do_issue, Slabs& S) {
+#pragma clang fp contract(off)
     float* sinv = lds + (size_t)(s & 1) * kBufFloats;         // [16] 1 / scale
     _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZS] hi
     _Float16* dzl = dzh + 16 * DZS;                           // [16][DZS] lo
     float z[4][4];
     {
       const float dr[4] = {dh_rec.x, dh_rec.y, dh_rec.z, dh_rec.w};
-      const float cm[4] = {cmask.x, cmask.y, cmask.z, cmask.w};
-      float dcv[4] = {dc.x, dc.y, dc.z, dc.w};
+      const float cm[4] = {cmask[0], cmask[1], cmask[2], cmask[3]};
+      float dcv[4] = {dc[0], dc[1], dc[2], dc[3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float dh = pre.dy[j] + cm[j] * dr[j];
-        const float dcc = dcv[j] + dh * pre.B[j];
+        const float dh = __builtin_fmaf(cm[j], dr[j], pre.dy[j]);
+        const float dcc = __builtin_fmaf(dh, pre.B[j], dcv[j]);
         z[j][0] = dcc * pre.Ci[j];
         z[j][1] = dcc * pre.Cf[j];
         z[j][2] = dcc * pre.Cg[j];
         z[j][3] = dh * pre.Ao[j];
         dcv[j] = dcc * pre.gf[j];
       }
-      dc = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
+      dc = f32x4{dcv[0], dcv[1], dcv[2], dcv[3]};
     }
     // power-of-two scale of this sample's 256 columns: max over its 16 threads (one DPP row)
     float m = 0.f;
@@ -2228,25 +2238,27 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       *reinterpret_cast<h8*>(rl) = lo8[0];
       *reinterpret_cast<h8*>(rl + 8) = lo8[1];
     }
-    // off the dependent path (the other waves are still on their way to the barrier): the
-    // next step's slab values, and this workgroup's rows of the dz slab
-    // (unconditional: values loaded under a branch are waited for at its end; past the
-    // launch's last step the bases stay on a valid frame and the values are never used)
-    load_slabs(s + 1, false);
-    if ((n & 3) == b) {
-      const __amdgpu_buffer_rsrc_t rz = rs(st_dz, fr_g);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 zz = {z[j][0], z[j][1], z[j][2], z[j][3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rz, vo_g, 16 * j, 0);
-      }
-    }
-    st_dz += fstep * (long long)fr_g;
     // (b is uniform: scalar branches, no indexed access)
     if (b == 0) { gsum.x += z[0][0]; gsum.y += z[0][1]; gsum.z += z[0][2]; gsum.w += z[0][3]; }
     else if (b == 1) { gsum.x += z[1][0]; gsum.y += z[1][1]; gsum.z += z[1][2]; gsum.w += z[1][3]; }
     else if (b == 2) { gsum.x += z[2][0]; gsum.y += z[2][1]; gsum.z += z[2][2]; gsum.w += z[2][3]; }
     else { gsum.x += z[3][0]; gsum.y += z[3][1]; gsum.z += z[3][2]; gsum.w += z[3][3]; }
+    // off the dependent path (the other waves are still on their way to the barrier), and ahead
+    // of the publish and the gather in the CU's in-order memory queue only by a whole MFMA phase:
+    // this workgroup's rows of the dz slab, and the slab values of step s + 2 into the set this
+    // step has just consumed
+    {
+      // (no branch around them, so that the compiler can count them in its waits: the lanes
+      // that do not own the row store beyond the resource's range, which the hardware drops)
+      const __amdgpu_buffer_rsrc_t rz = rs(st_dz, fr_g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 zz = {z[j][0], z[j][1], z[j][2], z[j][3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rz, vo_z, 16 * j, 0);
+      }
+    }
+    st_dz += fstep * (long long)fr_g;
+    load_slabs(s + 2, S);
     prof.stamp(2);
     __syncthreads();
     prof.stamp(3);
@@ -2296,34 +2308,46 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     if (do_issue) issue(s);
   };
 
+  // one step s >= 1 on slab set S
+  auto phase = [&](int s, Slabs& S) {
+    prof.stamp(5);
+    const Pre pre = precompute(S);                 // overlaps the hand-off
+    prof.stamp(0);
+    await(s - 1);
+    prof.stamp(1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {                 // (the tag bit stays in: <= 1 ulp)
+      acc.x += __uint_as_float(v[i][0]); acc.y += __uint_as_float(v[i][1]);
+      acc.z += __uint_as_float(v[i][2]); acc.w += __uint_as_float(v[i][3]);
+    }
+    tail(s, pre, acc, true, S);                    // (after the last step a harmless unused read)
+  };
+  // Both ways into the loop leave the vector-memory queue as the loop body does: the gather
+  // is the youngest operation, both slab sets are older (the waits the compiler counts for the
+  // loop body are the worst case over every path into it).
   int s = p.s_begin;
   if (s == 0) {
-    // step 0: no recurrent gradient yet, nothing to gather
-    const Pre pre = precompute();
-    tail(0, pre, make_float4(0.f, 0.f, 0.f, 0.f), false);
+    // step 0: no recurrent gradient yet, nothing to gather before it
+    load_slabs(0, SA);
+    load_slabs(1, SB);
+    const Pre pre = precompute(SA);
+    tail(0, pre, make_float4(0.f, 0.f, 0.f, 0.f), true, SA);   // (reloads SA with step 2)
     s = 1;
+  } else {
+    load_slabs(s, SB);
+    load_slabs(s + 1, SA);
+    issue(s - 1);                                  // continuing a sequence
   }
   prof.init((p.dbg & 32) && cw == 0 && unit == p.chain_begin);
-  if (s < s_end) {
-    issue(s - 1);
-    for (; s < s_end; ++s) {
-      prof.stamp(5);
-      const Pre pre = precompute();                // overlaps the hand-off
-      prof.stamp(0);
-      await(s - 1);
-      prof.stamp(1);
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {               // (the tag bit stays in: <= 1 ulp)
-        acc.x += __uint_as_float(v[i][0]); acc.y += __uint_as_float(v[i][1]);
-        acc.z += __uint_as_float(v[i][2]); acc.w += __uint_as_float(v[i][3]);
-      }
-      tail(s, pre, acc, true);                     // (after the last step a harmless unused read)
-    }
+  for (; s + 1 < s_end; s += 2) {
+    phase(s, SB);
+    phase(s + 1, SA);
   }
+  if (s < s_end) phase(s, SB);
   prof.flush(p.status, w);
   if (b == 0)
-    *reinterpret_cast<float4*>(p.dc_state + ((size_t)dir * p.n_pad + cn) * H + u0) = dc;
+    *reinterpret_cast<f32x4*>(p.dc_state + ((size_t)dir * p.n_pad + cn) * H + u0) = dc;
   if (p.db_part) {
     // sum over the 16 samples of every thread's float4 (unit u0 + b), fixed order
     float vs[4] = {gsum.x, gsum.y, gsum.z, gsum.w};
