@@ -805,7 +805,7 @@ template <> struct FwdMfma<4> {
   }
 };
 
-template <int NKW, bool FAST>
+template <int NKW, bool FAST, bool EXACT>
 __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg, float* lds) {
   // Requires H == 128 * NKW (every lane's gather groups and units exist)
   constexpr int NT = 1;                            // batch tiles per workgroup
@@ -821,9 +821,28 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
   const int kbase = 32 * NKW * w;                  // first unit of this wave's K slice
   f32x4* part = reinterpret_cast<f32x4*>(lds);     // [2 bufs][4 waves][4 gate tiles][64 lanes]
 
+  // EXACT: the products on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate, bitwise an fmaf
+  // chain).  MFMA m = (kk, half, e) of a gate tile takes from lane (g, nl) the fp32 word e of
+  // its gathered group (kk, half), i.e. k-index g <-> unit kbase + 32 kk + 8 g + 4 half + e: the
+  // exchange layout and the gather are those of the split path, the words are plain tagged fp32.
+  constexpr int NM = EXACT ? 8 * NKW : 1;          // fp32 MFMAs per gate tile
+  float uf[4][NM];                                 // EXACT: one A-fragment register each (AGPRs)
+  if constexpr (EXACT) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ugj = wg * 4 + j;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const int k = kbase + 32 * (m >> 3) + 8 * g + (m & 7);      // (m & 7) = 4 half + e
+        uf[j][m] = p.U[((size_t)(dir * H + k)) * H4 + 16 * ugj + nl];
+        asm volatile("" : "+a"(uf[j][m]));         // AGPR-class from here on
+      }
+    }
+  }
   f32x4 ufh[4][NKW], ufl[4][NKW];                  // bit patterns of 8 halfs each (AGPRs)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    if constexpr (EXACT) break;
     const int ugj = wg * 4 + j;
 #pragma unroll
     for (int kk = 0; kk < NKW; ++kk) {
@@ -914,7 +933,8 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     const int t = dir == 0 ? s : p.T - 1 - s;
     const CellFwd o = cell_forward(a, zx4, c[x], mask[x]);
     c[x] = o.c;
-    const unsigned w0 = packed_word(o.hm, (unsigned)(s >> 1) & 1u);
+    const unsigned w0 = EXACT ? tag_word(o.hm, (unsigned)(s >> 1) & 1u)
+                              : packed_word(o.hm, (unsigned)(s >> 1) & 1u);
     // (the last step's word is published too: nobody reads it, and no branch is needed)
     __builtin_amdgcn_raw_buffer_store_b32(w0, slot(x, s),
                                           (unsigned)(ug * p.xstride + nl * 16 + g * 4), 0,
@@ -933,6 +953,29 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     await(x, s - 1, (unsigned)((s - 1) >> 1) & 1u);
     prof.stamp(1);
     zx_next[x] = load_zx(x, s + 1);
+    // two LDS buffers by step parity (the one barrier per step keeps the waves at most one
+    // step apart)
+    const int buf = s & 1;
+    f32x4* mine = part + ((size_t)buf * 4 + w) * 4 * 64;
+    if constexpr (EXACT) {
+      // the gathered fp32 words ARE the B operands (tag bit left in: <= 1 ulp); the four gate
+      // tiles' accumulator chains are interleaved (32 cycles of pipe per MFMA, 40 of latency)
+      f32x4 acc[4];
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const float bw = __uint_as_float(v[x][m >> 2][m & 3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (m == 0)
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc[j]) : "a"(uf[j][0]), "v"(bw));
+          else
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "a"(uf[j][m]), "v"(bw));
+        }
+      }
+      asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mine[j * 64 + lane] = acc[j];
+    } else {
     // exchanged word = fp16 hi << 16 | fp16 lo (tag = LSB of lo, left in place)
     h8 bh[NKW], bl[NKW];
 #pragma unroll
@@ -950,10 +993,6 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       bh[kk] = __builtin_bit_cast(h8, hi);
       bl[kk] = __builtin_bit_cast(h8, lo);
     }
-    // two LDS buffers by step parity (the one barrier per step keeps the waves at most one
-    // step apart)
-    const int buf = s & 1;
-    f32x4* mine = part + ((size_t)buf * 4 + w) * 4 * 64;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 am, ac;
@@ -962,6 +1001,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(ac[e], 1.f / kLoScale, am[e]);
       mine[j * 64 + lane] = r;
+    }
     }
     prof.stamp(2);
     __syncthreads();
@@ -994,7 +1034,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
   prof.flush(p.status, w);
 }
 
-template <int NKW>
+template <int NKW, bool EXACT>
 __global__ void __launch_bounds__(kThreads)
 lstm_fwd_kernel_x(LstmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1002,8 +1042,8 @@ lstm_fwd_kernel_x(LstmParams p) {
   if (!map_block(p, unit_local, wg)) return;
   const int unit = p.chain_begin + unit_local;
   const bool fast = chain_on_one_xcd(p, unit, wg, reinterpret_cast<int*>(lds));
-  if (fast) fwd_body_x<NKW, true>(p, unit, wg, lds);
-  else fwd_body_x<NKW, false>(p, unit, wg, lds);
+  if (fast) fwd_body_x<NKW, true, EXACT>(p, unit, wg, lds);
+  else fwd_body_x<NKW, false, EXACT>(p, unit, wg, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -2009,13 +2049,14 @@ __device__ __forceinline__ void mfma_settle(f32x4& am, f32x4& a1, f32x4& a2) {
   asm volatile("s_nop 13" : "+v"(am), "+v"(a1), "+v"(a2));
 }
 
-template <int OT, bool FAST>
+template <int OT, bool FAST, bool EXACT>
 __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw, float* lds) {
   constexpr int PA = 4 * OT;                       // reduction slices (H / 64)
   constexpr int KS = 8;                            // K-steps of 32 columns per slice
   constexpr int NTILE = 4 * OT;                    // output tiles of a workgroup
   constexpr int DZS = 264;                         // LDS row stride of the dz tile (halfs)
-  constexpr int kBufFloats = 16 + (2 * 16 * DZS) / 2;         // sinv + hi + lo
+  constexpr int DZF = 260;                         // EXACT: row stride of the fp32 dz tile (floats)
+  constexpr int kBufFloats = EXACT ? 16 * DZF : 16 + (2 * 16 * DZS) / 2;   // fp32 tile | sinv + hi + lo
   constexpr int kSlotWords = 4 * NTILE * PA * 256;            // one exchange slot of a chain
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -2025,9 +2066,28 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   const int a = cw % PA, b = cw / PA;
   const int dir = unit / p.NB, bt = unit % p.NB;
 
+  // EXACT: products on v_mfma_f32_16x16x4_f32.  MFMA m = (c4, e) of an output tile takes from
+  // lane (g, nl) the fp32 word e of its 16-byte LDS read c4 (columns 16 c4 + 4 g .. + 3 of sample
+  // nl), i.e. k-index g <-> column 16 c4 + 4 g + e of the slice: the dz tile stays plain fp32 in
+  // LDS (no per-sample scale, no split), the U^T fragments are one fp32 register per MFMA.
+  constexpr int NM = EXACT ? 64 : 1;               // fp32 MFMAs per output tile
+  float uf[OT][NM];
+  if constexpr (EXACT) {
+#pragma unroll
+    for (int i = 0; i < OT; ++i) {
+      const int orow = 64 * OT * b + 16 * (w + 4 * i) + nl;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const int j = 256 * a + 16 * (m >> 2) + 4 * g + (m & 3);
+        uf[i][m] = p.U[((size_t)(dir * H + orow)) * H4 + j];
+        asm volatile("" : "+a"(uf[i][m]));         // AGPR-class from here on
+      }
+    }
+  }
   f32x4 ufh[OT][KS], ufl[OT][KS];                  // bit patterns of 8 halfs each (AGPRs)
 #pragma unroll
   for (int i = 0; i < OT; ++i) {
+    if constexpr (EXACT) break;
     const int orow = 64 * OT * b + 16 * (w + 4 * i) + nl;     // output unit of this lane's A row
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
@@ -2208,6 +2268,17 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       }
       dc = f32x4{dcv[0], dcv[1], dcv[2], dcv[3]};
     }
+    if constexpr (EXACT) {
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(z[j][0]), fabsf(z[j][1])), fmaxf(fabsf(z[j][2]), fabsf(z[j][3]))));
+      zmax = fmaxf(zmax, m);
+      float* row = lds + (size_t)(s & 1) * kBufFloats + n * DZF + 16 * q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(row + 4 * j) = f32x4{z[j][0], z[j][1], z[j][2], z[j][3]};
+    } else {
     // power-of-two scale of this sample's 256 columns: max over its 16 threads (one DPP row)
     float m = 0.f;
 #pragma unroll
@@ -2238,6 +2309,7 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       *reinterpret_cast<h8*>(rl) = lo8[0];
       *reinterpret_cast<h8*>(rl + 8) = lo8[1];
     }
+    }
     // (b is uniform: scalar branches, no indexed access)
     if (b == 0) { gsum.x += z[0][0]; gsum.y += z[0][1]; gsum.z += z[0][2]; gsum.w += z[0][3]; }
     else if (b == 1) { gsum.x += z[1][0]; gsum.y += z[1][1]; gsum.z += z[1][2]; gsum.w += z[1][3]; }
@@ -2262,6 +2334,38 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     prof.stamp(2);
     __syncthreads();
     prof.stamp(3);
+    if constexpr (EXACT) {
+      f32x4 bq[16];                                // this lane's 16 x 4 columns of sample nl
+      const float* trow = lds + (size_t)(s & 1) * kBufFloats + nl * DZF + 4 * g;
+#pragma unroll
+      for (int c4 = 0; c4 < 16; ++c4) bq[c4] = *reinterpret_cast<const f32x4*>(trow + 16 * c4);
+      const unsigned wtag = (unsigned)(s >> 2) & 1u;
+      const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+          xch + (size_t)(s & 3) * kSlotWords, 0, kSlotWords * 4, 0x00020000);
+      const unsigned soff = (unsigned)((((b * NTILE + w) * PA + a) * 256 + nl * 16 + 4 * g) * 4);
+      f32x4 acc[OT];
+      // (the OT tiles' accumulator chains interleaved: 32 cycles of pipe per MFMA, 40 of latency)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const float bw = bq[m >> 2][m & 3];
+#pragma unroll
+        for (int i = 0; i < OT; ++i) {
+          if (m == 0)
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc[i]) : "a"(uf[i][0]), "v"(bw));
+          else
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "a"(uf[i][m]), "v"(bw));
+        }
+      }
+      if constexpr (OT == 2) asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+      else asm volatile("s_nop 15" : "+v"(acc[0]));
+#pragma unroll
+      for (int i = 0; i < OT; ++i) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = tag_word(acc[i][e], wtag);
+        __builtin_amdgcn_raw_buffer_store_b128(o, wr, soff, i * (4 * PA * 1024), FAST ? 0 : kSc1);
+      }
+    } else
     {
       h8 bh[KS], bl[KS];
 #pragma unroll
@@ -2374,7 +2478,7 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   }
 }
 
-template <int OT>
+template <int OT, bool EXACT>
 __global__ void __launch_bounds__(kThreads)
 lstm_bwd_kernel_c(LstmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2382,8 +2486,8 @@ lstm_bwd_kernel_c(LstmParams p) {
   if (!map_block(p, unit_local, cw)) return;
   const int unit = p.chain_begin + unit_local;
   const bool fast = chain_on_one_xcd(p, unit, cw, reinterpret_cast<int*>(lds));
-  if (fast) bwd_body_c<OT, true>(p, unit, cw, lds);
-  else bwd_body_c<OT, false>(p, unit, cw, lds);
+  if (fast) bwd_body_c<OT, true, EXACT>(p, unit, cw, lds);
+  else bwd_body_c<OT, false, EXACT>(p, unit, cw, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -2492,6 +2596,14 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     pl.shm = (size_t)2 * 16 * (4 * pl.R + 4) * 4;
     pl.xchain_words = (size_t)2 * 16 * H;
     k = pick_fwd(pl.MAXR);
+    if (pl.prec == 0 && a->mode == 0 && (H == 256 || H == 512) &&
+        !(a->mi || a->zone_c || a->zone_h || a->uh) && env_int("ASR_LSTM_GENERIC", 0) == 0) {
+      // exact fp32 at the benchmarked widths: the structure of the split-fp16 kernel on
+      // v_mfma_f32_16x16x4_f32 (fwd_body_x<.., EXACT>)
+      pl.xchain_words = (size_t)2 * (H / 4) * (size_t)(fwd_xstride() / 4);
+      pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
+      k = H == 256 ? lstm_fwd_kernel_x<2, true> : lstm_fwd_kernel_x<4, true>;
+    }
     if (pl.prec == 1) {
       pl.xchain_words = (size_t)2 * (H / 4) * (size_t)(fwd_xstride() / 4);
       const int nkk = (H + 31) / 32;
@@ -2504,7 +2616,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
         // plain cell, persistent mode, H = 128 NKW: K split over the waves, U fragments in
         // AGPRs (fwd_body_x)
         pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
-        k = H == 256 ? lstm_fwd_kernel_x<2> : lstm_fwd_kernel_x<4>;
+        k = H == 256 ? lstm_fwd_kernel_x<2, false> : lstm_fwd_kernel_x<4, false>;
       } else {
         // any H, the cell variants, stepwise mode: h staged in LDS once per step (fwd_body_h)
         pl.shm = (size_t)4 * 16 * (32 * pl.NKK + 8) * 2;
@@ -2522,6 +2634,14 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     pl.shm = (size_t)(16 * 68 + pl.P * 256) * 4;
     pl.xchain_words = (size_t)2 * pl.P * pl.P * 256;
     k = pick_bwd(pl.TPW);
+    if (pl.prec == 0 && a->mode == 0 && (H == 256 || H == 512) &&
+        !(a->mi || a->zone_c || a->zone_h) && env_int("ASR_LSTM_GENERIC", 0) == 0) {
+      // exact fp32 at the benchmarked widths: the two-dimensional split on fp32 MFMAs
+      pl.form_c = 1;
+      pl.shm = (size_t)2 * 16 * 260 * 4;
+      pl.xchain_words = (size_t)4 * 4 * (H / 64) * (H / 64) * 256;
+      k = H == 256 ? lstm_bwd_kernel_c<1, true> : lstm_bwd_kernel_c<2, true>;
+    }
     if (pl.prec == 1) {
       pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 72 * 2);
       const bool variants = a->mi || a->zone_c || a->zone_h;
@@ -2535,7 +2655,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
         pl.form_c = 1;
         pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 264 * 2);
         pl.xchain_words = (size_t)4 * 4 * (H / 64) * (H / 64) * 256;
-        k = H == 256 ? lstm_bwd_kernel_c<1> : lstm_bwd_kernel_c<2>;
+        k = H == 256 ? lstm_bwd_kernel_c<1, false> : lstm_bwd_kernel_c<2, false>;
       } else if (wide) {
         k = H == 256 ? lstm_bwd_kernel_x<4> : lstm_bwd_kernel_x<8>;
       } else {

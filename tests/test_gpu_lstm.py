@@ -448,6 +448,55 @@ def test_bptt_two_dimensional_split_matches_the_one_dimensional_kernel(N, H, mon
                                float(np.abs(got - again).max()))
 
 
+@pytest.mark.parametrize('N,H', [(32, 256), (64, 512), (16, 512)])
+def test_exact_fp32_kernels_at_the_benchmarked_widths(N, H, monkeypatch):
+    """ASR_LSTM_PREC=0 at H = 256 / 512: the structure of the split-fp16 kernels (forward: K split
+    over the waves; BPTT: two-dimensional split) on v_mfma_f32_16x16x4_f32, against the any-H
+    exact kernels (ASR_LSTM_GENERIC=1) and against the split-fp16 default: activations to 2e-6 /
+    1e-5, gate gradients to 1e-6 / 2e-5 of the largest; sliced == whole bit for bit; db_part ==
+    the sums of the dz slab; with a recurrent-dropout mask."""
+    from asr_study_amd import ops
+    T = 41
+    rs = np.random.RandomState(7 * H + N)
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.1).astype(np.float32)).to(dev)
+    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
+
+    def run(ranges):
+        y = torch.full((T, n_pad, 2 * H), 3.0, device=dev)
+        cell = torch.full((T, n_pad, 2, H), 3.0, device=dev)
+        gates = torch.full((T, n_pad, 2, 4 * H), 3.0, device=dev)
+        dz = torch.full((T, n_pad, 2, 4 * H), 7.0, device=dev)
+        dbp = torch.full((n_pad // 16, 2, 4 * H), 9.0, device=dev)
+        for r in ranges:
+            ws = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask, steps=r)
+        ops.lstm_status(ws)
+        for r in ranges:
+            ws = ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=mask, steps=r,
+                                  db_part=dbp)
+        ops.lstm_status(ws)
+        want = dz.double().reshape(T, n_pad // 16, 16, 2, 4 * H).sum(dim=(0, 2))
+        assert (dbp.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+        return [t.cpu().numpy() for t in (y, cell, gates, dz)]
+    monkeypatch.setenv('ASR_LSTM_PREC', '1')
+    split = run([None])
+    monkeypatch.setenv('ASR_LSTM_PREC', '0')
+    monkeypatch.setenv('ASR_LSTM_GENERIC', '1')
+    generic = run([None])
+    monkeypatch.setenv('ASR_LSTM_GENERIC', '0')
+    got = run([None])
+    for name, a, b, c in zip(('y', 'cell', 'gates', 'dz'), got, generic, split):
+        scale = max(1.0, np.abs(b).max()) if name != 'dz' else np.abs(b).max()
+        assert report('exact %s vs generic exact N%d H%d' % (name, N, H), a, b) < 2e-6 * scale
+        assert report('exact %s vs split-fp16' % name, a, c) < (2e-5 if name == 'dz' else 1e-5) * scale
+    sliced = run([(0, 1), (1, 13), (14, 27)])
+    for name, a, b in zip(('y', 'cell', 'gates', 'dz'), got, sliced):
+        assert np.array_equal(a, b), name
+
+
 @pytest.mark.parametrize('H', [256, 512])
 def test_single_utterance_forward_kernel(H):
     """asr_lstm_args.n_valid = 1 (predict.py: one utterance per call): the tile-free exact-fp32
