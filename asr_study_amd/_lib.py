@@ -42,14 +42,14 @@ class PackArgs(C.Structure):
     _fields_ = [('src', void_p), ('rows', C.c_int), ('cols', C.c_int), ('ld', C.c_int),
                 ('mask', void_p), ('mask_period', C.c_int), ('mask_ld', C.c_int),
                 ('absmax', void_p), ('scale_out', void_p),
-                ('r_hi', void_p), ('r_lo', void_p), ('ldk_r', C.c_int),
-                ('c_hi', void_p), ('c_lo', void_p), ('ldk_c', C.c_int)]
+                ('r_hl', void_p), ('ldk_r', C.c_int),
+                ('c_hl', void_p), ('ldk_c', C.c_int)]
 
 
 class GemmHlArgs(C.Structure):
     _fields_ = [('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
-                ('a_hi', void_p), ('a_lo', void_p), ('lda', C.c_int),
-                ('b_hi', void_p), ('b_lo', void_p), ('ldb', C.c_int),
+                ('a_hl', void_p), ('lda', C.c_int),
+                ('b_hl', void_p), ('ldb', C.c_int),
                 ('a_scale', void_p), ('b_scale', void_p),
                 ('C', void_p), ('ldc', C.c_int),
                 ('alpha', C.c_float), ('beta', C.c_float),
@@ -113,6 +113,7 @@ SIGNATURES = {
     'asr_pack_hl': (C.c_int, [C.POINTER(PackArgs), void_p]),
     'asr_gemm_hl_workspace_bytes': (C.c_size_t, [C.POINTER(GemmHlArgs)]),
     'asr_gemm_hl': (C.c_int, [C.POINTER(GemmHlArgs), void_p, C.c_size_t, void_p]),
+    'asr_gemm_hl_profile': (C.c_int, [C.c_int, C.POINTER(C.c_longlong), void_p]),
     'asr_absmax': (C.c_int, [void_p, C.c_int64, void_p, void_p]),
     'asr_dropout_masks': (C.c_int, [void_p, C.c_int64, C.c_float, C.c_float, C.c_uint64,
                                     C.c_uint32, C.c_uint32, void_p]),

@@ -785,16 +785,26 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
 //   "r" planes (rows, ldk_r): K = the source's columns  (A of x@W, A of dz@W^T)
 //   "c" planes (cols, ldk_c): K = the source's rows     (both operands of the weight
 //                                                         gradients x^T dz and h^T dz)
-// rows of a plane are ldk halfs long (ldk % 32 == 0, zero padded).  gemm_hlx_kernel is then a
+// A plane row holds ldk reduction indices (ldk % 32 == 0, zero padded).  The two planes are ONE
+// array, interleaved in groups of 16 indices: a row is 2 ldk halfs,
+//   half [32 g, 32 g + 16)      = hi[16 g .. 16 g + 15]
+//   half [32 g + 16, 32 g + 32) = lo[16 g .. 16 g + 15]
+// so the 32-deep K slab of a row -- both planes -- is ONE 128-byte line.  (With separate
+// planes a slab touched half of a line in each, the other halves belonging to the next slab,
+// by which time the 32 KB L1 had long turned over: every line crossed L2 -> L1 twice.)  A
+// reduction offset is a multiple of 16 (a group).  gemm_hlx_kernel is then a
 // plain fp16 GEMM with three MFMAs per fragment pair and fp32 accumulation: 16-byte global
 // loads -> ds_write_b128 -> ds_read_b128 -> v_mfma_f32_32x32x16_f16, no VALU in the K loop
 // besides addresses.  Tile / LDS image / epilogue are those of the fast kernel.
 struct HlSrc {
-  const _Float16* hi; const _Float16* lo;
-  int ld;                 // halfs per plane row
+  const _Float16* p;      // interleaved planes, offset to (first row, first reduction group)
+  int ld;                 // reduction indices per row: a row is 2 ld halfs
   int rows;               // MN extent
-  unsigned extent;        // bytes addressable from hi / lo
+  unsigned extent;        // bytes addressable from p
 };
+__device__ __forceinline__ size_t hl_index(int row, int k, int ld) {      // half index of hi
+  return (size_t)row * (2 * (size_t)ld) + (size_t)(k >> 4) * 32 + (k & 15);
+}
 
 // 64 x 64 source tile per workgroup; thread (ty = tid >> 4, tx = tid & 15) owns the 4 x 4
 // block rows 4 ty.., columns 4 tx..
@@ -802,8 +812,7 @@ __global__ void __launch_bounds__(256)
 pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
                const float* __restrict__ mask, int mask_period, int mask_ld,
                const float* __restrict__ absmax, float* __restrict__ scale_out,
-               _Float16* __restrict__ r_hi, _Float16* __restrict__ r_lo, int ldk_r,
-               _Float16* __restrict__ c_hi, _Float16* __restrict__ c_lo, int ldk_c) {
+               _Float16* __restrict__ r_hl, int ldk_r, _Float16* __restrict__ c_hl, int ldk_c) {
   __shared__ __attribute__((aligned(16))) _Float16 th[64][72], tl[64][72];   // [col][row]
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
@@ -839,12 +848,13 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
       hi[i][e] = h;
       lo[i][e] = (_Float16)(x - (float)h);
     }
-    if (r_hi && r < rows && c < ldk_r) {      // (columns in [cols, ldk_r) receive zeros)
-      *reinterpret_cast<hx4*>(r_hi + (size_t)r * ldk_r + c) = hi[i];
-      *reinterpret_cast<hx4*>(r_lo + (size_t)r * ldk_r + c) = lo[i];
+    if (r_hl && r < rows && c < ldk_r) {      // (columns in [cols, ldk_r) receive zeros)
+      _Float16* q = r_hl + hl_index(r, c, ldk_r);
+      *reinterpret_cast<hx4*>(q) = hi[i];
+      *reinterpret_cast<hx4*>(q + 16) = lo[i];
     }
   }
-  if (!c_hi) return;
+  if (!c_hl) return;
   // transposed planes through LDS: [col][row], then 16-byte runs along the rows
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -861,10 +871,9 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
     const int cc = idx >> 3, rq = (idx & 7) * 8;
     const int col = c0 + cc, row = r0 + rq;
     if (col < cols && row < ldk_c) {            // (rows in [rows, ldk_c) receive zeros)
-      *reinterpret_cast<hx8*>(c_hi + (size_t)col * ldk_c + row) =
-          *reinterpret_cast<const hx8*>(&th[cc][rq]);
-      *reinterpret_cast<hx8*>(c_lo + (size_t)col * ldk_c + row) =
-          *reinterpret_cast<const hx8*>(&tl[cc][rq]);
+      _Float16* q = c_hl + hl_index(col, row, ldk_c);
+      *reinterpret_cast<hx8*>(q) = *reinterpret_cast<const hx8*>(&th[cc][rq]);
+      *reinterpret_cast<hx8*>(q + 16) = *reinterpret_cast<const hx8*>(&tl[cc][rq]);
     }
   }
 }
@@ -888,41 +897,44 @@ __device__ __forceinline__ int hl256_slot(int row, int kc) {      // half index 
 
 template <int NT>
 struct HlLoaderX {
-  __amdgpu_buffer_rsrc_t rh, rl;
-  unsigned off[2];
-  int kq[2];
+  // One operand's share of a K slab: (NT / 2) rows x 128 bytes (the row's line: hi and lo of 32
+  // reduction indices) = 4 NT 16-byte chunks; thread t takes chunks t + NT i, i < 4
+  // (row = chunk >> 3): a wave instruction reads 8 whole lines.  Chunk c of a line is
+  // reduction chunk 2 (c >> 2) + (c & 1) of plane (c >> 1) & 1.
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned off[4];
   int k_begin, k_end;
+  __device__ __forceinline__ static int kq(int i) {           // first reduction index of chunk i
+    const int c = (threadIdx.x + NT * i) & 7;
+    return 16 * (c >> 2) + 8 * (c & 1);
+  }
   __device__ __forceinline__ void init(const HlSrc& s, int row0, int kb, int ke) {
     const int tid = threadIdx.x;
-    rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.hi), 0, s.extent, 0x00020000);
-    rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.lo), 0, s.extent, 0x00020000);
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.p), 0, s.extent, 0x00020000);
     k_begin = kb; k_end = ke;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ch = tid + NT * i;                 // (2 NT / 4) rows x 4 chunks
-      const int row = row0 + (ch >> 2);
-      kq[i] = 8 * (ch & 3);
-      off[i] = row < s.rows ? (unsigned)(((size_t)row * s.ld + kb + kq[i]) * 2) : kOob;
+    for (int i = 0; i < 4; ++i) {
+      const int ch = tid + NT * i;
+      const int row = row0 + (ch >> 3);
+      off[i] = row < s.rows ? (unsigned)((hl_index(row, kb, s.ld) + 8 * (ch & 7)) * 2) : kOob;
     }
   }
-  __device__ __forceinline__ void load(int kt, u32x4g (&h)[2], u32x4g (&l)[2]) const {
+  __device__ __forceinline__ void load(int kt, u32x4g (&v)[4]) const {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool ok = k_begin + kt * HBK + kq[i] < k_end && off[i] != kOob;
-      const unsigned o = ok ? off[i] + (unsigned)(kt * HBK * 2) : kOob;
-      h[i] = __builtin_amdgcn_raw_buffer_load_b128(rh, o, 0, 0);
-      l[i] = __builtin_amdgcn_raw_buffer_load_b128(rl, o, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = k_begin + kt * HBK + kq(i) < k_end && off[i] != kOob;
+      const unsigned o = ok ? off[i] + (unsigned)(kt * HBK * 4) : kOob;
+      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
     }
   }
-  __device__ __forceinline__ static void store(const u32x4g (&h)[2], const u32x4g (&l)[2],
-                                               _Float16* Shi, _Float16* Slo) {
+  __device__ __forceinline__ static void store(const u32x4g (&v)[4], _Float16* Shi, _Float16* Slo) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int ch = tid + NT * i;
-      const int slot = hl256_slot(ch >> 2, ch & 3);
-      *reinterpret_cast<u32x4g*>(Shi + slot) = h[i];
-      *reinterpret_cast<u32x4g*>(Slo + slot) = l[i];
+      const int c = ch & 7;
+      const int slot = hl256_slot(ch >> 3, 2 * (c >> 2) + (c & 1));
+      *reinterpret_cast<u32x4g*>(((c >> 1) & 1 ? Slo : Shi) + slot) = v[i];
     }
   }
 };
@@ -932,6 +944,22 @@ struct HlLoaderX {
 //   <4, 4, 2>: 256 x 256, 512 threads, 128 KB LDS -- the main kernel;
 //   <2, 2, 2>: 128 x 128, 256 threads,  64 KB LDS -- small outputs, and the one that fits on a
 //              CU BESIDE a recurrent workgroup (96 KB + 64 KB of LDS, 2 + 1 waves per SIMD).
+// Debug (asr_gemm_hl_profile): shader clocks per phase of the K loop, summed over the slabs of
+// workgroup 0 of a launch, per wave: 0 fragment reads, 1 barrier before the MFMAs, 2 MFMAs of
+// the first 16-deep half (with the staging traffic), 3 MFMAs of the second half, 4 barrier
+// behind the MFMAs, 5 the prologue; 6 = the K loop in ticks of the 100 MHz real-time counter (s_memrealtime).
+#ifndef HL_EXP
+#define HL_EXP 0            // timing experiments only (tools/build_variant.sh): 1 no LDS staging
+#endif                      // writes, 2 no global loads in the K loop, 4 no epilogue stores
+#ifndef HL_STAGE
+#define HL_STAGE 0
+#endif
+#ifndef HL_LOAD_GAP
+#define HL_LOAD_GAP 2
+#endif
+__device__ int g_hl_prof_on = 0;
+__device__ long long g_hl_prof[8][8];
+
 template <int WN, int MI, int NJ>
 __global__ void __launch_bounds__(128 * WN)
 gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int splits,
@@ -941,7 +969,9 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
   static_assert(TM2 == TN2 && TM2 * 4 == 2 * NT, "square tile, two chunks per thread and plane");
   using HlLoader256 = HlLoaderX<NT>;
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
-  constexpr int kPlane = TM2 * 32;                   // halfs per plane
+  // halfs per plane: + 64 bytes, so that a row's hi and lo chunks (one 8-lane group of the
+  // staging ds_write_b128) fall into different banks
+  constexpr int kPlane = TM2 * 32 + 32;
   auto plane = [&](int buf, int which) { return hsm + (size_t)(buf * 4 + which) * kPlane; };
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -962,6 +992,16 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
 #pragma unroll
       for (int e = 0; e < 16; ++e) am[i][j][e] = 0.f;
 
+  const bool prof = g_hl_prof_on != 0 && blockIdx.x == 0;
+  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long plast = prof ? (long long)__builtin_readcyclecounter() : 0;
+  auto stamp = [&](int i) {
+    if (prof) {
+      const long long now = (long long)__builtin_readcyclecounter();
+      pt[i] += now - plast;
+      plast = now;
+    }
+  };
   HlLoader256 la, lb;
   la.init(A, m0, k_begin, k_end);
   lb.init(B, n0, k_begin, k_end);
@@ -971,14 +1011,14 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
   // they fly across this step's 48 MFMAs per wave AND its barrier (plain buffer loads, no
   // vmcnt wait at the barrier).  The scheduling fence keeps the compiler from sinking the
   // loads to their use, which would expose the whole L2/HBM latency every step.
-  u32x4g ah[2], al[2], bh[2], bl[2];
+  u32x4g av[4], bv[4];
   const int nk = (k_end - k_begin + HBK - 1) / HBK;
-  la.load(0, ah, al);
-  lb.load(0, bh, bl);
-  HlLoader256::store(ah, al, plane(0, 0), plane(0, 1));
-  HlLoader256::store(bh, bl, plane(0, 2), plane(0, 3));
-  la.load(1, ah, al);
-  lb.load(1, bh, bl);
+  la.load(0, av);
+  lb.load(0, bv);
+  HlLoader256::store(av, plane(0, 0), plane(0, 1));
+  HlLoader256::store(bv, plane(0, 2), plane(0, 3));
+  la.load(1, av);
+  lb.load(1, bv);
   __syncthreads();
   const int lrow = lane & 31, lhalf = lane >> 5;
   // Ping-pong: a step is four phases -- read the fragments of one 16-deep half, 24 MFMAs on
@@ -990,6 +1030,8 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
   // buffer is last read three phases (>= one barrier) before either row rewrites it, and is
   // first read three phases after the later row wrote it.
   if (wm == 1) __builtin_amdgcn_s_barrier();
+  stamp(5);
+  const long long real0 = prof ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
     const _Float16* Ah = plane(cur, 0);
@@ -1011,20 +1053,44 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
         fah[i] = *reinterpret_cast<const hx8*>(Ah + slot);
         fal[i] = *reinterpret_cast<const hx8*>(Al + slot);
       }
+#if HL_STAGE == 1
+      if (ks == 0) {
+        HlLoader256::store(av, plane(nxt, 0), plane(nxt, 1));
+        HlLoader256::store(bv, plane(nxt, 2), plane(nxt, 3));
+        la.load(kt + 2, av);
+        lb.load(kt + 2, bv);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
+      stamp(0);
       __syncthreads();
+      stamp(1);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      if (ks == 0) {
+      if (ks == 0 && HL_STAGE == 0) {
         // the staging traffic rides in the issue gaps of this phase's MFMAs (32 cycles of pipe
         // per MFMA, ~4 of issue): the 8 LDS writes of slab kt+1 first -- each frees its
         // registers -- then the 8 loads of slab kt+2 into them; the read phases stay bare
-        HlLoader256::store(ah, al, plane(nxt, 0), plane(nxt, 1));
-        HlLoader256::store(bh, bl, plane(nxt, 2), plane(nxt, 3));
+#if !(HL_EXP & 1)
+        HlLoader256::store(av, plane(nxt, 0), plane(nxt, 1));
+        HlLoader256::store(bv, plane(nxt, 2), plane(nxt, 3));
+#endif
         // past the last slab every offset is out of range: those loads return zeros, unused
-        la.load(kt + 2, ah, al);
-        lb.load(kt + 2, bh, bl);
+#if !(HL_EXP & 2)
+        la.load(kt + 2, av);
+        lb.load(kt + 2, bv);
+#endif
+
       }
+#if HL_STAGE == 2
+      if (ks == 0) {
+        HlLoader256::store(av, plane(nxt, 0), plane(nxt, 1));
+        la.load(kt + 2, av);
+      } else {
+        HlLoader256::store(bv, plane(nxt, 2), plane(nxt, 3));
+        lb.load(kt + 2, bv);
+      }
+#endif
       // term-major order: consecutive MFMAs go to eight different accumulators
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -1041,7 +1107,7 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], am[i][j], 0, 0, 0);
-      if (ks == 0) {
+      if (ks == 0 && HL_STAGE == 0) {
         constexpr int NM = 3 * MI * NJ;                    // MFMAs of the phase: 24 or 12
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -1054,13 +1120,35 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
           __builtin_amdgcn_sched_group_barrier(0x020, NM >= 24 ? 1 : 2, 0);   // VMEM read
         }
       }
+#if HL_STAGE == 2
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, HL_LOAD_GAP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+#endif
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(ks == 0 ? 2 : 3);
       __syncthreads();
+      stamp(4);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
+  if (prof && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g_hl_prof[wave][i] = pt[i];
+    g_hl_prof[wave][6] = (long long)__builtin_amdgcn_s_memrealtime() - real0;
+  }
+#if HL_EXP & 4
+  if (K != -12345) return;
+#endif
   const float unscale = 1.f / (sa * sb);
   const int lcol = lane & 31;
   const bool interior = m0 + TM2 <= M && n0 + TN2 <= N;
@@ -1410,25 +1498,32 @@ extern "C" int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream_) {
   ASR_CHECK_ARG(a && a->src && a->rows > 0 && a->cols > 0 && a->ld >= a->cols,
                 "pack_hl: bad source");
   ASR_CHECK_ARG(aligned16(a->src) && a->ld % 4 == 0, "pack_hl: source rows must be 16-byte aligned");
-  ASR_CHECK_ARG((a->r_hi != nullptr) == (a->r_lo != nullptr) &&
-                (a->c_hi != nullptr) == (a->c_lo != nullptr) && (a->r_hi || a->c_hi),
-                "pack_hl: need the hi and lo plane of at least one orientation");
-  if (a->r_hi)
+  ASR_CHECK_ARG(a->r_hl || a->c_hl, "pack_hl: need the planes of at least one orientation");
+  if (a->r_hl)
     ASR_CHECK_ARG(a->ldk_r % 32 == 0 && a->ldk_r >= a->cols && a->ldk_r < a->cols + 32 &&
-                  aligned16(a->r_hi) && aligned16(a->r_lo), "pack_hl: bad row-plane geometry");
-  if (a->c_hi)
+                  aligned16(a->r_hl), "pack_hl: bad row-plane geometry");
+  if (a->c_hl)
     ASR_CHECK_ARG(a->ldk_c % 32 == 0 && a->ldk_c >= a->rows && a->ldk_c < a->rows + 32 &&
-                  aligned16(a->c_hi) && aligned16(a->c_lo), "pack_hl: bad column-plane geometry");
+                  aligned16(a->c_hl), "pack_hl: bad column-plane geometry");
   if (a->mask)
     ASR_CHECK_ARG(a->mask_period > 0 && a->mask_ld >= a->cols,
                   "pack_hl: a mask needs a positive row period and mask_ld >= cols");
   dim3 grid((a->cols + 63) / 64, (a->rows + 63) / 64);
   hipLaunchKernelGGL(pack_hl_kernel, grid, dim3(256), 0, stream, a->src, a->rows, a->cols, a->ld,
                      a->mask, a->mask ? a->mask_period : 1, a->mask_ld, a->absmax, a->scale_out,
-                     reinterpret_cast<_Float16*>(a->r_hi), reinterpret_cast<_Float16*>(a->r_lo),
-                     a->ldk_r, reinterpret_cast<_Float16*>(a->c_hi),
-                     reinterpret_cast<_Float16*>(a->c_lo), a->ldk_c);
+                     reinterpret_cast<_Float16*>(a->r_hl), a->ldk_r,
+                     reinterpret_cast<_Float16*>(a->c_hl), a->ldk_c);
   ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}
+
+// Debug: enable != 0 arms the phase profile of the next asr_gemm_hl launches;
+// out64 (may be NULL) receives the 8 waves x 8 phases of the last armed launch's workgroup 0.
+extern "C" int asr_gemm_hl_profile(int enable, long long* out48, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_HIP(hipStreamSynchronize(stream));
+  if (out48) ASR_CHECK_HIP(hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_hl_prof), sizeof(long long) * 64));
+  ASR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_hl_prof_on), &enable, sizeof(int)));
   return ASR_OK;
 }
 
@@ -1451,15 +1546,17 @@ extern "C" size_t asr_gemm_hl_workspace_bytes(const asr_gemm_hl_args* a) {
 extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws_bytes,
                            asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  ASR_CHECK_ARG(a && a->a_hi && a->a_lo && a->b_hi && a->b_lo && a->C, "gemm_hl: null pointer");
+  ASR_CHECK_ARG(a && a->a_hl && a->b_hl && a->C, "gemm_hl: null pointer");
   ASR_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 8 == 0,
                 "gemm_hl: bad shape %d %d %d (K must be a multiple of 8)", a->M, a->N, a->K);
   ASR_CHECK_ARG(a->lda >= a->K && a->ldb >= a->K && a->lda % 8 == 0 && a->ldb % 8 == 0 &&
                 a->ldc >= a->N, "gemm_hl: bad leading dimensions");
-  ASR_CHECK_ARG(aligned16(a->a_hi) && aligned16(a->a_lo) && aligned16(a->b_hi) &&
-                aligned16(a->b_lo), "gemm_hl: planes must be 16-byte aligned");
-  const size_t ext_a = ((size_t)(a->M - 1) * a->lda + a->K) * 2;
-  const size_t ext_b = ((size_t)(a->N - 1) * a->ldb + a->K) * 2;
+  ASR_CHECK_ARG((reinterpret_cast<uintptr_t>(a->a_hl) & 63) == 0 &&
+                (reinterpret_cast<uintptr_t>(a->b_hl) & 63) == 0,
+                "gemm_hl: planes must start at a reduction group (64-byte aligned)");
+  // bytes from the first row's first group to the end of the last row's last group
+  const size_t ext_a = ((size_t)(a->M - 1) * 2 * a->lda + (size_t)((a->K + 15) / 16) * 32) * 2;
+  const size_t ext_b = ((size_t)(a->N - 1) * 2 * a->ldb + (size_t)((a->K + 15) / 16) * 32) * 2;
   const size_t lim = ((size_t)1 << 32) - ((size_t)1 << 20);
   ASR_CHECK_ARG(ext_a < lim && ext_b < lim, "gemm_hl: operand larger than 4 GiB");
   int kps = 0;
@@ -1477,15 +1574,15 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
     ep.partial = reinterpret_cast<float*>(workspace);
   }
   HlSrc A, B;
-  A.hi = reinterpret_cast<const _Float16*>(a->a_hi); A.lo = reinterpret_cast<const _Float16*>(a->a_lo);
+  A.p = reinterpret_cast<const _Float16*>(a->a_hl);
   A.ld = a->lda; A.rows = a->M; A.extent = (unsigned)ext_a;
-  B.hi = reinterpret_cast<const _Float16*>(a->b_hi); B.lo = reinterpret_cast<const _Float16*>(a->b_lo);
+  B.p = reinterpret_cast<const _Float16*>(a->b_hl);
   B.ld = a->ldb; B.rows = a->N; B.extent = (unsigned)ext_b;
   // tile: 256 x 256 (512 threads, 128 KB LDS) for outputs of at least that size, else 128 x 128
   // (256 threads, 64 KB; asr_gemm_hl_args.tile = 128 or ASR_GEMM_HL_TILE=128 force it)
   static const int tile_env = [] { const char* v = getenv("ASR_GEMM_HL_TILE"); return v ? atoi(v) : 256; }();
   if (tile_env >= 256 && a->tile != 128 && a->M >= 256 && a->N >= 256) {
-    const size_t shm2 = (size_t)2 * 4 * 256 * 32 * sizeof(_Float16);
+    const size_t shm2 = (size_t)2 * 4 * (256 * 32 + 32) * sizeof(_Float16);
     static bool attr2_done = false;
     if (!attr2_done) {
       ASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hlx_kernel<4, 4, 2>,
@@ -1496,7 +1593,7 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
     hipLaunchKernelGGL((gemm_hlx_kernel<4, 4, 2>), dim3(total), dim3(512), shm2, stream, A, B,
                        a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
   } else {
-    const size_t shm1 = (size_t)2 * 4 * 128 * 32 * sizeof(_Float16);
+    const size_t shm1 = (size_t)2 * 4 * (128 * 32 + 32) * sizeof(_Float16);
     const int total = ((a->M + 127) / 128) * ((a->N + 127) / 128) * splits;
     hipLaunchKernelGGL((gemm_hlx_kernel<2, 2, 2>), dim3(total), dim3(256), shm1, stream, A, B,
                        a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);

@@ -55,11 +55,19 @@ def pad16(n):
 
 
 # --------------------------------------------------------------------------- GEMM
-def _resolve_split(split_k, M, N, K):
+_SPLIT_WGS = None
+
+
+def _resolve_split(split_k, M, N, K, tile=128):
     if split_k == 'auto':
-        # long-K / small-output GEMMs (dW, dU): split K until ~1024 workgroups exist
-        tiles = ((int(M) + 127) // 128) * ((int(N) + 127) // 128)
-        split_k = max(1, min(64, (1024 + tiles - 1) // tiles, int(K) // 256))
+        # long-K / small-output GEMMs (dW, dU): split K until ~ASR_GEMM_SPLIT_WGS workgroups
+        # exist (tiles of `tile` x `tile`)
+        global _SPLIT_WGS
+        if _SPLIT_WGS is None:
+            import os
+            _SPLIT_WGS = int(os.environ.get('ASR_GEMM_SPLIT_WGS', '1024'))
+        tiles = ((int(M) + tile - 1) // tile) * ((int(N) + tile - 1) // tile)
+        split_k = max(1, min(64, (_SPLIT_WGS + tiles - 1) // tiles, int(K) // 256))
     return int(split_k)
 
 
@@ -535,16 +543,31 @@ def lstm_ln_seq_bwd(dy, wx, U, cellp, uh, y, cell, gates, duh, dwx, dparams, T, 
 
 # --------------------------------------------------------------------------- packed operands
 class HlPlanes(object):
-    """Two fp16 planes (hi, lo) of a matrix whose rows are ``ld`` halfs long, reduction index
-    contiguous, plus the device float holding the power-of-two scale they were packed with
-    (include/asr_hip.h, asr_pack_hl)."""
+    """The two fp16 planes (hi, lo) of a matrix with ``ld`` reduction indices per row,
+    interleaved in groups of 16 -- ``hl[row, g, 0]`` = hi[16g:16g+16], ``hl[row, g, 1]`` = lo --
+    so that a 32-deep slab of a row is one 128-byte line; plus the device float holding the
+    power-of-two scale they were packed with (include/asr_hip.h, asr_pack_hl)."""
 
     def __init__(self, rows, k, device):
         self.rows, self.k = int(rows), int(k)
         self.ld = (self.k + 31) // 32 * 32
-        self.hi = torch.empty((self.rows, self.ld), dtype=torch.float16, device=device)
-        self.lo = torch.empty((self.rows, self.ld), dtype=torch.float16, device=device)
+        self.hl = torch.empty((self.rows, self.ld // 16, 2, 16), dtype=torch.float16,
+                              device=device)
         self.scale = torch.ones(1, dtype=torch.float32, device=device)
+
+    @property
+    def hi(self):
+        """(rows, ld) view-copy of the hi plane (tests / debugging)."""
+        return self.hl[:, :, 0, :].reshape(self.rows, self.ld)
+
+    @property
+    def lo(self):
+        return self.hl[:, :, 1, :].reshape(self.rows, self.ld)
+
+    def ptr(self, row=0, k=0):
+        """Address of (row, reduction index k); k a multiple of 16."""
+        assert k % 16 == 0
+        return self.hl.data_ptr() + 2 * (int(row) * 2 * self.ld + (int(k) // 16) * 32)
 
 
 def pack_hl(src, rows, cols, ld=None, src_off=0, mask=None, mask_period=0, absmax=None,
@@ -563,10 +586,10 @@ def pack_hl(src, rows, cols, ld=None, src_off=0, mask=None, mask_period=0, absma
     a.scale_out = first.scale.data_ptr()
     if r is not None:
         assert r.rows >= rows and r.k == cols
-        a.r_hi, a.r_lo, a.ldk_r = r.hi.data_ptr(), r.lo.data_ptr(), r.ld
+        a.r_hl, a.ldk_r = r.hl.data_ptr(), r.ld
     if c is not None:
         assert c.rows >= cols and c.k == rows
-        a.c_hi, a.c_lo, a.ldk_c = c.hi.data_ptr(), c.lo.data_ptr(), c.ld
+        a.c_hl, a.ldk_c = c.hl.data_ptr(), c.ld
     L.check(lib.asr_pack_hl(C.byref(a), _stream()), 'asr_pack_hl')
     if r is not None and c is not None:
         c.scale = r.scale               # one scale for both orientations
@@ -582,10 +605,8 @@ def gemm_hl(A, B, Cm, M, N, K, a_row=0, a_k=0, b_row=0, b_k=0, c_off=0, ldc=None
     lib = L.load()
     g = L.GemmHlArgs()
     g.M, g.N, g.K = int(M), int(N), int(K)
-    ao = 2 * (int(a_row) * A.ld + int(a_k))
-    bo = 2 * (int(b_row) * B.ld + int(b_k))
-    g.a_hi, g.a_lo, g.lda = A.hi.data_ptr() + ao, A.lo.data_ptr() + ao, A.ld
-    g.b_hi, g.b_lo, g.ldb = B.hi.data_ptr() + bo, B.lo.data_ptr() + bo, B.ld
+    g.a_hl, g.lda = A.ptr(a_row, a_k), A.ld
+    g.b_hl, g.ldb = B.ptr(b_row, b_k), B.ld
     g.a_scale, g.b_scale = A.scale.data_ptr(), B.scale.data_ptr()
     g.C = Cm.data_ptr() + 4 * int(c_off)
     g.ldc = int(ldc if ldc is not None else N)

@@ -160,14 +160,19 @@ typedef struct asr_pack_args {
   const float* mask; int mask_period, mask_ld;   /* or NULL; row period (any n_pad)   */
   const float* absmax;                           /* device float, or NULL (scale 1)   */
   float* scale_out;                              /* device float, or NULL             */
-  void* r_hi; void* r_lo; int ldk_r;             /* (rows, ldk_r) halfs each, or NULL */
-  void* c_hi; void* c_lo; int ldk_c;             /* (cols, ldk_c) halfs each, or NULL */
+  void* r_hl; int ldk_r;                         /* (rows, 2 ldk_r) halfs, or NULL    */
+  void* c_hl; int ldk_c;                         /* (cols, 2 ldk_c) halfs, or NULL    */
 } asr_pack_args;
 int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream);
+/* Debug: arm (enable != 0) / read the K-loop phase profile of asr_gemm_hl's workgroup 0:      */
+/* out64 = 8 waves x 8 phases of shader clocks (fragment reads, barrier, MFMAs first half,    */
+/* MFMAs second half, barrier, prologue, the K loop in 100 MHz real-time ticks, unused);      */
+/* NULL to only arm / disarm.                                                                 */
+int asr_gemm_hl_profile(int enable, long long* out64, asr_stream_t stream);
 typedef struct asr_gemm_hl_args {
   int M, N, K;
-  const void* a_hi; const void* a_lo; int lda;   /* halfs per row                     */
-  const void* b_hi; const void* b_lo; int ldb;
+  const void* a_hl; int lda;                     /* interleaved planes; reduction     */
+  const void* b_hl; int ldb;                     /* indices per row (a row = 2 ld halfs) */
   const float* a_scale; const float* b_scale;    /* device floats (asr_pack_hl) or NULL */
   float* C; int ldc;
   float alpha, beta;

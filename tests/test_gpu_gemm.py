@@ -182,7 +182,7 @@ def test_pack_hl_planes_both_orientations(rows, cols, ld, period):
     amax = ops.absmax(sd)
     r = ops.HlPlanes(rows, cols, 'cuda:0')
     c = ops.HlPlanes(cols, rows, 'cuda:0')
-    for t in (r.hi, r.lo, c.hi, c.lo):
+    for t in (r.hl, c.hl):
         t.fill_(7.0)
     ops.pack_hl(sd, rows, cols, ld=ld, mask=to_dev(mask) if period else None, mask_period=period,
                 absmax=amax, r=r, c=c)
