@@ -21,6 +21,7 @@
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BM = 128, BN = 128, PAD = 4;
 constexpr int LDS_LD = BM + PAD;   // BM == BN
@@ -878,85 +879,92 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
   }
 }
 
-// One operand's share of a K slab: 128 rows x 32 halfs per plane = 512 16-byte chunks;
-// thread t takes chunks t and t + 256 (row = chunk >> 2, k chunk = chunk & 3) of both planes.
 // ---------------------------------------------------------------------------
 // The packed-plane kernel.  256 x 256 x 32 tile by default (outputs of at least 256 x 256).
 // With 128 x 128 tiles both split-fp16 GEMMs sit at ~250 TF/s algorithmic whatever the K loop
 // costs: a workgroup moves 32 KB from L2 per 1 MFLOP (32 flop/B), i.e. ~7.5 TB/s at that
 // rate, with an L2 hit rate of ~72 % -- the loop is fed at the L2 / fabric rate.  A 256 x 256
-// tile halves the bytes per flop.  512 threads = 8 waves (2 x 4, 128 x 64 each = 4 x 2 MFMA
-// tiles, 128 accumulator registers); LDS image per plane [256 rows][32 halfs] UNPADDED
-// (64-byte rows; 4 planes x 2 buffers = 128 KB) with the 16-byte chunk index XOR-swizzled by
-// (row >> 2) & 3, which makes both the ds_write_b128 of the staging pass and the ds_read_b128
-// of the fragments bank-conflict free (lane groups of MI355X_MICROARCH.md "LDS").
+// tile halves the bytes per flop.  512 threads = 8 waves (2 x 4, 128 x 64 each = 8 x 4 MFMA
+// tiles of 16 x 16, 128 accumulator registers); LDS image per plane [256 rows][32 halfs]
+// (64-byte rows; 4 planes x 2 buffers = 128 KB) with the 16-byte chunk index XOR-swizzled by a
+// permutation of (row >> 2) & 3, which makes both the ds_write_b128 of the staging pass and the
+// ds_read_b128 of the 16 x 32 fragments bank-conflict free (lane groups of
+// MI355X_MICROARCH.md "LDS"; checked exhaustively when the layout was chosen).
+//
+// The kernel runs at the 1400 W package power cap (tools/clock_probe.py): what it sustains is
+// set by energy per flop, not by issue slots.  v_mfma_f32_16x16x32_f16 sustains 2.0 PFLOP/s on
+// random operands at the cap (shader clock 2.04 GHz) where v_mfma_f32_32x32x16_f16 sustains
+// 1.66 (1.80 GHz) -- tools/micro/mfma_power.hip -- so the tile is built from the 16 x 16 shape.
 
 __device__ __forceinline__ int hl256_slot(int row, int kc) {      // half index in a plane
-  return row * 32 + ((kc ^ ((row >> 2) & 3)) << 3);
+  return row * 32 + ((kc ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 3);    // 0, 2, 3, 1
 }
 
 template <int NT>
 struct HlLoaderX {
   // One operand's share of a K slab: (NT / 2) rows x 128 bytes (the row's line: hi and lo of 32
-  // reduction indices) = 4 NT 16-byte chunks; thread t takes chunks t + NT i, i < 4
-  // (row = chunk >> 3): a wave instruction reads 8 whole lines.  Chunk c of a line is
-  // reduction chunk 2 (c >> 2) + (c & 1) of plane (c >> 1) & 1.
+  // reduction indices) = 4 NT 16-byte chunks; thread t takes chunks t + NT i, i < 4: row
+  // (t >> 3) + (NT / 8) i, chunk t & 7 of the line -- a wave instruction reads 8 whole lines.
+  // Chunk c of a line is reduction chunk 2 (c >> 2) + (c & 1) of plane (c >> 1) & 1.  One
+  // offset register: the four rows are a uniform stride apart (scalar offset operand, which
+  // the descriptor's range check does not see: rows past the operand and the reduction tail
+  // are compares that send the lane's offset out of range -> zeros).
   __amdgpu_buffer_rsrc_t rs;
-  unsigned off[4];
-  int k_begin, k_end;
-  __device__ __forceinline__ static int kq(int i) {           // first reduction index of chunk i
-    const int c = (threadIdx.x + NT * i) & 7;
-    return 16 * (c >> 2) + 8 * (c & 1);
-  }
+  unsigned off;            // bytes: (row0 + t >> 3, first reduction group) + 16 (t & 7)
+  unsigned row_step;       // bytes between the thread's consecutive chunks: NT / 8 rows
+  int kq;                  // first reduction index of the thread's chunk within a slab
+  int depth;               // reduction indices from the first slab on
+  int rows_left;           // operand rows from the thread's first one on
   __device__ __forceinline__ void init(const HlSrc& s, int row0, int kb, int ke) {
     const int tid = threadIdx.x;
     rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.p), 0, s.extent, 0x00020000);
-    k_begin = kb; k_end = ke;
+    const int c = tid & 7;
+    kq = 16 * (c >> 2) + 8 * (c & 1);
+    depth = ke - kb;
+    rows_left = s.rows - row0 - (tid >> 3);
+    off = (unsigned)((hl_index(row0 + (tid >> 3), kb, s.ld) + 8 * c) * 2);
+    row_step = (unsigned)(NT / 8) * (unsigned)s.ld * 4u;
+  }
+  // (the address arithmetic apart from the loads: VALU at the head of an MFMA phase is slow)
+  __device__ __forceinline__ void offsets(int kt, unsigned (&o)[4]) const {
+    const unsigned ok = kt * HBK + kq < depth ? off + (unsigned)(kt * HBK * 4) : kOob;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = tid + NT * i;
-      const int row = row0 + (ch >> 3);
-      off[i] = row < s.rows ? (unsigned)((hl_index(row, kb, s.ld) + 8 * (ch & 7)) * 2) : kOob;
-    }
+    for (int i = 0; i < 4; ++i) o[i] = i * (NT / 8) < rows_left ? ok : kOob;
+  }
+  __device__ __forceinline__ void issue(const unsigned (&o)[4], u32x4g (&v)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[i], i * row_step, 0);
   }
   __device__ __forceinline__ void load(int kt, u32x4g (&v)[4]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = k_begin + kt * HBK + kq(i) < k_end && off[i] != kOob;
-      const unsigned o = ok ? off[i] + (unsigned)(kt * HBK * 4) : kOob;
-      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
-    }
+    unsigned o[4];
+    offsets(kt, o);
+    issue(o, v);
   }
   __device__ __forceinline__ static void store(const u32x4g (&v)[4], _Float16* Shi, _Float16* Slo) {
     const int tid = threadIdx.x;
+    const int c = tid & 7;
+    _Float16* dst = ((c >> 1) & 1 ? Slo : Shi) + hl256_slot(tid >> 3, 2 * (c >> 2) + (c & 1));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = tid + NT * i;
-      const int c = ch & 7;
-      const int slot = hl256_slot(ch >> 3, 2 * (c >> 2) + (c & 1));
-      *reinterpret_cast<u32x4g*>(((c >> 1) & 1 ? Slo : Shi) + slot) = v[i];
-    }
+    for (int i = 0; i < 4; ++i)       // + NT / 8 rows: the same swizzle (NT / 8 is a multiple of 16)
+      *reinterpret_cast<u32x4g*>(dst + i * (NT / 8) * 32) = v[i];
   }
 };
 
-// WN waves across the columns (2 rows of waves), MI x NJ 32 x 32 MFMA tiles per wave: the
-// square tile is 64 MI = 32 NJ WN wide and every thread stages two 16-byte chunks per plane.
+// WN waves across the columns (2 rows of waves); a wave owns 32 MI x 32 NJ of the tile as
+// RB x CB = 2 MI x 2 NJ MFMA tiles of 16 x 16: the square tile is 64 MI = 32 NJ WN wide and
+// every thread stages four 16-byte chunks per operand.
 //   <4, 4, 2>: 256 x 256, 512 threads, 128 KB LDS -- the main kernel;
 //   <2, 2, 2>: 128 x 128, 256 threads,  64 KB LDS -- small outputs, and the one that fits on a
 //              CU BESIDE a recurrent workgroup (96 KB + 64 KB of LDS, 2 + 1 waves per SIMD).
+// The MFMA takes the fragment of B (16 columns of C) as its first operand and the fragment of A
+// (16 rows of C) as its second: a lane then holds FOUR CONSECUTIVE COLUMNS of one row of C
+// (row = lane & 15, columns 4 (lane >> 4) ..), and the epilogue is 16-byte stores.
+//
 // Debug (asr_gemm_hl_profile): shader clocks per phase of the K loop, summed over the slabs of
 // workgroup 0 of a launch, per wave: 0 fragment reads, 1 barrier before the MFMAs, 2 MFMAs of
-// the first 16-deep half (with the staging traffic), 3 MFMAs of the second half, 4 barrier
-// behind the MFMAs, 5 the prologue; 6 = the K loop in ticks of the 100 MHz real-time counter (s_memrealtime).
-#ifndef HL_EXP
-#define HL_EXP 0            // timing experiments only (tools/build_variant.sh): 1 no LDS staging
-#endif                      // writes, 2 no global loads in the K loop, 4 no epilogue stores
-#ifndef HL_STAGE
-#define HL_STAGE 0
-#endif
-#ifndef HL_LOAD_GAP
-#define HL_LOAD_GAP 2
-#endif
+// the first half of the rows (with the staging traffic), 3 MFMAs of the second half, 4 barrier
+// behind the MFMAs, 5 the prologue; 6 = the K loop in ticks of the 100 MHz real-time counter.
 __device__ int g_hl_prof_on = 0;
 __device__ long long g_hl_prof[8][8];
 
@@ -966,8 +974,9 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
                 Epilogue ep, const float* __restrict__ a_scale,
                 const float* __restrict__ b_scale) {
   constexpr int NT = 128 * WN, TM2 = 64 * MI, TN2 = 32 * NJ * WN;
-  static_assert(TM2 == TN2 && TM2 * 4 == 2 * NT, "square tile, two chunks per thread and plane");
-  using HlLoader256 = HlLoaderX<NT>;
+  constexpr int RB = 2 * MI, CB = 2 * NJ;           // 16 x 16 tiles per wave: rows x columns
+  static_assert(TM2 == TN2 && TM2 * 8 == 4 * NT, "square tile, four chunks per thread and operand");
+  using Loader = HlLoaderX<NT>;
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
   // halfs per plane: + 64 bytes, so that a row's hi and lo chunks (one 8-lane group of the
   // staging ds_write_b128) fall into different banks
@@ -984,16 +993,14 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
   if (k_end > K) k_end = K;
   const float sa = a_scale ? *a_scale : 1.f, sb = b_scale ? *b_scale : 1.f;
 
-  f32x16 am[MI][NJ];
+  f32x4 am[RB][CB];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) am[i][j][e] = 0.f;
+    for (int j = 0; j < CB; ++j) am[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const bool prof = g_hl_prof_on != 0 && blockIdx.x == 0;
-  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long pt[6] = {0, 0, 0, 0, 0, 0};
   long long plast = prof ? (long long)__builtin_readcyclecounter() : 0;
   auto stamp = [&](int i) {
     if (prof) {
@@ -1002,28 +1009,29 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
       plast = now;
     }
   };
-  HlLoader256 la, lb;
+  Loader la, lb;
   la.init(A, m0, k_begin, k_end);
   lb.init(B, n0, k_begin, k_end);
   // One register set, two slabs ahead: at the top of step kt the registers hold slab kt+1
   // (issued a whole step earlier, so it has landed); it is written to the LDS buffer the
   // barrier at the end of step kt-1 released, and the loads of slab kt+2 are issued at once --
-  // they fly across this step's 48 MFMAs per wave AND its barrier (plain buffer loads, no
+  // they fly across this step's 96 MFMAs per wave AND its barriers (plain buffer loads, no
   // vmcnt wait at the barrier).  The scheduling fence keeps the compiler from sinking the
   // loads to their use, which would expose the whole L2/HBM latency every step.
   u32x4g av[4], bv[4];
   const int nk = (k_end - k_begin + HBK - 1) / HBK;
   la.load(0, av);
   lb.load(0, bv);
-  HlLoader256::store(av, plane(0, 0), plane(0, 1));
-  HlLoader256::store(bv, plane(0, 2), plane(0, 3));
+  Loader::store(av, plane(0, 0), plane(0, 1));
+  Loader::store(bv, plane(0, 2), plane(0, 3));
   la.load(1, av);
   lb.load(1, bv);
   __syncthreads();
-  const int lrow = lane & 31, lhalf = lane >> 5;
-  // Ping-pong: a step is four phases -- read the fragments of one 16-deep half, 24 MFMAs on
-  // them (with, in the first half, the LDS writes of the next slab and the loads of the one
-  // after interleaved), and again for the other half -- each closed by a workgroup barrier.  The second row of
+  const int frow = lane & 15, fk = lane >> 4;       // fragment: row of its 16, 16-byte K chunk
+  // Ping-pong: a step is four phases -- read the fragments of half of the wave's rows (and, the
+  // first time, of all its columns), 12 MI NJ MFMAs on them (with, in the first half, the LDS
+  // writes of the next slab and the loads of the one after interleaved), and again for the
+  // other rows -- each closed by a workgroup barrier.  The second row of
   // waves (wm = 1; waves w and w+4 share a SIMD) runs ONE BARRIER LATE, so on every SIMD one
   // wave multiplies while the other reads: the matrix pipe no longer idles through the LDS
   // round trips of two waves in lockstep.  Buffer hazards with the one-phase lag: a slab's
@@ -1038,103 +1046,78 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
     const _Float16* Al = plane(cur, 1);
     const _Float16* Bh = plane(cur, 2);
     const _Float16* Bl = plane(cur, 3);
-    hx8 fah[MI], fal[MI], fbh[NJ], fbl[NJ];
+    hx8 fah[MI], fal[MI], fbh[CB], fbl[CB];
 #pragma unroll
-    for (int ks = 0; ks < HBK / 16; ++ks) {
+    for (int hf = 0; hf < 2; ++hf) {
+      if (hf == 0) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int slot = hl256_slot(wn * (32 * NJ) + j * 32 + lrow, 2 * ks + lhalf);
-        fbh[j] = *reinterpret_cast<const hx8*>(Bh + slot);
-        fbl[j] = *reinterpret_cast<const hx8*>(Bl + slot);
+        for (int j = 0; j < CB; ++j) {
+          const int slot = hl256_slot(wn * (32 * NJ) + j * 16 + frow, fk);
+          fbh[j] = *reinterpret_cast<const hx8*>(Bh + slot);
+          fbl[j] = *reinterpret_cast<const hx8*>(Bl + slot);
+        }
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const int slot = hl256_slot(wm * (32 * MI) + i * 32 + lrow, 2 * ks + lhalf);
+        const int slot = hl256_slot(wm * (32 * MI) + (hf * MI + i) * 16 + frow, fk);
         fah[i] = *reinterpret_cast<const hx8*>(Ah + slot);
         fal[i] = *reinterpret_cast<const hx8*>(Al + slot);
       }
-#if HL_STAGE == 1
-      if (ks == 0) {
-        HlLoader256::store(av, plane(nxt, 0), plane(nxt, 1));
-        HlLoader256::store(bv, plane(nxt, 2), plane(nxt, 3));
-        la.load(kt + 2, av);
-        lb.load(kt + 2, bv);
+      unsigned oa[4], ob[4];
+      if (hf == 0) {
+        la.offsets(kt + 2, oa);
+        lb.offsets(kt + 2, ob);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(oa[i]), "+v"(ob[i]));
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       stamp(0);
       __syncthreads();
       stamp(1);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      if (ks == 0 && HL_STAGE == 0) {
-        // the staging traffic rides in the issue gaps of this phase's MFMAs (32 cycles of pipe
+      if (hf == 0) {
+        // the staging traffic rides in the issue gaps of this phase's MFMAs (16 cycles of pipe
         // per MFMA, ~4 of issue): the 8 LDS writes of slab kt+1 first -- each frees its
-        // registers -- then the 8 loads of slab kt+2 into them; the read phases stay bare
-#if !(HL_EXP & 1)
-        HlLoader256::store(av, plane(nxt, 0), plane(nxt, 1));
-        HlLoader256::store(bv, plane(nxt, 2), plane(nxt, 3));
-#endif
-        // past the last slab every offset is out of range: those loads return zeros, unused
-#if !(HL_EXP & 2)
-        la.load(kt + 2, av);
-        lb.load(kt + 2, bv);
-#endif
-
+        // registers -- then the 8 loads of slab kt+2 into them; the read phases stay bare.
+        // Past the last slab every offset is out of range: those loads return zeros, unused.
+        Loader::store(av, plane(nxt, 0), plane(nxt, 1));
+        Loader::store(bv, plane(nxt, 2), plane(nxt, 3));
+        la.issue(oa, av);
+        lb.issue(ob, bv);
       }
-#if HL_STAGE == 2
-      if (ks == 0) {
-        HlLoader256::store(av, plane(nxt, 0), plane(nxt, 1));
-        la.load(kt + 2, av);
-      } else {
-        HlLoader256::store(bv, plane(nxt, 2), plane(nxt, 3));
-        lb.load(kt + 2, bv);
-      }
-#endif
-      // term-major order: consecutive MFMAs go to eight different accumulators
+      // term-major order: consecutive MFMAs go to MI CB different accumulators
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh[j], am[i][j], 0, 0, 0);
+        for (int j = 0; j < CB; ++j)
+          am[hf * MI + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[j], fal[i], am[hf * MI + i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], am[i][j], 0, 0, 0);
+        for (int j = 0; j < CB; ++j)
+          am[hf * MI + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[j], fah[i], am[hf * MI + i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], am[i][j], 0, 0, 0);
-      if (ks == 0 && HL_STAGE == 0) {
-        constexpr int NM = 3 * MI * NJ;                    // MFMAs of the phase: 24 or 12
+        for (int j = 0; j < CB; ++j)
+          am[hf * MI + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[j], fah[i], am[hf * MI + i][j], 0, 0, 0);
+      if (hf == 0) {
+        constexpr int NM = 3 * MI * CB;                    // MFMAs of the phase: 48 or 24
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
+          __builtin_amdgcn_sched_group_barrier(0x008, NM >= 48 ? 2 : 1, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                  // DS write
         }
 #pragma unroll
-        for (int g = 0; g < (NM - 8) / 2 && g < 8; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, NM >= 24 ? 2 : 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x020, NM >= 24 ? 1 : 2, 0);   // VMEM read
+        for (int g = 0; g < 8; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NM >= 48 ? 4 : 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  // VMEM read
         }
       }
-#if HL_STAGE == 2
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, HL_LOAD_GAP, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-#endif
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      stamp(ks == 0 ? 2 : 3);
+      stamp(hf == 0 ? 2 : 3);
       __syncthreads();
       stamp(4);
       __builtin_amdgcn_sched_barrier(0);
@@ -1146,105 +1129,105 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
     for (int i = 0; i < 6; ++i) g_hl_prof[wave][i] = pt[i];
     g_hl_prof[wave][6] = (long long)__builtin_amdgcn_s_memrealtime() - real0;
   }
-#if HL_EXP & 4
-  if (K != -12345) return;
-#endif
+  // ---- epilogue: lane = (row frow of a 16 x 16 tile, its columns 4 fk .. 4 fk + 3)
   const float unscale = 1.f / (sa * sb);
-  const int lcol = lane & 31;
+  const int row_w = m0 + wm * (32 * MI) + frow;      // + 16 i
+  const int col_w = n0 + wn * (32 * NJ) + 4 * fk;    // + 16 j
   const bool interior = m0 + TM2 <= M && n0 + TN2 <= N;
+  // 16-byte stores need 16-byte aligned rows
+  const bool vec_c = (ep.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(ep.C) & 15) == 0;
   // The epilogue is 1/5 of a K = 1024 tile if it is written element by element with its
   // options tested inside (hipcc branches around every optional load and waits for it): the
   // variants are separated OUTSIDE the element loops, the interior ones are straight-line code.
-  if (interior && ep.partial) {                 // split-K partial sums
+  if (interior && ep.partial && (N & 3) == 0) {                 // split-K partial sums
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        float* dst = ep.partial + ((size_t)tb.z * M + m0 + wm * (32 * MI) + i * 32 + 4 * lhalf) * N +
-                     n0 + wn * (32 * NJ) + j * 32 + lcol;
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          dst[(size_t)((e & 3) + 8 * (e >> 2)) * N] = am[i][j][e] * unscale;
+      for (int j = 0; j < CB; ++j) {
+        float* dst = ep.partial + ((size_t)tb.z * M + row_w + 16 * i) * N + col_w + 16 * j;
+        *reinterpret_cast<f32x4*>(dst) = am[i][j] * unscale;
       }
     return;
   }
   const bool use_old = ep.beta != 0.f;
   const bool use_msk = ep.c_scale != nullptr;
-  if (interior && !ep.partial && !use_old && !use_msk) {      // C = alpha A B^T + bias
+  if (interior && !ep.partial && vec_c && !use_old && !use_msk) {      // C = alpha A B^T + bias
     const float sc = unscale * ep.alpha;
+    f32x4 bias[CB];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < CB; ++j) {
+      bias[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ep.bias)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = n0 + wn * (32 * NJ) + j * 32 + lcol;
-        float* dst = ep.C + (size_t)(m0 + wm * (32 * MI) + i * 32 + 4 * lhalf) * ep.ldc + col;
-        const float bias = ep.bias ? ep.bias[col] : 0.f;
+        for (int e = 0; e < 4; ++e) bias[j][e] = ep.bias[col_w + 16 * j + e];
+    }
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          dst[(size_t)((e & 3) + 8 * (e >> 2)) * ep.ldc] = am[i][j][e] * sc + bias;
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        float* dst = ep.C + (size_t)(row_w + 16 * i) * ep.ldc + col_w + 16 * j;
+        *reinterpret_cast<f32x4*>(dst) = am[i][j] * sc + bias[j];
       }
     return;
   }
-  if (interior && !ep.partial) {                 // with old C and / or a row mask: loads first
+  const bool vec_m = !use_msk || ((ep.c_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(ep.c_scale) & 15) == 0);
+  if (interior && !ep.partial && vec_c && vec_m) {   // with old C and / or a row mask: loads first
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < RB; ++i) {
+      const int row = row_w + 16 * i;
+      f32x4 old[CB], msk[CB];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int col = n0 + wn * (32 * NJ) + j * 32 + lcol;
-        const int row0 = m0 + wm * (32 * MI) + i * 32 + 4 * lhalf;
-        float* dst = ep.C + (size_t)row0 * ep.ldc + col;
-        const float bias = ep.bias ? ep.bias[col] : 0.f;
-        float old[16], msk[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { old[e] = 0.f; msk[e] = 1.f; }
-        if (use_old) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) old[e] = dst[(size_t)((e & 3) + 8 * (e >> 2)) * ep.ldc];
-        }
-        if (use_msk) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            msk[e] = ep.c_scale[(size_t)mod_period(row0 + (e & 3) + 8 * (e >> 2), ep.c_period) *
-                                ep.c_ld + col];
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          dst[(size_t)((e & 3) + 8 * (e >> 2)) * ep.ldc] =
-              (am[i][j][e] * unscale * ep.alpha + bias) * msk[e] + ep.beta * old[e];
+      for (int j = 0; j < CB; ++j) {
+        old[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        msk[j] = f32x4{1.f, 1.f, 1.f, 1.f};
       }
+      if (use_old) {
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+          old[j] = *reinterpret_cast<const f32x4*>(ep.C + (size_t)row * ep.ldc + col_w + 16 * j);
+      }
+      if (use_msk) {
+        const float* mrow = ep.c_scale + (size_t)mod_period(row, ep.c_period) * ep.c_ld;
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+          msk[j] = *reinterpret_cast<const f32x4*>(mrow + col_w + 16 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < CB; ++j) {
+        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ep.bias)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bias[e] = ep.bias[col_w + 16 * j + e];
+        float* dst = ep.C + (size_t)row * ep.ldc + col_w + 16 * j;
+        *reinterpret_cast<f32x4*>(dst) = (am[i][j] * (unscale * ep.alpha) + bias) * msk[j] + ep.beta * old[j];
+      }
+    }
     return;
   }
-  // edge tiles: per-element bound checks
+  // edge tiles (and unaligned outputs): per-element bound checks
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int col = n0 + wn * (32 * NJ) + j * 32 + lcol;
-      const int row0 = m0 + wm * (32 * MI) + i * 32 + 4 * lhalf;
-      if (col >= N) continue;
-      if (ep.partial) {
-        float* dst = ep.partial + ((size_t)tb.z * M + row0) * N + col;
+    for (int j = 0; j < CB; ++j) {
+      const int row = row_w + 16 * i;
+      if (row >= M) continue;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int dr = (e & 3) + 8 * (e >> 2);
-          if (row0 + dr < M) dst[(size_t)dr * N] = am[i][j][e] * unscale;
+      for (int e = 0; e < 4; ++e) {
+        const int col = col_w + 16 * j + e;
+        if (col >= N) continue;
+        if (ep.partial) {
+          ep.partial[((size_t)tb.z * M + row) * N + col] = am[i][j][e] * unscale;
+          continue;
         }
-        continue;
-      }
-      float* dst = ep.C + (size_t)row0 * ep.ldc + col;
-      const float bias = ep.bias ? ep.bias[col] : 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int dr = (e & 3) + 8 * (e >> 2);
-        if (row0 + dr >= M) continue;
-        float v = am[i][j][e] * unscale * ep.alpha + bias;
-        if (use_msk)
-          v *= ep.c_scale[(size_t)mod_period(row0 + dr, ep.c_period) * ep.c_ld + col];
-        if (use_old) v += ep.beta * dst[(size_t)dr * ep.ldc];
-        dst[(size_t)dr * ep.ldc] = v;
+        float* dst = ep.C + (size_t)row * ep.ldc + col;
+        float v = am[i][j][e] * unscale * ep.alpha + (ep.bias ? ep.bias[col] : 0.f);
+        if (use_msk) v *= ep.c_scale[(size_t)mod_period(row, ep.c_period) * ep.c_ld + col];
+        if (use_old) v += ep.beta * *dst;
+        *dst = v;
       }
     }
 }
+
 
 // max |x| of a flat tensor -> out[0] (float).  Two launches: per-block maxima via
 // atomicMax on the float bits (all non-negative, so integer order == float order).
@@ -1557,8 +1540,10 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
   // bytes from the first row's first group to the end of the last row's last group
   const size_t ext_a = ((size_t)(a->M - 1) * 2 * a->lda + (size_t)((a->K + 15) / 16) * 32) * 2;
   const size_t ext_b = ((size_t)(a->N - 1) * 2 * a->ldb + (size_t)((a->K + 15) / 16) * 32) * 2;
+  // (32-bit offsets; a tile's rows past the operand are computed before they are masked)
   const size_t lim = ((size_t)1 << 32) - ((size_t)1 << 20);
-  ASR_CHECK_ARG(ext_a < lim && ext_b < lim, "gemm_hl: operand larger than 4 GiB");
+  ASR_CHECK_ARG(ext_a + (size_t)1024 * a->lda * 4 < lim && ext_b + (size_t)1024 * a->ldb * 4 < lim,
+                "gemm_hl: operand larger than 4 GiB");
   int kps = 0;
   const int splits = hl_splits(a, &kps);
   Epilogue ep;
