@@ -10,7 +10,7 @@
 // previous step has finished: a latency problem, not a throughput one.
 //
 // Design (CDNA4; measured history in DESIGN.md, from 11.4 / 19.5 us per step in the first
-// version to 2.2 / 2.5 now at H = 256):
+// version to 1.5 / 1.6 now at H = 256, 1.8 / 2.1 at H = 512):
 //  * A layer is a set of independent CHAINS (direction, 16-row batch tile).  A
 //    chain is split over 256-thread workgroups by hidden units (16 per WG); the
 //    four waves of a WG sit one per SIMD (one MFMA pipe each) and keep their slice
@@ -21,10 +21,11 @@
 //  * Arithmetic (default, ASR_LSTM_PREC=1): every fp32 operand is split into fp16
 //    hi + lo (22 mantissa bits) and a product is three v_mfma_f32_16x16x32_f16 with
 //    fp32 accumulation (error ~2^-22) instead of eight exact fp32 MFMAs; BPTT scales
-//    each batch column by its own power of two first.  ASR_LSTM_PREC=0 keeps the
-//    exact v_mfma_f32_16x16x4_f32 kernels (fwd_body / bwd_body).
+//    each batch column by its own power of two first.  ASR_LSTM_PREC=0 selects the
+//    same kernel structure on exact v_mfma_f32_16x16x4_f32 (the EXACT instantiations of
+//    fwd_body_x / bwd_body_c: plain cell, H = 256 / 512, persistent mode).
 //  * Forward: workgroups exchange h_t, split and packed by the PRODUCER (one word =
-//    fp16 hi << 16 | fp16 lo).  From H = 256 up (fwd_body_k) K is split over the four
+//    fp16 hi << 16 | fp16 lo).  At H = 256 / 512 (fwd_body_x) K is split over the four
 //    waves: a wave multiplies all 64 gate columns of the WG with the quarter of h it
 //    gathered itself (registers -> MFMA B operand, no LDS staging), and the partial
 //    gate tiles meet in LDS; narrower layers (fwd_body_h) stage h in LDS once and
@@ -33,7 +34,15 @@
 //    own dz_J (local) with U[:, J] for ALL H outputs and publishes the partial dh
 //    tiles; a consumer lane gathers the 16-byte group of its (sample, unit quad) from
 //    every producer, adds them in registers and across four lanes with DPP quad
-//    permutes.  Exchange volume is H x 16 words per producer, not the 4H-wide dz.
+//    permutes.  Exchange volume is H x 16 words per producer, not the 4H-wide dz
+//    (bwd_body_h, bwd_body_x).  At H = 512 that exchange is 1 MB per chain-step and was
+//    written through to HBM: bwd_body_c splits a chain in two dimensions instead (4 OT
+//    unit blocks x 4 sample quarters, the whole batch per chain), a workgroup reduces
+//    over its 64 units in registers and exchanges 64 x 16 dh words with the 4 OT - 1
+//    others of its sample quarter.
+//  * Kernel choice is asr_lstm_plan's (make_plan): _x / _c for the plain cell at
+//    H = 256 / 512 in persistent mode, _h / _hv otherwise (any H <= 512, variants,
+//    stepwise); ASR_LSTM_GENERIC=1 forces _h (the tests compare the two).
 //  * A step's first poll is preceded by a short nap (ASR_LSTM_PREPOLL_F/_B): a poll
 //    that reaches the L2 before the producers' stores costs a whole extra round trip.
 //  * The optional cell variants (multiplicative integration, zoneout) are the VAR
@@ -296,177 +305,6 @@ __device__ __forceinline__ bool map_block(const LstmParams& p, int& chain_local,
 }
 
 // ---------------------------------------------------------------------------
-// forward.  WG = 4 waves = 4 unit groups (4 units each); each wave spans all of K.
-template <int MAXR, bool FAST>
-__device__ __forceinline__ void fwd_body(const LstmParams& p, int chain, int wg, float* lds) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, nl = lane & 15;
-  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
-  const int UG = H >> 2;
-  const int R = p.R;
-  const int dir = chain / p.NB, bt = chain % p.NB;
-  const int ug = wg * 4 + w;
-  const bool ug_ok = ug < UG;
-  const int n = bt * 16 + nl;
-  const int u = 4 * ug + g;
-  const int kbase = g * R;                        // this lane's K slice [kbase, kbase+R)
-  const int HS = 4 * R + 4;                       // LDS row stride of the h tile (>= H+4)
-  float* hbuf0 = lds;                             // [2][16][HS]
-  const int hb_words = 16 * HS;
-
-  float uf[MAXR];
-#pragma unroll
-  for (int kk = 0; kk < MAXR; ++kk) {
-    const int k = kbase + kk;
-    uf[kk] = (ug_ok && kk < R && k < H) ? p.U[((size_t)(dir * H + k)) * H4 + 16 * ug + nl] : 0.f;
-  }
-  float mask = 1.f;
-  if (ug_ok && p.mask_u) mask = p.mask_u[((size_t)dir * p.n_pad + n) * H + u];
-  float c = 0.f;
-  bool dead = false;
-  unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;    // [2][UG][16][4]
-  const int slot_words = 16 * H;
-  const int s_end = p.s_begin + p.s_count;
-
-  if (ug_ok && p.s_begin > 0) {
-    const int tpp = dir == 0 ? p.s_begin - 1 : p.T - p.s_begin;
-    c = p.cell[(((size_t)tpp * p.n_pad + n) * 2 + dir) * H + u];
-  }
-  // zero the K padding of the LDS tiles once (columns >= H are never written)
-  for (int e = tid; e < 2 * hb_words; e += kThreads) hbuf0[e] = 0.f;
-  __syncthreads();
-  auto load_zx = [&](int ss) -> float4 {
-    if (!ug_ok || ss >= s_end || (p.dbg & 1)) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const int tt = dir == 0 ? ss : p.T - 1 - ss;
-    return *reinterpret_cast<const float4*>(
-        p.zx + (((size_t)tt * p.n_pad + n) * 2 + dir) * H4 + 4 * u);
-  };
-  float4 zx_next = load_zx(p.s_begin);
-  constexpr int NL = (MAXR * 4 * 16 / 4 + kThreads - 1) / kThreads;   // 16-B groups / thread
-  const bool prof = (p.dbg & 32) && wg == 0 && chain == p.chain_begin && lane == 0;
-  long long pt[5] = {0, 0, 0, 0, 0}, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
-  for (int s = p.s_begin; s < s_end; ++s) {
-    if (prof) tk0 = wall_clock64();
-    const int t = dir == 0 ? s : p.T - 1 - s;
-    const float4 zx4 = zx_next;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
-    if (s > 0) {
-      // ---- gather h_{s-1} (already masked by its producer) into LDS, once per WG
-      float* hbuf = hbuf0 + (s & 1) * hb_words;
-      const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
-      __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          xch + (size_t)((s - 1) & 1) * slot_words, 0, slot_words * 4, 0x00020000);
-      unsigned off[NL];
-      bool use[NL];
-      u32x4 v[NL];
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const int grp = tid + i * kThreads;       // group = (unit group, sample)
-        use[i] = grp < UG * 16;
-        off[i] = (unsigned)grp * 16u;
-      }
-      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
-                              p.prepoll, p.repoll, p.spin);
-      if (prof) tk1 = wall_clock64();
-      // next step's input projection: issued behind the poll (so the poll's in-order
-      // wait never includes its HBM latency), consumed one whole compute phase later
-      zx_next = load_zx(s + 1);
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        if (use[i]) {
-          const int grp = tid + i * kThreads;
-          const int gu = grp >> 4, gn = grp & 15;
-          *reinterpret_cast<float4*>(hbuf + gn * HS + 4 * gu) =
-              make_float4(__uint_as_float(v[i][0] & ~1u), __uint_as_float(v[i][1] & ~1u),
-                          __uint_as_float(v[i][2] & ~1u), __uint_as_float(v[i][3] & ~1u));
-        }
-      }
-      __syncthreads();
-      if (prof) tk2 = wall_clock64();
-      if (ug_ok && !(p.dbg & 4)) {
-        const float* hrow = hbuf + nl * HS + kbase;
-        // all B operands first (back-to-back ds_read_b128, counted lgkmcnt waits),
-        // then one uninterrupted MFMA chain
-        float4 hv[MAXR / 4];
-#pragma unroll
-        for (int q = 0; q < MAXR / 4; ++q)
-          hv[q] = (4 * q < R) ? *reinterpret_cast<const float4*>(hrow + 4 * q)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < MAXR / 4; ++q) {
-          if (4 * q < R) {
-            // four independent accumulators: the 40-cycle dependent latency of the
-            // 32-cycle-issue MFMA never stalls the pipe
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q], hv[q].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q + 1], hv[q].y, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q + 2], hv[q].z, acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[4 * q + 3], hv[q].w, acc3, 0, 0, 0);
-          }
-        }
-      }
-    } else {
-      zx_next = load_zx(s + 1);
-    }
-    const f32x4 a = (acc0 + acc1) + (acc2 + acc3);
-    if (prof) { asm volatile("" :: "v"(a[0])); tk3 = wall_clock64(); }
-    if (ug_ok) {
-      const float gi = hard_sigmoid(a[0] + zx4.x);
-      const float gf = hard_sigmoid(a[1] + zx4.y);
-      const float gg = fast_tanh(a[2] + zx4.z);
-      const float go = hard_sigmoid(a[3] + zx4.w);
-      c = gf * c + gi * gg;
-      const float h = go * fast_tanh(c);
-      if (s + 1 < p.T) {
-        // lanes nl, nl+16, nl+32, nl+48 hold units 4ug..4ug+3 of sample nl: collect
-        // them in lane nl so the wave publishes ONE contiguous 256-byte tile
-        const unsigned wtag = (unsigned)(s >> 1) & 1u;
-        const unsigned w0 = tag_word(h * mask, wtag);
-        u32x4 o;
-        o[0] = w0;
-        o[1] = (unsigned)__shfl_down((int)w0, 16, 64);
-        o[2] = (unsigned)__shfl_down((int)w0, 32, 64);
-        o[3] = (unsigned)__shfl_down((int)w0, 48, 64);
-        if (lane < 16) {
-          __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-              xch + (size_t)(s & 1) * slot_words, 0, slot_words * 4, 0x00020000);
-          xstore<FAST>(o, wr, (unsigned)(ug * 16 + nl) * 16u);
-        }
-      }
-      if (!(p.dbg & 2)) {
-        const size_t row = (size_t)t * p.n_pad + n;
-        p.y[row * H2 + dir * H + u] = h;
-        p.cell[(row * 2 + dir) * H + u] = c;
-        *reinterpret_cast<float4*>(p.gates + (row * 2 + dir) * H4 + 4 * u) =
-            make_float4(gi, gf, gg, go);
-      }
-    }
-    if (prof && s > 0) {
-      const long long tk4 = wall_clock64();
-      pt[0] += tk1 - tk0; pt[1] += tk2 - tk1; pt[2] += tk3 - tk2; pt[3] += tk4 - tk3;
-    }
-  }
-  if (prof) {
-    long long* out = reinterpret_cast<long long*>(p.status + 16) + 6 * w;
-    for (int i = 0; i < 4; ++i) out[i] = pt[i];
-  }
-}
-
-template <int MAXR>
-__global__ void __launch_bounds__(kThreads)
-lstm_fwd_kernel(LstmParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int chain_local, wg;
-  if (!map_block(p, chain_local, wg)) return;
-  const int chain = p.chain_begin + chain_local;
-  const bool fast = chain_on_one_xcd(p, chain, wg, reinterpret_cast<int*>(lds));
-  if (fast) fwd_body<MAXR, true>(p, chain, wg, lds);
-  else fwd_body<MAXR, false>(p, chain, wg, lds);
-}
-
-
 // forward, split-fp16 MFMA variant.  NKK = number of K=32 MFMA steps (H <= 32*NKK).
 template <int NKK, bool FAST, bool VAR>
 __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int wg, float* lds) {
@@ -761,47 +599,75 @@ __device__ __forceinline__ unsigned packed_word(float hm, unsigned tag) {
 // transport.
 template <int NKW> struct FwdMfma;
 template <> struct FwdMfma<2> {
-  // am = sum_kk Uh[kk] Bh[kk] ; ac = sum_kk (Uh[kk] Bl[kk] + Ul[kk] Bh[kk])
-  static __device__ __forceinline__ void run(f32x4& am, f32x4& ac, const f32x4 (&uh)[2],
-                                             const f32x4 (&ul)[2], const h8 (&bh)[2],
-                                             const h8 (&bl)[2]) {
+  // TWO unit groups at once: am_j = sum_kk Uh_j[kk] Bh[kk] ; ac_j = sum_kk (Uh_j[kk] Bl[kk] +
+  // Ul_j[kk] Bh[kk]), each chain's terms in the order kk = 0, 1, .. -- every result bit as if a
+  // group ran alone -- but the four chains interleaved so that an accumulator is reused three
+  // MFMAs (48 cycles of pipe) later at the earliest: a lone group's 2 chains wait on the ~40
+  // cycles of MFMA latency at every step (the K-slice phase measured 1450 cycles for 768 of
+  // pipe).
+  static __device__ __forceinline__ void run2(f32x4& am0, f32x4& ac0, f32x4& am1, f32x4& ac1,
+                                              const f32x4 (&uh0)[2], const f32x4 (&ul0)[2],
+                                              const f32x4 (&uh1)[2], const f32x4 (&ul1)[2],
+                                              const h8 (&bh)[2], const h8 (&bl)[2]) {
     asm volatile(
         "s_nop 1\n\t"
-        "v_mfma_f32_16x16x32_f16 %0, %2, %6, 0\n\t"
-        "v_mfma_f32_16x16x32_f16 %1, %2, %8, 0\n\t"
-        "v_mfma_f32_16x16x32_f16 %0, %3, %7, %0\n\t"
-        "v_mfma_f32_16x16x32_f16 %1, %4, %6, %1\n\t"
-        "v_mfma_f32_16x16x32_f16 %1, %3, %9, %1\n\t"
-        "v_mfma_f32_16x16x32_f16 %1, %5, %7, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %4, %14, 0\n\t"      // ac0 += uh0[0] bl[0]
+        "v_mfma_f32_16x16x32_f16 %3, %8, %14, 0\n\t"      // ac1 += uh1[0] bl[0]
+        "v_mfma_f32_16x16x32_f16 %0, %4, %12, 0\n\t"      // am0 += uh0[0] bh[0]
+        "v_mfma_f32_16x16x32_f16 %1, %6, %12, %1\n\t"      // ac0 += ul0[0] bh[0]
+        "v_mfma_f32_16x16x32_f16 %3, %10, %12, %3\n\t"      // ac1 += ul1[0] bh[0]
+        "v_mfma_f32_16x16x32_f16 %2, %8, %12, 0\n\t"      // am1 += uh1[0] bh[0]
+        "v_mfma_f32_16x16x32_f16 %1, %5, %15, %1\n\t"      // ac0 += uh0[1] bl[1]
+        "v_mfma_f32_16x16x32_f16 %3, %9, %15, %3\n\t"      // ac1 += uh1[1] bl[1]
+        "v_mfma_f32_16x16x32_f16 %0, %5, %13, %0\n\t"      // am0 += uh0[1] bh[1]
+        "v_mfma_f32_16x16x32_f16 %1, %7, %13, %1\n\t"      // ac0 += ul0[1] bh[1]
+        "v_mfma_f32_16x16x32_f16 %3, %11, %13, %3\n\t"      // ac1 += ul1[1] bh[1]
+        "v_mfma_f32_16x16x32_f16 %2, %9, %13, %2\n\t"      // am1 += uh1[1] bh[1]
         "s_nop 11"
-        : "=&v"(am), "=&v"(ac)
-        : "a"(uh[0]), "a"(uh[1]), "a"(ul[0]), "a"(ul[1]), "v"(bh[0]), "v"(bh[1]), "v"(bl[0]),
-          "v"(bl[1]));
+        : "=&v"(am0), "=&v"(ac0), "=&v"(am1), "=&v"(ac1)
+        : "a"(uh0[0]), "a"(uh0[1]), "a"(ul0[0]), "a"(ul0[1]), "a"(uh1[0]), "a"(uh1[1]), "a"(ul1[0]), "a"(ul1[1]), "v"(bh[0]), "v"(bh[1]), "v"(bl[0]), "v"(bl[1]));
   }
 };
 template <> struct FwdMfma<4> {
-  static __device__ __forceinline__ void run(f32x4& am, f32x4& ac, const f32x4 (&uh)[4],
-                                             const f32x4 (&ul)[4], const h8 (&bh)[4],
-                                             const h8 (&bl)[4]) {
+  // TWO unit groups at once: am_j = sum_kk Uh_j[kk] Bh[kk] ; ac_j = sum_kk (Uh_j[kk] Bl[kk] +
+  // Ul_j[kk] Bh[kk]), each chain's terms in the order kk = 0, 1, .. -- every result bit as if a
+  // group ran alone -- but the four chains interleaved so that an accumulator is reused three
+  // MFMAs (48 cycles of pipe) later at the earliest: a lone group's 2 chains wait on the ~40
+  // cycles of MFMA latency at every step (the K-slice phase measured 1450 cycles for 768 of
+  // pipe).
+  static __device__ __forceinline__ void run2(f32x4& am0, f32x4& ac0, f32x4& am1, f32x4& ac1,
+                                              const f32x4 (&uh0)[4], const f32x4 (&ul0)[4],
+                                              const f32x4 (&uh1)[4], const f32x4 (&ul1)[4],
+                                              const h8 (&bh)[4], const h8 (&bl)[4]) {
     asm volatile(
         "s_nop 1\n\t"
-        "v_mfma_f32_16x16x32_f16 %0, %2, %10, 0\n\t"      // am  = uh0 bh0
-        "v_mfma_f32_16x16x32_f16 %1, %2, %14, 0\n\t"      // ac  = uh0 bl0
-        "v_mfma_f32_16x16x32_f16 %0, %3, %11, %0\n\t"     // am += uh1 bh1
-        "v_mfma_f32_16x16x32_f16 %1, %6, %10, %1\n\t"     // ac += ul0 bh0
-        "v_mfma_f32_16x16x32_f16 %0, %4, %12, %0\n\t"     // am += uh2 bh2
-        "v_mfma_f32_16x16x32_f16 %1, %3, %15, %1\n\t"     // ac += uh1 bl1
-        "v_mfma_f32_16x16x32_f16 %0, %5, %13, %0\n\t"     // am += uh3 bh3
-        "v_mfma_f32_16x16x32_f16 %1, %7, %11, %1\n\t"     // ac += ul1 bh1
-        "v_mfma_f32_16x16x32_f16 %1, %4, %16, %1\n\t"     // ac += uh2 bl2
-        "v_mfma_f32_16x16x32_f16 %1, %8, %12, %1\n\t"     // ac += ul2 bh2
-        "v_mfma_f32_16x16x32_f16 %1, %5, %17, %1\n\t"     // ac += uh3 bl3
-        "v_mfma_f32_16x16x32_f16 %1, %9, %13, %1\n\t"     // ac += ul3 bh3
+        "v_mfma_f32_16x16x32_f16 %1, %4, %24, 0\n\t"      // ac0 += uh0[0] bl[0]
+        "v_mfma_f32_16x16x32_f16 %3, %12, %24, 0\n\t"      // ac1 += uh1[0] bl[0]
+        "v_mfma_f32_16x16x32_f16 %0, %4, %20, 0\n\t"      // am0 += uh0[0] bh[0]
+        "v_mfma_f32_16x16x32_f16 %1, %8, %20, %1\n\t"      // ac0 += ul0[0] bh[0]
+        "v_mfma_f32_16x16x32_f16 %3, %16, %20, %3\n\t"      // ac1 += ul1[0] bh[0]
+        "v_mfma_f32_16x16x32_f16 %2, %12, %20, 0\n\t"      // am1 += uh1[0] bh[0]
+        "v_mfma_f32_16x16x32_f16 %1, %5, %25, %1\n\t"      // ac0 += uh0[1] bl[1]
+        "v_mfma_f32_16x16x32_f16 %3, %13, %25, %3\n\t"      // ac1 += uh1[1] bl[1]
+        "v_mfma_f32_16x16x32_f16 %0, %5, %21, %0\n\t"      // am0 += uh0[1] bh[1]
+        "v_mfma_f32_16x16x32_f16 %1, %9, %21, %1\n\t"      // ac0 += ul0[1] bh[1]
+        "v_mfma_f32_16x16x32_f16 %3, %17, %21, %3\n\t"      // ac1 += ul1[1] bh[1]
+        "v_mfma_f32_16x16x32_f16 %2, %13, %21, %2\n\t"      // am1 += uh1[1] bh[1]
+        "v_mfma_f32_16x16x32_f16 %1, %6, %26, %1\n\t"      // ac0 += uh0[2] bl[2]
+        "v_mfma_f32_16x16x32_f16 %3, %14, %26, %3\n\t"      // ac1 += uh1[2] bl[2]
+        "v_mfma_f32_16x16x32_f16 %0, %6, %22, %0\n\t"      // am0 += uh0[2] bh[2]
+        "v_mfma_f32_16x16x32_f16 %1, %10, %22, %1\n\t"      // ac0 += ul0[2] bh[2]
+        "v_mfma_f32_16x16x32_f16 %3, %18, %22, %3\n\t"      // ac1 += ul1[2] bh[2]
+        "v_mfma_f32_16x16x32_f16 %2, %14, %22, %2\n\t"      // am1 += uh1[2] bh[2]
+        "v_mfma_f32_16x16x32_f16 %1, %7, %27, %1\n\t"      // ac0 += uh0[3] bl[3]
+        "v_mfma_f32_16x16x32_f16 %3, %15, %27, %3\n\t"      // ac1 += uh1[3] bl[3]
+        "v_mfma_f32_16x16x32_f16 %0, %7, %23, %0\n\t"      // am0 += uh0[3] bh[3]
+        "v_mfma_f32_16x16x32_f16 %1, %11, %23, %1\n\t"      // ac0 += ul0[3] bh[3]
+        "v_mfma_f32_16x16x32_f16 %3, %19, %23, %3\n\t"      // ac1 += ul1[3] bh[3]
+        "v_mfma_f32_16x16x32_f16 %2, %15, %23, %2\n\t"      // am1 += uh1[3] bh[3]
         "s_nop 11"
-        : "=&v"(am), "=&v"(ac)
-        : "a"(uh[0]), "a"(uh[1]), "a"(uh[2]), "a"(uh[3]), "a"(ul[0]), "a"(ul[1]), "a"(ul[2]),
-          "a"(ul[3]), "v"(bh[0]), "v"(bh[1]), "v"(bh[2]), "v"(bh[3]), "v"(bl[0]), "v"(bl[1]),
-          "v"(bl[2]), "v"(bl[3]));
+        : "=&v"(am0), "=&v"(ac0), "=&v"(am1), "=&v"(ac1)
+        : "a"(uh0[0]), "a"(uh0[1]), "a"(uh0[2]), "a"(uh0[3]), "a"(ul0[0]), "a"(ul0[1]), "a"(ul0[2]), "a"(ul0[3]), "a"(uh1[0]), "a"(uh1[1]), "a"(uh1[2]), "a"(uh1[3]), "a"(ul1[0]), "a"(ul1[1]), "a"(ul1[2]), "a"(ul1[3]), "v"(bh[0]), "v"(bh[1]), "v"(bh[2]), "v"(bh[3]), "v"(bl[0]), "v"(bl[1]), "v"(bl[2]), "v"(bl[3]));
   }
 };
 
@@ -994,13 +860,17 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       bl[kk] = __builtin_bit_cast(h8, lo);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 am, ac;
-      FwdMfma<NKW>::run(am, ac, ufh[j], ufl[j], bh, bl);
-      f32x4 r;
+    for (int j = 0; j < 4; j += 2) {
+      f32x4 am0, ac0, am1, ac1;
+      FwdMfma<NKW>::run2(am0, ac0, am1, ac1, ufh[j], ufl[j], ufh[j + 1], ufl[j + 1], bh, bl);
+      f32x4 r0, r1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(ac[e], 1.f / kLoScale, am[e]);
-      mine[j * 64 + lane] = r;
+      for (int e = 0; e < 4; ++e) {
+        r0[e] = __builtin_fmaf(ac0[e], 1.f / kLoScale, am0[e]);
+        r1[e] = __builtin_fmaf(ac1[e], 1.f / kLoScale, am1[e]);
+      }
+      mine[j * 64 + lane] = r0;
+      mine[(j + 1) * 64 + lane] = r1;
     }
     }
     prof.stamp(2);
@@ -1200,207 +1070,6 @@ __device__ __forceinline__ void tile_gate_sums(float4 gsum, float* lds, float* d
   }
   __syncthreads();
 }
-
-// backward (BPTT).  WG `cw` of a chain owns units [16 cw, 16 cw + 16) = gate
-// columns j in [64 cw, 64 cw + 64).  TPW = output tiles (16 units) per wave.
-template <int TPW, bool FAST>
-__device__ __forceinline__ void bwd_body(const LstmParams& p, int chain, int cw, float* lds) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, nl = lane & 15;
-  const int H = p.H, H4 = 4 * H, H2 = 2 * H;
-  const int P = p.P;                              // = ceil(H / 16)
-  const int dir = chain / p.NB, bt = chain % p.NB;
-  constexpr int DZS = 68;                         // LDS row stride of the dz tile
-  float* dzl = lds;                               // [16 n][DZS] own gate gradients
-  float* part = lds + 16 * DZS;                   // [P][256] gathered partial dh
-
-  // stationary A fragments: rows k = 16*mt + (lane&15), cols j = 64*cw + 16*g + kk
-  float uf[TPW][16];
-#pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int mt = w + 4 * i;
-    const int krow = 16 * mt + nl;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const int j = 64 * cw + 16 * g + kk;
-      uf[i][kk] = (mt < P && krow < H && j < H4) ? p.U[((size_t)(dir * H + krow)) * H4 + j] : 0.f;
-    }
-  }
-  // every thread owns one (sample, unit) of the cell backward: n = tid/16, ul = tid%16
-  const int cn = bt * 16 + (tid >> 4);
-  const int cu = 16 * cw + (tid & 15);
-  const bool cvalid = cu < H;
-  float cmask = 1.f;
-  if (cvalid && p.mask_u) cmask = p.mask_u[((size_t)dir * p.n_pad + cn) * H + cu];
-  float dc = 0.f;
-  float zmax = 0.f;
-  float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);   // sum over steps of this (sample, unit)'s dz
-  if (cvalid && p.s_begin > 0) dc = p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu];
-  bool dead = false;
-  unsigned* xch = p.xbuf + (size_t)chain * p.xchain_words;   // [2][P cons][P prod][256]
-  const size_t slot_words = (size_t)P * P * 256;
-  const int s_end = p.s_begin + p.s_count;
-  constexpr int NL = TPW;                          // P*64 groups / 256 threads <= TPW
-  const bool prof = (p.dbg & 32) && cw == 0 && chain == p.chain_begin && lane == 0;
-  long long pt[5] = {0, 0, 0, 0, 0}, tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
-
-  // slab loads (dy, c_t, c_prev, gates) run one step ahead of their use and are
-  // issued right AFTER a step's gather, so the poll's in-order wait never covers
-  // their HBM latency
-  float nx_dy = 0.f, nx_c = 0.f, nx_cp = 0.f;
-  float4 nx_g = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_slabs = [&](int ss) {
-    nx_dy = 0.f; nx_c = 0.f; nx_cp = 0.f; nx_g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!cvalid || ss >= s_end) return;
-    const int tt = dir == 0 ? p.T - 1 - ss : ss;
-    const int tcc = dir == 0 ? tt - 1 : tt + 1;
-    const size_t row = (size_t)tt * p.n_pad + cn;
-    nx_dy = p.dy[row * H2 + dir * H + cu];
-    nx_c = p.cell[(row * 2 + dir) * H + cu];
-    if (ss + 1 < p.T) nx_cp = p.cell[(((size_t)tcc * p.n_pad + cn) * 2 + dir) * H + cu];
-    nx_g = *reinterpret_cast<const float4*>(p.gates + (row * 2 + dir) * H4 + 4 * cu);
-  };
-  load_slabs(p.s_begin);
-
-  for (int s = p.s_begin; s < s_end; ++s) {
-    if (prof) tk0 = wall_clock64();
-    const int t = dir == 0 ? p.T - 1 - s : s;     // reverse of the forward order
-    // ---- this step's slab values were loaded during the previous step
-    const float dyv = nx_dy, cv = nx_c, cpv = nx_cp;
-    const float4 gt = nx_g;
-    float dh_rec = 0.f;
-    if (s > 0) {
-      // ---- gather the partial dh tiles addressed to this WG: [P prod][16 n][16 u]
-      const unsigned tag = (unsigned)((s - 1) >> 1) & 1u;
-      __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          xch + (size_t)((s - 1) & 1) * slot_words + (size_t)cw * P * 256, 0, P * 256 * 4,
-          0x00020000);
-      unsigned off[NL];
-      bool use[NL];
-      u32x4 v[NL];
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const int grp = tid + i * kThreads;
-        use[i] = grp < P * 64;
-        off[i] = (unsigned)grp * 16u;
-      }
-      gather_groups<FAST, NL>(rsrc, off, use, tag, p.poll, dead, p.status, v, p.dbg & 64,
-                              p.prepoll, p.repoll, p.spin);
-      if (prof) tk1 = wall_clock64();
-      load_slabs(s + 1);
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        if (use[i]) {
-          *reinterpret_cast<float4*>(part + 4 * (tid + i * kThreads)) =
-              make_float4(__uint_as_float(v[i][0] & ~1u), __uint_as_float(v[i][1] & ~1u),
-                          __uint_as_float(v[i][2] & ~1u), __uint_as_float(v[i][3] & ~1u));
-        }
-      }
-      __syncthreads();
-      if (prof) tk2 = wall_clock64();
-      // element (n, ul) of every producer tile sits at [n*16 + ul] == tid
-      for (int pr = 0; pr < P; ++pr) dh_rec += part[pr * 256 + tid];
-    } else {
-      load_slabs(s + 1);
-    }
-    // ---- cell backward for own units -> dz (LDS for the MFMA, global for the GEMMs)
-    {
-      float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cvalid) {
-        const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
-        const float dh = dyv + cmask * dh_rec;
-        const float tch = fast_tanh(cv);
-        const float d_o = dh * tch;
-        const float dcc = dc + dh * go * (1.f - tch * tch);
-        const float d_i = dcc * gg, d_g = dcc * gi, d_f = dcc * cpv;
-        dc = dcc * gf;
-        z4.x = d_i * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
-        z4.y = d_f * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
-        z4.z = d_g * (1.f - gg * gg);
-        z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
-        *reinterpret_cast<float4*>(p.dz + (((size_t)t * p.n_pad + cn) * 2 + dir) * H4 + 4 * cu) = z4;
-        zmax = fmaxf(zmax, fmaxf(fmaxf(fabsf(z4.x), fabsf(z4.y)), fmaxf(fabsf(z4.z), fabsf(z4.w))));
-        gsum.x += z4.x; gsum.y += z4.y; gsum.z += z4.z; gsum.w += z4.w;
-      }
-      *reinterpret_cast<float4*>(dzl + (tid >> 4) * DZS + 4 * (tid & 15)) = z4;
-    }
-    __syncthreads();
-    if (prof) tk3 = wall_clock64();
-    // ---- partial dh_{prev}[k] = sum_{j in J} U[k][j] dz[j] for ALL k; publish per tile
-    if (s + 1 < p.T) {
-      float bv[16];
-      {
-        const float* drow = dzl + nl * DZS + 16 * g;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 d4 = *reinterpret_cast<const float4*>(drow + 4 * q);
-          bv[4 * q] = d4.x; bv[4 * q + 1] = d4.y; bv[4 * q + 2] = d4.z; bv[4 * q + 3] = d4.w;
-        }
-      }
-      const unsigned wtag = (unsigned)(s >> 1) & 1u;
-      __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-          xch + (size_t)(s & 1) * slot_words, 0, (unsigned)(slot_words * 4), 0x00020000);
-      // straight-line: tile i's publish is issued as soon as its 16 MFMAs retire and
-      // never waits for an earlier tile's store (distinct registers, no branches; a
-      // tile index past the chain is dropped by the buffer bounds check)
-      u32x4 o[TPW];
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        const int mt = w + 4 * i;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 16; kk += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][kk], bv[kk], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(uf[i][kk + 1], bv[kk + 1], acc1, 0, 0, 0);
-        }
-        const f32x4 a = acc0 + acc1;
-        // lane (g, nl) holds units 4g..4g+3 of consumer tile mt for sample nl
-        o[i][0] = tag_word(a[0], wtag); o[i][1] = tag_word(a[1], wtag);
-        o[i][2] = tag_word(a[2], wtag); o[i][3] = tag_word(a[3], wtag);
-        const unsigned off = mt < P
-            ? (unsigned)((((size_t)mt * P + cw) * 256 + nl * 16 + 4 * g) * 4)
-            : 0xFFFFFFF0u;
-        xstore<FAST>(o[i], wr, off);
-      }
-    }
-    // part[] is overwritten by the next gather, which every thread starts only after
-    // the barrier above; dzl is rewritten only after the next step's first barrier,
-    // which every wave reaches after its MFMA reads of this step.
-    if (prof && s > 0) {
-      const long long tk4 = wall_clock64();
-      pt[0] += tk1 - tk0; pt[1] += tk2 - tk1; pt[2] += tk3 - tk2; pt[3] += tk4 - tk3;
-    }
-  }
-  if (prof) {
-    long long* out = reinterpret_cast<long long*>(p.status + 16) + 6 * w;
-    for (int i = 0; i < 4; ++i) out[i] = pt[i];
-  }
-  if (cvalid && p.dc_state) p.dc_state[((size_t)dir * p.n_pad + cn) * H + cu] = dc;
-  if (p.db_part) {
-    const int left = H4 - 64 * cw;
-    tile_gate_sums(gsum, lds, p.db_part + ((size_t)bt * 2 + dir) * H4 + 64 * cw, p.s_begin > 0,
-                   left < 64 ? left : 64);
-  }
-  if (p.dz_absmax) {
-    zmax = asr_wave_max(zmax);
-    if (lane == 0 && zmax > 0.f) atomicMax(p.dz_absmax, __float_as_uint(zmax));
-  }
-}
-
-template <int TPW>
-__global__ void __launch_bounds__(kThreads)
-lstm_bwd_kernel(LstmParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int chain_local, cw;
-  if (!map_block(p, chain_local, cw)) return;
-  const int chain = p.chain_begin + chain_local;
-  const bool fast = chain_on_one_xcd(p, chain, cw, reinterpret_cast<int*>(lds));
-  if (fast) bwd_body<TPW, true>(p, chain, cw, lds);
-  else bwd_body<TPW, false>(p, chain, cw, lds);
-}
-
 
 // backward, split-fp16 MFMA variant.  The gate gradients dz span many orders of
 // magnitude, so each batch column n is scaled by its own power of two (max |dz|
@@ -2492,7 +2161,7 @@ lstm_bwd_kernel_c(LstmParams p) {
 
 // ---------------------------------------------------------------------------
 struct Plan {
-  int R, P, TPW, MAXR, NKK, prec;
+  int R, P, TPW, NKK, prec;
   int n1;                  // 1: single-utterance forward kernel (2 chains = 2 directions)
   int form_c;              // 1: BPTT with the two-dimensional split (lstm_bwd_kernel_c)
   size_t shm;
@@ -2504,13 +2173,6 @@ int up4(int x) { return (x + 3) & ~3; }
 
 typedef void (*kern_t)(LstmParams);
 
-kern_t pick_fwd(int maxr) {
-  switch (maxr) {
-    case 32: return lstm_fwd_kernel<32>;
-    case 64: return lstm_fwd_kernel<64>;
-    default: return lstm_fwd_kernel<128>;
-  }
-}
 kern_t pick_fwd_h(int nkk) {
   switch (nkk) {
     case 4: return lstm_fwd_kernel_h<4>;
@@ -2541,15 +2203,6 @@ kern_t pick_bwd_h(int tpw) {
     default: return lstm_bwd_kernel_h<8>;
   }
 }
-kern_t pick_bwd(int tpw) {
-  switch (tpw) {
-    case 1: return lstm_bwd_kernel<1>;
-    case 2: return lstm_bwd_kernel<2>;
-    case 4: return lstm_bwd_kernel<4>;
-    default: return lstm_bwd_kernel<8>;
-  }
-}
-
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -2581,7 +2234,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   if (!bwd && a->n_valid == 1 && a->mode == 0 && (H == 256 || H == 512) &&
       !(a->mi || a->zone_c || a->zone_h || a->uh) && env_int("ASR_LSTM_N1", 1)) {
     // one utterance: the tile-free exact-fp32 kernel (fwd_body_n1); 2 chains = 2 directions
-    pl.R = 0; pl.MAXR = 0; pl.TPW = 0; pl.NKK = 0; pl.n1 = 1;
+    pl.R = 0; pl.TPW = 0; pl.NKK = 0; pl.n1 = 1;
     pl.shm = (size_t)(H + 256) * 4;
     pl.xchain_words = (size_t)2 * H;
     k = H == 256 ? lstm_fwd_kernel_n1<64> : lstm_fwd_kernel_n1<128>;
@@ -2591,15 +2244,16 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       asr_set_error("lstm fwd: H=%d too large for the register-resident U slice (max 512)", H);
       return ASR_ERR_INVALID;
     }
-    pl.MAXR = pl.R <= 32 ? 32 : pl.R <= 64 ? 64 : 128;
     pl.TPW = 0;
-    pl.shm = (size_t)2 * 16 * (4 * pl.R + 4) * 4;
-    pl.xchain_words = (size_t)2 * 16 * H;
-    k = pick_fwd(pl.MAXR);
-    if (pl.prec == 0 && a->mode == 0 && (H == 256 || H == 512) &&
-        !(a->mi || a->zone_c || a->zone_h || a->uh) && env_int("ASR_LSTM_GENERIC", 0) == 0) {
-      // exact fp32 at the benchmarked widths: the structure of the split-fp16 kernel on
-      // v_mfma_f32_16x16x4_f32 (fwd_body_x<.., EXACT>)
+    k = nullptr;
+    if (pl.prec == 0) {
+      // exact fp32: the structure of the split-fp16 kernel on v_mfma_f32_16x16x4_f32
+      // (fwd_body_x<.., EXACT>) -- built for the widths it is benchmarked and compared at
+      if (!(a->mode == 0 && (H == 256 || H == 512) && !(a->mi || a->zone_c || a->zone_h || a->uh))) {
+        asr_set_error("lstm fwd: ASR_LSTM_PREC=0 (exact fp32 MFMA) exists for the plain cell at "
+                      "H = 256 / 512 in persistent mode; H=%d mode=%d", H, a->mode);
+        return ASR_ERR_INVALID;
+      }
       pl.xchain_words = (size_t)2 * (H / 4) * (size_t)(fwd_xstride() / 4);
       pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
       k = H == 256 ? lstm_fwd_kernel_x<2, true> : lstm_fwd_kernel_x<4, true>;
@@ -2624,19 +2278,22 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       }
     }
   } else {
-    pl.R = 16; pl.MAXR = 0;
+    pl.R = 16;
     const int tpw = (pl.P + 3) / 4;
     if (tpw > 8) {
       asr_set_error("lstm bwd: H=%d too large (max 512)", H);
       return ASR_ERR_INVALID;
     }
     pl.TPW = tpw <= 1 ? 1 : tpw <= 2 ? 2 : tpw <= 4 ? 4 : 8;
-    pl.shm = (size_t)(16 * 68 + pl.P * 256) * 4;
     pl.xchain_words = (size_t)2 * pl.P * pl.P * 256;
-    k = pick_bwd(pl.TPW);
-    if (pl.prec == 0 && a->mode == 0 && (H == 256 || H == 512) &&
-        !(a->mi || a->zone_c || a->zone_h) && env_int("ASR_LSTM_GENERIC", 0) == 0) {
-      // exact fp32 at the benchmarked widths: the two-dimensional split on fp32 MFMAs
+    k = nullptr;
+    if (pl.prec == 0) {
+      // exact fp32: the two-dimensional split on fp32 MFMAs (bwd_body_c<.., EXACT>)
+      if (!(a->mode == 0 && (H == 256 || H == 512) && !(a->mi || a->zone_c || a->zone_h))) {
+        asr_set_error("lstm bwd: ASR_LSTM_PREC=0 (exact fp32 MFMA) exists for the plain cell at "
+                      "H = 256 / 512 in persistent mode; H=%d mode=%d", H, a->mode);
+        return ASR_ERR_INVALID;
+      }
       pl.form_c = 1;
       pl.shm = (size_t)2 * 16 * 260 * 4;
       pl.xchain_words = (size_t)4 * 4 * (H / 64) * (H / 64) * 256;

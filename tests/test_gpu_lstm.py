@@ -451,19 +451,24 @@ def test_bptt_two_dimensional_split_matches_the_one_dimensional_kernel(N, H, mon
 @pytest.mark.parametrize('N,H', [(32, 256), (64, 512), (16, 512)])
 def test_exact_fp32_kernels_at_the_benchmarked_widths(N, H, monkeypatch):
     """ASR_LSTM_PREC=0 at H = 256 / 512: the structure of the split-fp16 kernels (forward: K split
-    over the waves; BPTT: two-dimensional split) on v_mfma_f32_16x16x4_f32, against the any-H
-    exact kernels (ASR_LSTM_GENERIC=1) and against the split-fp16 default: activations to 2e-6 /
-    1e-5, gate gradients to 1e-6 / 2e-5 of the largest; sliced == whole bit for bit; db_part ==
-    the sums of the dz slab; with a recurrent-dropout mask."""
+    over the waves; BPTT: two-dimensional split) on v_mfma_f32_16x16x4_f32, against the float64
+    oracle (activations to 5e-6, gate gradients to 1e-5 of the largest: fp32 rounding only) and
+    against the split-fp16 default (1e-5 / 2e-5); sliced == whole bit for bit; db_part == the
+    sums of the dz slab; with a recurrent-dropout mask.  Any other width / mode is refused."""
     from asr_study_amd import ops
+    from asr_study_amd._lib import AsrHipError
     T = 41
-    rs = np.random.RandomState(7 * H + N)
+    rs, x, p, masks = _case(T, N, 8, H, 7 * H + N, True)
     n_pad = ops.pad16(N)
     dev = 'cuda:0'
-    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
-    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
-    dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.1).astype(np.float32)).to(dev)
-    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
+    dhs = {d: rs.randn(T, N, H) * 0.1 for d in ('fwd', 'bwd')}
+    want = _oracle(x, p, masks, dhs)
+    zx_h, U_h, mk_h = _pack_inputs(x, p, masks, H, n_pad)
+    zx, U, mask = to_dev(zx_h), to_dev(U_h), to_dev(mk_h)
+    dy_h = np.zeros((T, n_pad, 2 * H), np.float32)
+    dy_h[:, :N, :H] = dhs['fwd']
+    dy_h[:, :N, H:] = dhs['bwd']
+    dy = to_dev(dy_h)
 
     def run(ranges):
         y = torch.full((T, n_pad, 2 * H), 3.0, device=dev)
@@ -478,23 +483,34 @@ def test_exact_fp32_kernels_at_the_benchmarked_widths(N, H, monkeypatch):
             ws = ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=mask, steps=r,
                                   db_part=dbp)
         ops.lstm_status(ws)
-        want = dz.double().reshape(T, n_pad // 16, 16, 2, 4 * H).sum(dim=(0, 2))
-        assert (dbp.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+        sums = dz.double().reshape(T, n_pad // 16, 16, 2, 4 * H).sum(dim=(0, 2))
+        assert (dbp.double() - sums).abs().max().item() < 2e-5 * max(1.0, sums.abs().max().item())
         return [t.cpu().numpy() for t in (y, cell, gates, dz)]
     monkeypatch.setenv('ASR_LSTM_PREC', '1')
     split = run([None])
     monkeypatch.setenv('ASR_LSTM_PREC', '0')
-    monkeypatch.setenv('ASR_LSTM_GENERIC', '1')
-    generic = run([None])
-    monkeypatch.setenv('ASR_LSTM_GENERIC', '0')
     got = run([None])
-    for name, a, b, c in zip(('y', 'cell', 'gates', 'dz'), got, generic, split):
-        scale = max(1.0, np.abs(b).max()) if name != 'dz' else np.abs(b).max()
-        assert report('exact %s vs generic exact N%d H%d' % (name, N, H), a, b) < 2e-6 * scale
+    tag = 'N%d H%d' % (N, H)
+    for di, d in enumerate(('fwd', 'bwd')):
+        ref = dict(y=want[d]['hs'], cell=want[d]['cache']['cs'],
+                   gates=gate_major_to_unit_major(want[d]['cache']['gates'], H),
+                   dz=gate_major_to_unit_major(want[d]['cache']['dzs'], H))
+        mine = dict(y=got[0][:, :N, di * H:(di + 1) * H], cell=got[1][:, :N, di],
+                    gates=got[2][:, :N, di], dz=got[3][:, :N, di])
+        for name in ('y', 'cell', 'gates', 'dz'):
+            scale = max(1.0, np.abs(ref[name]).max()) if name != 'dz' else np.abs(ref[name]).max()
+            tol = 1e-5 if name == 'dz' else 5e-6
+            assert report('exact %s %s vs float64 %s' % (name, d, tag), mine[name], ref[name]) < tol * scale
+    for name, a, c in zip(('y', 'cell', 'gates', 'dz'), got, split):
+        scale = max(1.0, np.abs(a).max()) if name != 'dz' else np.abs(a).max()
         assert report('exact %s vs split-fp16' % name, a, c) < (2e-5 if name == 'dz' else 1e-5) * scale
     sliced = run([(0, 1), (1, 13), (14, 27)])
     for name, a, b in zip(('y', 'cell', 'gates', 'dz'), got, sliced):
         assert np.array_equal(a, b), name
+    # the exact arithmetic is built for these widths in persistent mode only
+    with pytest.raises(AsrHipError):
+        ops.lstm_seq_fwd(zx, U, torch.empty_like(dy), torch.empty(T, n_pad, 2, H, device=dev),
+                         torch.empty_like(zx), T, n_pad, H, mask_u=mask, mode=1)
 
 
 @pytest.mark.parametrize('H', [256, 512])
