@@ -52,16 +52,23 @@ __device__ __forceinline__ float wave_shift_down(float v, float fill) {
 // (no scaling multiplies, and the sum lies in [1, 3], so no denormal fix-up either).
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr double kLn2 = 0.6931471805599453;
+// Two transcendentals and no branch: log2(2^a + 2^b) = max + log2(1 + 2^(min - max)); with both
+// arguments -inf the difference is taken against a finite floor (-inf - floor = -inf, 2^-inf = 0)
+// and the sum max + 0 is -inf again.
 __device__ __forceinline__ float lse2_b2(float a, float b) {
   const float m = fmaxf(a, b);
-  if (m == kNegInf) return m;
-  return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m));
+  const float d = fminf(a, b) - fmaxf(m, -3.0e38f);
+  return m + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(d));
 }
+
+// Three-way sum with three transcendentals: the largest term is 1, the other two are the median
+// and the minimum (v_max3 / v_med3 / v_min3).
 __device__ __forceinline__ float lse3_b2(float a, float b, float c) {
   const float m = fmaxf(fmaxf(a, b), c);
-  if (m == kNegInf) return m;
-  return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) +
-                                   __builtin_amdgcn_exp2f(c - m));
+  const float f = fmaxf(m, -3.0e38f);
+  const float md = __builtin_amdgcn_fmed3f(a, b, c) - f;
+  const float mn = fminf(fminf(a, b), c) - f;
+  return m + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(md) + __builtin_amdgcn_exp2f(mn));
 }
 
 // ---------------------------------------------------------------------------
@@ -119,10 +126,15 @@ struct CtcLane {
 #pragma unroll
     for (int p = 0; p < PPL; ++p) {
       const float lp1 = (p == 0) ? lprev : sl[p - 1];
-      nsb[p] = lse2_b2(sb[p], lp1) + eb;
-      const float sk = diffp[p] ? lp1 : kNegInf;
+      // blank state: from itself or the previous label.  The label state adds itself to the
+      // same sum when the skip from the previous label is legal: with several pairs per lane
+      // the step is issue-bound and re-uses that sum (4 transcendentals per pair instead of
+      // 5); with one pair per lane it is latency-bound and the two sums run side by side.
+      const float x = lse2_b2(sb[p], lp1);
+      nsb[p] = x + eb;
       const float e = valid[p] ? el[p] : kNegInf;
-      nsl[p] = lse3_b2(sl[p], sb[p], sk) + e;
+      if (PPL == 1) nsl[p] = lse3_b2(sl[p], sb[p], diffp[p] ? lp1 : kNegInf) + e;
+      else nsl[p] = lse2_b2(sl[p], diffp[p] ? x : sb[p]) + e;
     }
 #pragma unroll
     for (int p = 0; p < PPL; ++p) { sb[p] = nsb[p]; sl[p] = nsl[p]; }
