@@ -784,6 +784,9 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     const long long t0 = wall_clock64();
     bool gave_up = false;
     while (stale) {
+#ifdef POLLCOUNT
+      if (prof.on) prof.pt[0] += 1000000;
+#endif
       for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
       load_groups(x, rsrc);
       stale = !all_tagged<NL>(v[x], flip);
@@ -1868,6 +1871,9 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     const long long t0 = wall_clock64();
     bool gave_up = false;
     while (stale) {
+#ifdef POLLCOUNT
+      if (prof.on) prof.pt[0] += 1000000;
+#endif
       for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
       load_groups(rsrc);
       stale = !all_tagged<NL>(v, flip);
@@ -1971,12 +1977,16 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
           hi8[j >> 1][4 * (j & 1) + e] = x;
           lo8[j >> 1][4 * (j & 1) + e] = y;
         }
-      _Float16* rh = dzh + n * DZS + 16 * q;
-      _Float16* rl = dzl + n * DZS + 16 * q;
+      // column c = 16 q + 8 half + e of the tile row lives at half 128 half + 8 q + e: the 8
+      // lanes of a ds_write_b128 group then cover 128 contiguous bytes, and the fragment reads
+      // below (lane = sample nl, chunk g) hit 16 different 16-byte bank groups (the
+      // column-major order 16 q + 8 half had both two-way conflicted: 49 % of the LDS cycles)
+      _Float16* rh = dzh + n * DZS + 8 * q;
+      _Float16* rl = dzl + n * DZS + 8 * q;
       *reinterpret_cast<h8*>(rh) = hi8[0];
-      *reinterpret_cast<h8*>(rh + 8) = hi8[1];
+      *reinterpret_cast<h8*>(rh + 128) = hi8[1];
       *reinterpret_cast<h8*>(rl) = lo8[0];
-      *reinterpret_cast<h8*>(rl + 8) = lo8[1];
+      *reinterpret_cast<h8*>(rl + 128) = lo8[1];
     }
     }
     // (b is uniform: scalar branches, no indexed access)
@@ -2039,8 +2049,9 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       h8 bh[KS], bl[KS];
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
-        bh[kk] = *reinterpret_cast<const h8*>(dzh + nl * DZS + 32 * kk + 8 * g);
-        bl[kk] = *reinterpret_cast<const h8*>(dzl + nl * DZS + 32 * kk + 8 * g);
+        // columns 32 kk + 8 g .. + 7 = (q = 2 kk + (g >> 1), half = g & 1)
+        bh[kk] = *reinterpret_cast<const h8*>(dzh + nl * DZS + 128 * (g & 1) + 16 * kk + 8 * (g >> 1));
+        bl[kk] = *reinterpret_cast<const h8*>(dzl + nl * DZS + 128 * (g & 1) + 16 * kk + 8 * (g >> 1));
       }
       const float us = sinv[nl];
       const float usl = us * (1.f / kLoScale);
