@@ -144,14 +144,6 @@ class Model(object):
         self._pipe_split16 = min(15, max(9, int(_os.environ.get('ASR_PIPE_SPLIT', '12'))))
         self.pipeline = self.overlap and self._pipeline_mode == '1'
         self._pipe = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
-        # ASR_REC_CUS=n: the recurrences run on a stream confined to n compute units (two
-        # latency-bound workgroups per CU, 80 KB of LDS each) and leave the rest of the chip
-        # to the GEMM streams
-        self._rec = None
-        self._rec_cus = int(_os.environ.get('ASR_REC_CUS', '0') or 0)
-        # tile of the weight-gradient GEMMs (side stream): 128 = the 4-wave / 80 KB kernel that
-        # can share a CU with a recurrent workgroup (when those reserve no LDS: ASR_LSTM_EXCL=0)
-        self._side_tile = int(_os.environ.get('ASR_SIDE_TILE', '0') or 0)
         # big GEMMs on operands packed once into split-fp16 planes (ops.pack_hl / gemm_hl);
         # ASR_GEMM_PACKED=0 keeps the convert-per-tile kernels, ASR_GEMM_PREC=0 (exact fp32) too
         # 'auto': from 512 hidden units on (measured: +4 % at 5 x BiLSTM(512) with the 256 x 256
@@ -425,32 +417,6 @@ class Model(object):
     def _gview(self, off, n):
         return self.grads[off:off + n]
 
-    # ------------------------------------------------------------------ recurrence partition
-    def _recurrence(self, fn):
-        """Runs a recurrent launch (ops.lstm_seq_fwd / _bwd) -- on the CU-masked stream when the
-        chip is partitioned (ASR_REC_CUS), ordered against the current stream by events."""
-        if not self._rec_cus or self.device.type != 'cuda':
-            return fn()
-        if self._rec is None:
-            total = torch.cuda.get_device_properties(self.device).multi_processor_count
-            self._rec = ops.cu_masked_stream(self.device, min(self._rec_cus, total), total)
-        main = torch.cuda.current_stream(self.device)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        prev = ops.LSTM_LDS_KB
-        ops.LSTM_LDS_KB = 80
-        try:
-            with torch.cuda.stream(self._rec):
-                self._rec.wait_event(ev)
-                r = fn()
-                done = torch.cuda.Event()
-                done.record(self._rec)
-        finally:
-            ops.LSTM_LDS_KB = prev
-        main.wait_event(done)
-        return r
-
-    # ------------------------------------------------------------------ packed operands
     def _planes(self, name, rows, k):
         """Cached ops.HlPlanes buffer (rows, k) under `name` (stale shapes dropped)."""
         key = (name, int(rows), int(k))
@@ -644,9 +610,9 @@ class Model(object):
                     rec['ws'] = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
                                                  mode=self.lstm_mode, steps=(S, T - S))
                 else:
-                    rec['ws'] = self._recurrence(lambda: ops.lstm_seq_fwd(
+                    rec['ws'] = ops.lstm_seq_fwd(
                         zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU, mode=self.lstm_mode,
-                        n_valid=n_valid if not need_grad else 0, **var))
+                        n_valid=n_valid if not need_grad else 0, **var)
                 rec.update(y=y, cell=cell, gates=gates)
                 a = y
             rec['out'] = a
@@ -893,9 +859,9 @@ class Model(object):
                 else:
                     if s.mi is None:
                         var['db_part'] = pgrad[0]
-                    rec['ws_b'] = self._recurrence(lambda: ops.lstm_seq_bwd(
+                    rec['ws_b'] = ops.lstm_seq_bwd(
                         da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp, mask_u=BU,
-                        mode=self.lstm_mode, dz_absmax=zmx, **var))
+                        mode=self.lstm_mode, dz_absmax=zmx, **var)
                     flush_side()    # previous layer's dW/dU/db now overlap this BPTT
                 y = rec['y']
                 hl = self._stage_packed(s)
@@ -922,17 +888,17 @@ class Model(object):
                         ops.gemm_hl(yu, pdz_c, self.grads, Hp, 4 * Hp, kk,
                                     a_k=0 if d == 0 else n_pad, b_row=d * 4 * Hp,
                                     b_k=n_pad if d == 0 else 0, c_off=s.oU + d * Hp * 4 * Hp,
-                                    split_k=split, ws_name=wsn, tile=self._side_tile)
+                                    split_k=split, ws_name=wsn)
 
                 def grads_W_hl(wsn, s=s, pa=rec.get('pa'), Hp=Hp, pdz_c=pdz_c, pgrad=pgrad):
                     if len(pa) == 1:
                         ops.gemm_hl(pa[0][1], pdz_c, self.grads, s.f_in_pad, 8 * Hp, rows,
-                                    c_off=s.oW, split_k=split, ws_name=wsn, tile=self._side_tile)
+                                    c_off=s.oW, split_k=split, ws_name=wsn)
                     else:
                         for d in range(2):
                             ops.gemm_hl(pa[d][1], pdz_c, self.grads, s.f_in_pad, 4 * Hp, rows,
                                         b_row=d * 4 * Hp, c_off=s.oW + d * 4 * Hp, ldc=8 * Hp,
-                                        split_k=split, ws_name=wsn, tile=self._side_tile)
+                                        split_k=split, ws_name=wsn)
                     buf, nrow, ncol, goff = pgrad
                     ops.colsum(buf, nrow, ncol, ncol, self._gview(goff, ncol), ws_name=wsn + '_cs')
 

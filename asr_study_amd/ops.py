@@ -55,19 +55,12 @@ def pad16(n):
 
 
 # --------------------------------------------------------------------------- GEMM
-_SPLIT_WGS = None
-
-
 def _resolve_split(split_k, M, N, K, tile=128):
     if split_k == 'auto':
-        # long-K / small-output GEMMs (dW, dU): split K until ~ASR_GEMM_SPLIT_WGS workgroups
-        # exist (tiles of `tile` x `tile`)
-        global _SPLIT_WGS
-        if _SPLIT_WGS is None:
-            import os
-            _SPLIT_WGS = int(os.environ.get('ASR_GEMM_SPLIT_WGS', '1024'))
+        # long-K / small-output GEMMs (dW, dU): split K until ~1024 workgroups' worth of
+        # `tile` x `tile` tiles exist (256 workgroups of the 256 x 256 kernel)
         tiles = ((int(M) + tile - 1) // tile) * ((int(N) + tile - 1) // tile)
-        split_k = max(1, min(64, (_SPLIT_WGS + tiles - 1) // tiles, int(K) // 256))
+        split_k = max(1, min(64, (1024 + tiles - 1) // tiles, int(K) // 256))
     return int(split_k)
 
 
@@ -159,8 +152,8 @@ def colsum(X, M, N, ldx, out, beta=0.0, x_off=0, ws_name='colsum'):
 
 
 # --------------------------------------------------------------------------- LSTM
-# LDS a recurrent workgroup reserves (asr_lstm_args.lds_reserve_kb; 0 = the library's 96 KB).
-# The engine sets 80 while its recurrences run on a CU-masked stream (two workgroups per CU).
+# LDS a recurrent workgroup reserves (asr_lstm_args.lds_reserve_kb; 0 = the library's 96 KB:
+# no GEMM workgroup fits beside it).
 LSTM_LDS_KB = 0
 
 

@@ -68,6 +68,19 @@ def launch_command(n, argv, port=None):
             str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
 
 
+def _rec_kernel_name(H, backward):
+    """The recurrent kernel asr_lstm_plan selects for the plain cell at hidden size H (csrc/lstm.hip,
+    make_plan): the wide kernels at 256 / 512, the any-H ones otherwise."""
+    exact = os.environ.get('ASR_LSTM_PREC', '1') == '0'
+    if H not in (256, 512):
+        return 'lstm_bwd_kernel_h' if backward else 'lstm_fwd_kernel_h'
+    if not backward:
+        return 'lstm_fwd_kernel_x<%d, %s>' % (H // 128, 'true' if exact else 'false')
+    if exact or H == 512:
+        return 'lstm_bwd_kernel_c<%d, %s> (two-dimensional split)' % (H // 256, 'true' if exact else 'false')
+    return 'lstm_bwd_kernel_x<%d>' % (H // 64)
+
+
 def _pmc_traffic(config):
     """HBM bytes per LAYER of the recurrent kernels from the committed rocprofv3 PMC passes
     (FETCH_SIZE x2 + WRITE_SIZE, per-launch average x launches per layer):
@@ -624,9 +637,12 @@ def main():
                     'algorithmic_tflop_per_step': round(fl / args.steps / 1e12, 3),
                     'note': 'achieved = executed MFMA flop/s (split-fp16: 3 fp16 MFMAs per fp32 '
                             'product) summed over the launches, vs the dense fp16 MFMA peak at '
-                            '2.4 GHz (the chip sustains ~1.95 GHz under this load: the pipes '
-                            'are ~51 % busy, profiles/r2g_pmc_gemm_hl.md); event intervals of '
-                            'side-stream launches include contention with the recurrences'}
+                            '2.4 GHz.  The kernel runs at the 1400 W package power cap: the chip '
+                            'holds 1.95-2.0 GHz under it (1.75-1.8 with 32x32x16 MFMAs, which is '
+                            'why the tile is built from 16x16x32), where pure 16x16x32 MFMAs on '
+                            'random operands sustain 2.0 PF/s (tools/clock_probe.py, '
+                            'tools/micro/mfma_power.hip, DESIGN.md 6); PMC: MFMA pipes 58 % busy '
+                            '(profiles/r3z_pmc_step_cfg3.md)'}
         line = {
             'metric': 'audio-seconds/sec trained (MFCC+BiLSTM+CTC)',
             'value': round(value, 1), 'unit': 'audio-seconds/s', 'n_gpus': world,
@@ -643,10 +659,10 @@ def main():
                        'global_batch': world * N, 'utterance_seconds': 10.0, 'frames': T,
                        'dropout': args.dropout, 'optimizer': 'adam(clipnorm=400)',
                        'parallelism': 'dp%d' % world, 'params': model.count_params()},
-            'roofline': roof('bwd', bwd_t, 'lstm_bwd_kernel (persistent BPTT of one BiLSTM '
-                                            'layer, both directions)'),
-            'roofline_lstm_fwd': roof('fwd', fwd_t, 'lstm_fwd_kernel (persistent forward '
-                                                     'recurrence of one BiLSTM layer)'),
+            'roofline': roof('bwd', bwd_t, '%s (persistent BPTT of one BiLSTM layer, both '
+                                            'directions)' % _rec_kernel_name(H, True)),
+            'roofline_lstm_fwd': roof('fwd', fwd_t, '%s (persistent forward recurrence of one '
+                                                     'BiLSTM layer)' % _rec_kernel_name(H, False)),
         }
         line.update(extra)
         line['allreduce_model']['ring_share_of_step'] = round(

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 final evidence: kernel stats + HBM traffic of the cfg3 bench, the in-step PMC groups.
-# Usage (repo root, on the box): bash tools/r3_final_prof.sh <tag>
+# Usage (repo root, on the box): bash tools/prof_final.sh <tag>
 tag=${1:-r3z}
 bash tools/prof_round3.sh $tag > gpurun_out/${tag}_prof.log 2>&1
 python tools/summarize_prof.py gpurun_out/$tag/prof bench gpurun_out/$tag/kernel_stats.md "cfg3 bench, round 3 (final)" > /dev/null 2> gpurun_out/$tag/summ.err
