@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libasr_hip.so')
-SOURCES = ['capi.cpp', 'ctc.hip', 'beam.hip', 'frontend.hip', 'gemm.hip', 'lstm.hip', 'lstm_ln.hip',
+SOURCES = ['capi.cpp', 'ctc.hip', 'beam.hip', 'frontend.hip', 'gemm.hip', 'lstm.hip', 'lstm_fwd.hip', 'lstm_bwd.hip', 'lstm_ln.hip',
            'optim.hip', 'random.hip', 'decode_host.cpp', 'comm.cpp', 'roles.cpp']
 ARCH = 'gfx950'
 
@@ -21,6 +21,7 @@ STAMP = LIB + '.srchash'
 def _deps():
     return [os.path.join(CSRC, s) for s in SOURCES] + [
         os.path.join(CSRC, 'common.h'),
+        os.path.join(CSRC, 'lstm_common.h'),
         os.path.join(os.path.dirname(HERE), 'include', 'asr_hip.h')]
 
 
