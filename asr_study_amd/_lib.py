@@ -55,7 +55,7 @@ class GemmHlArgs(C.Structure):
                 ('alpha', C.c_float), ('beta', C.c_float),
                 ('bias', void_p),
                 ('c_scale', void_p), ('c_scale_period', C.c_int), ('c_scale_ld', C.c_int),
-                ('split_k', C.c_int), ('tile', C.c_int)]
+                ('split_k', C.c_int), ('tile', C.c_int), ('k_major', C.c_int)]
 
 
 class LstmArgs(C.Structure):

@@ -452,17 +452,17 @@ class Model(object):
                         r=self._planes('Wn%d' % si, s.f_in_pad, 8 * s.Hp),
                         c=self._planes('Wt%d' % si, 8 * s.Hp, s.f_in_pad))
 
-    def _pack_input(self, si, s, a, BW, rows, n_pad, amax, need_c):
-        """The stage's input slab (rows, f_in_pad) [x B_W of each direction] -> planes with the
-        features as reduction index (x@W) and, for training, with the rows as reduction index
-        (dW = x^T dz).  One entry per direction when masks are on, else one shared entry."""
+    def _pack_input(self, si, s, a, BW, rows, n_pad, amax):
+        """The stage's input slab (rows, f_in_pad) [x B_W of each direction] -> (rows, f_in_pad)
+        planes: x@W reduces over their columns, dW = x^T dz over their rows (asr_gemm_hl's
+        k_major form reads them transposed out of LDS -- no second orientation is packed).
+        One entry per direction when masks are on, else one shared entry."""
         out = []
         for d in range(2 if BW is not None else 1):
             r = self._planes('ar%d_%d' % (si, d), rows, s.f_in_pad)
-            c = self._planes('ac%d_%d' % (si, d), s.f_in_pad, rows) if need_c else None
             ops.pack_hl(a, rows, s.f_in_pad, mask=None if BW is None else BW[d],
-                        mask_period=n_pad, absmax=amax, r=r, c=c)
-            out.append((r, c))
+                        mask_period=n_pad, absmax=amax, r=r)
+            out.append(r)
         return out
 
     def _gate_gemm_hl(self, s, si, pa, zx, rows):
@@ -472,10 +472,10 @@ class Model(object):
         Wt = self._planes('Wt%d' % si, 8 * Hp, s.f_in_pad)
         bias = self._view(s.ob, 8 * Hp)
         if len(pa) == 1:
-            ops.gemm_hl(pa[0][0], Wt, zx, rows, 8 * Hp, s.f_in_pad, bias=bias)
+            ops.gemm_hl(pa[0], Wt, zx, rows, 8 * Hp, s.f_in_pad, bias=bias)
             return
         for d in range(2):
-            ops.gemm_hl(pa[d][0], Wt, zx, rows, 4 * Hp, s.f_in_pad, b_row=d * 4 * Hp,
+            ops.gemm_hl(pa[d], Wt, zx, rows, 4 * Hp, s.f_in_pad, b_row=d * 4 * Hp,
                         c_off=d * 4 * Hp, ldc=8 * Hp, bias=bias[d * 4 * Hp:(d + 1) * 4 * Hp])
 
     # ------------------------------------------------------------------ forward
@@ -569,7 +569,7 @@ class Model(object):
                     prev = self.stages[si - 1] if si > 0 else None
                     amax = self._const_one() if (prev is not None and prev.kind == 'bilstm') \
                         else ops.absmax(a, self._buf('aamax%d' % si, (1,)))
-                    rec['pa'] = self._pack_input(si, s, a, BW, rows, n_pad, amax, need_grad)
+                    rec['pa'] = self._pack_input(si, s, a, BW, rows, n_pad, amax)
                     self._gate_gemm_hl(s, si, rec['pa'], zx, rows)
                 elif inner_done is None:
                     self._gate_gemm(a, s, zx, BW, 0, rows, n_pad)
@@ -865,40 +865,40 @@ class Model(object):
                     flush_side()    # previous layer's dW/dU/db now overlap this BPTT
                 y = rec['y']
                 hl = self._stage_packed(s)
-                pdz_r = pdz_c = None
+                pdz_r = None
                 if hl:
-                    # dz -> planes, once: gate columns as reduction index for dX, rows for the
-                    # weight gradients (the scale is the BPTT kernel's own max|dz|)
-                    pdz_r = None if first else self._planes('dzr%d' % par, rows, 8 * Hp)
-                    pdz_c = self._planes('dzc%d' % par, 8 * Hp, rows)
-                    ops.pack_hl(dz, rows, 8 * Hp, absmax=zmx, r=pdz_r, c=pdz_c)
+                    # dz -> (rows, 8H) planes, once: dX reduces over their gate columns, the
+                    # weight gradients over their rows (k_major); the scale is the BPTT kernel's
+                    # own max|dz|
+                    pdz_r = self._planes('dzr%d' % par, rows, 8 * Hp)
+                    ops.pack_hl(dz, rows, 8 * Hp, absmax=zmx, r=pdz_r)
 
-                def grads_U_hl(wsn, s=s, y=y, BU=BU, Hp=Hp, pdz_c=pdz_c):
-                    # dU[d] = (h_prev (.) B_U)^T dz[d] from planes with the rows as reduction
-                    # index; h_prev = y one frame earlier in the direction's processing order
+                def grads_U_hl(wsn, s=s, y=y, BU=BU, Hp=Hp, pdz_r=pdz_r):
+                    # dU[d] = (h_prev (.) B_U)^T dz[d], reduced over the plane rows; h_prev = y
+                    # one frame earlier in the direction's processing order = a row offset
                     kk = (T - 1) * n_pad
                     for d in range(2):
                         if kk <= 0:
                             self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
                             continue
-                        yu = self._planes('yu%d' % d, Hp, rows)
+                        yu = self._planes('yu%d' % d, rows, Hp)
                         ops.pack_hl(y, rows, Hp, ld=2 * Hp, src_off=d * Hp,
                                     mask=None if BU is None else BU[d], mask_period=n_pad,
-                                    absmax=self._const_one(), c=yu)
-                        ops.gemm_hl(yu, pdz_c, self.grads, Hp, 4 * Hp, kk,
-                                    a_k=0 if d == 0 else n_pad, b_row=d * 4 * Hp,
-                                    b_k=n_pad if d == 0 else 0, c_off=s.oU + d * Hp * 4 * Hp,
-                                    split_k=split, ws_name=wsn)
+                                    absmax=self._const_one(), r=yu)
+                        ops.gemm_hl(yu, pdz_r, self.grads, Hp, 4 * Hp, kk,
+                                    a_row=0 if d == 0 else n_pad, b_k=d * 4 * Hp,
+                                    b_row=n_pad if d == 0 else 0, c_off=s.oU + d * Hp * 4 * Hp,
+                                    split_k=split, ws_name=wsn, k_major=True)
 
-                def grads_W_hl(wsn, s=s, pa=rec.get('pa'), Hp=Hp, pdz_c=pdz_c, pgrad=pgrad):
+                def grads_W_hl(wsn, s=s, pa=rec.get('pa'), Hp=Hp, pdz_r=pdz_r, pgrad=pgrad):
                     if len(pa) == 1:
-                        ops.gemm_hl(pa[0][1], pdz_c, self.grads, s.f_in_pad, 8 * Hp, rows,
-                                    c_off=s.oW, split_k=split, ws_name=wsn)
+                        ops.gemm_hl(pa[0], pdz_r, self.grads, s.f_in_pad, 8 * Hp, rows,
+                                    c_off=s.oW, split_k=split, ws_name=wsn, k_major=True)
                     else:
                         for d in range(2):
-                            ops.gemm_hl(pa[d][1], pdz_c, self.grads, s.f_in_pad, 4 * Hp, rows,
-                                        b_row=d * 4 * Hp, c_off=s.oW + d * 4 * Hp, ldc=8 * Hp,
-                                        split_k=split, ws_name=wsn)
+                            ops.gemm_hl(pa[d], pdz_r, self.grads, s.f_in_pad, 4 * Hp, rows,
+                                        b_k=d * 4 * Hp, c_off=s.oW + d * 4 * Hp, ldc=8 * Hp,
+                                        split_k=split, ws_name=wsn, k_major=True)
                     buf, nrow, ncol, goff = pgrad
                     ops.colsum(buf, nrow, ncol, ncol, self._gview(goff, ncol), ws_name=wsn + '_cs')
 

@@ -964,6 +964,77 @@ struct HlLoaderX {
   }
 };
 
+// K-MAJOR operands (asr_gemm_hl_args.k_major): the weight gradients x^T dz and h^T dz reduce over
+// the ROWS of their operands, i.e. they can read the same (rows, cols) planes as x@W and
+// dz@W^T if the fragments are transposed on the way out of LDS -- ds_read_b64_tr_b16 -- and the
+// second orientation of x, y and dz is never packed (a third of the pack passes' bytes).
+// A slab is 32 plane rows (reduction indices) x TM2 columns: per row TM2 / 16 groups of
+// (16 hi, 16 lo) = 4 TM2 contiguous bytes; a wave's load instruction reads one whole row.
+// LDS image per operand: one SUBTILE per (column group, plane): [32 k][16 columns] halfs,
+// 32-byte rows, 1 KB, the layout ds_read_b64_tr_b16 reads conflict-free (guide T10): lane
+// l = 16 g + c of a read at byte 8 l receives column c of rows 4 g .. 4 g + 3.  Two reads (rows
+// 0..15, rows 16..31) give a lane the reduction indices {4 g .., 16 + 4 g ..}: a permutation of
+// the MFMA's k order that both operands share, so the products are unchanged.  Subtiles are
+// 1056 bytes apart: the 8 lanes of a staging ds_write_b128 group hold 4 subtiles x 2 halves of
+// one row, and 32-byte steps spread them over all banks.
+constexpr int kSubtile = 1056;                       // bytes
+template <int NT>
+struct HlLoaderT {
+  static constexpr int CPR = NT / 8;                 // 16-byte chunks per slab row (tile / 4)
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned off;            // bytes: (first row + t / CPR, tile's first column group) + 16 (t % CPR)
+  unsigned row_step;       // bytes between the thread's consecutive chunks: 8 rows
+  unsigned slab_step;      // bytes per slab: 32 rows
+  int rows_left;           // reduction rows from the thread's first one on (slab 0)
+  __device__ __forceinline__ void init(const HlSrc& s, int col0, int kb, int ke) {
+    const int tid = threadIdx.x;
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.p), 0, s.extent, 0x00020000);
+    const unsigned pitch = (unsigned)s.ld * 4u;      // bytes per plane row (hi + lo)
+    const int r = tid / CPR, c = tid % CPR;
+    rows_left = ke - kb - r;
+    // (column groups past the operand's M / N extent: out of range -> zeros; the last group
+    // may hold columns past it, which feed only output rows / columns that are never stored)
+    const bool col_ok = col0 + 16 * (c >> 2) < ((s.rows + 15) & ~15);
+    off = col_ok ? (unsigned)(kb + r) * pitch + (unsigned)col0 * 4u + 16u * c : kOob;
+    row_step = 8u * pitch;
+    slab_step = 32u * pitch;
+  }
+  __device__ __forceinline__ void offsets(int kt, unsigned (&o)[4]) const {
+    const unsigned ok = off == kOob ? kOob : off + (unsigned)kt * slab_step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = kt * HBK + 8 * i < rows_left ? ok : kOob;
+  }
+  __device__ __forceinline__ void issue(const unsigned (&o)[4], u32x4g (&v)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[i], i * row_step, 0);
+  }
+  __device__ __forceinline__ void load(int kt, u32x4g (&v)[4]) const {
+    unsigned o[4];
+    offsets(kt, o);
+    issue(o, v);
+  }
+  // chunk c of row r: column group c >> 2, plane (c >> 1) & 1 -> subtile c >> 1, its half c & 1
+  __device__ __forceinline__ static void store(const u32x4g (&v)[4], char* image) {
+    const int tid = threadIdx.x;
+    const int r = tid / CPR, c = tid % CPR;
+    char* dst = image + (c >> 1) * kSubtile + r * 32 + (c & 1) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4g*>(dst + i * 256) = v[i];
+  }
+  // the 16 (columns of group `grp`) x 32 (k) fragment of one plane as the MFMA wants it
+  __device__ __forceinline__ static hx8 fragment(const char* image, int grp, int plane, int lane) {
+    typedef short s4 __attribute__((__vector_size__(4 * sizeof(short))));
+    const char* q = image + (grp * 2 + plane) * kSubtile + lane * 8;
+    const s4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s4*)(q));
+    const s4 t2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s4*)(q + 512));
+    const hx4 a = __builtin_bit_cast(hx4, t1), b = __builtin_bit_cast(hx4, t2);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+};
+
 // WN waves across the columns (2 rows of waves); a wave owns 32 MI x 32 NJ of the tile as
 // RB x CB = 2 MI x 2 NJ MFMA tiles of 16 x 16: the square tile is 64 MI = 32 NJ WN wide and
 // every thread stages four 16-byte chunks per operand.
@@ -981,7 +1052,7 @@ struct HlLoaderX {
 __device__ int g_hl_prof_on = 0;
 __device__ long long g_hl_prof[8][8];
 
-template <int WN, int MI, int NJ>
+template <int WN, int MI, int NJ, bool KM>
 __global__ void __launch_bounds__(128 * WN)
 gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int splits,
                 Epilogue ep, const float* __restrict__ a_scale,
@@ -989,8 +1060,13 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
   constexpr int NT = 128 * WN, TM2 = 64 * MI, TN2 = 32 * NJ * WN;
   constexpr int RB = 2 * MI, CB = 2 * NJ;           // 16 x 16 tiles per wave: rows x columns
   static_assert(TM2 == TN2 && TM2 * 8 == 4 * NT, "square tile, four chunks per thread and operand");
-  using Loader = HlLoaderX<NT>;
+  // KM: the operands are K-major planes (rows = reduction index), HlLoaderT; else HlLoaderX
+  using Loader = std::conditional_t<KM, HlLoaderT<NT>, HlLoaderX<NT>>;
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
+  constexpr int kOpBytes = (TM2 / 16) * 2 * kSubtile;          // KM: one operand's slab image
+  auto opimg = [&](int buf, int which) {
+    return reinterpret_cast<char*>(hsm) + (size_t)(buf * 2 + which) * kOpBytes;
+  };
   // halfs per plane: + 64 bytes, so that a row's hi and lo chunks (one 8-lane group of the
   // staging ds_write_b128) fall into different banks
   constexpr int kPlane = TM2 * 32 + 32;
@@ -1035,8 +1111,13 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
   const int nk = (k_end - k_begin + HBK - 1) / HBK;
   la.load(0, av);
   lb.load(0, bv);
-  Loader::store(av, plane(0, 0), plane(0, 1));
-  Loader::store(bv, plane(0, 2), plane(0, 3));
+  if constexpr (KM) {
+    Loader::store(av, opimg(0, 0));
+    Loader::store(bv, opimg(0, 1));
+  } else {
+    Loader::store(av, plane(0, 0), plane(0, 1));
+    Loader::store(bv, plane(0, 2), plane(0, 3));
+  }
   la.load(1, av);
   lb.load(1, bv);
   __syncthreads();
@@ -1062,6 +1143,20 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
     hx8 fah[MI], fal[MI], fbh[CB], fbl[CB];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
+      if constexpr (KM) {
+        if (hf == 0) {
+#pragma unroll
+          for (int j = 0; j < CB; ++j) {
+            fbh[j] = Loader::fragment(opimg(cur, 1), wn * CB + j, 0, lane);
+            fbl[j] = Loader::fragment(opimg(cur, 1), wn * CB + j, 1, lane);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          fah[i] = Loader::fragment(opimg(cur, 0), wm * RB + hf * MI + i, 0, lane);
+          fal[i] = Loader::fragment(opimg(cur, 0), wm * RB + hf * MI + i, 1, lane);
+        }
+      } else {
       if (hf == 0) {
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
@@ -1075,6 +1170,7 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
         const int slot = hl256_slot(wm * (32 * MI) + (hf * MI + i) * 16 + frow, fk);
         fah[i] = *reinterpret_cast<const hx8*>(Ah + slot);
         fal[i] = *reinterpret_cast<const hx8*>(Al + slot);
+      }
       }
       unsigned oa[4], ob[4];
       if (hf == 0) {
@@ -1094,8 +1190,13 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
         // per MFMA, ~4 of issue): the 8 LDS writes of slab kt+1 first -- each frees its
         // registers -- then the 8 loads of slab kt+2 into them; the read phases stay bare.
         // Past the last slab every offset is out of range: those loads return zeros, unused.
-        Loader::store(av, plane(nxt, 0), plane(nxt, 1));
-        Loader::store(bv, plane(nxt, 2), plane(nxt, 3));
+        if constexpr (KM) {
+          Loader::store(av, opimg(nxt, 0));
+          Loader::store(bv, opimg(nxt, 1));
+        } else {
+          Loader::store(av, plane(nxt, 0), plane(nxt, 1));
+          Loader::store(bv, plane(nxt, 2), plane(nxt, 3));
+        }
         la.issue(oa, av);
         lb.issue(ob, bv);
       }
@@ -1543,16 +1644,24 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
                            asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ASR_CHECK_ARG(a && a->a_hl && a->b_hl && a->C, "gemm_hl: null pointer");
-  ASR_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 8 == 0,
+  ASR_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && (a->k_major || a->K % 8 == 0),
                 "gemm_hl: bad shape %d %d %d (K must be a multiple of 8)", a->M, a->N, a->K);
+  const bool km = a->k_major != 0;
+  if (km)
+    ASR_CHECK_ARG(a->lda >= a->M && a->ldb >= a->N && a->lda % 16 == 0 && a->ldb % 16 == 0 &&
+                  a->ldc >= a->N, "gemm_hl (k_major): bad leading dimensions");
+  else
   ASR_CHECK_ARG(a->lda >= a->K && a->ldb >= a->K && a->lda % 8 == 0 && a->ldb % 8 == 0 &&
                 a->ldc >= a->N, "gemm_hl: bad leading dimensions");
   ASR_CHECK_ARG((reinterpret_cast<uintptr_t>(a->a_hl) & 63) == 0 &&
                 (reinterpret_cast<uintptr_t>(a->b_hl) & 63) == 0,
                 "gemm_hl: planes must start at a reduction group (64-byte aligned)");
   // bytes from the first row's first group to the end of the last row's last group
-  const size_t ext_a = ((size_t)(a->M - 1) * 2 * a->lda + (size_t)((a->K + 15) / 16) * 32) * 2;
-  const size_t ext_b = ((size_t)(a->N - 1) * 2 * a->ldb + (size_t)((a->K + 15) / 16) * 32) * 2;
+  // (k_major: K plane rows of 4 ld bytes, the last one up to the operand's last column group)
+  const size_t ext_a = km ? ((size_t)(a->K - 1) * a->lda + (size_t)((a->M + 15) / 16) * 16) * 4
+                          : ((size_t)(a->M - 1) * 2 * a->lda + (size_t)((a->K + 15) / 16) * 32) * 2;
+  const size_t ext_b = km ? ((size_t)(a->K - 1) * a->ldb + (size_t)((a->N + 15) / 16) * 16) * 4
+                          : ((size_t)(a->N - 1) * 2 * a->ldb + (size_t)((a->K + 15) / 16) * 32) * 2;
   // (32-bit offsets; a tile's rows past the operand are computed before they are masked)
   const size_t lim = ((size_t)1 << 32) - ((size_t)1 << 20);
   ASR_CHECK_ARG(ext_a + (size_t)1024 * a->lda * 4 < lim && ext_b + (size_t)1024 * a->ldb * 4 < lim,
@@ -1580,21 +1689,39 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
   // (256 threads, 64 KB; asr_gemm_hl_args.tile = 128 or ASR_GEMM_HL_TILE=128 force it)
   static const int tile_env = [] { const char* v = getenv("ASR_GEMM_HL_TILE"); return v ? atoi(v) : 256; }();
   if (tile_env >= 256 && a->tile != 128 && a->M >= 256 && a->N >= 256) {
-    const size_t shm2 = (size_t)2 * 4 * (256 * 32 + 32) * sizeof(_Float16);
-    static bool attr2_done = false;
-    if (!attr2_done) {
-      ASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hlx_kernel<4, 4, 2>,
+    const size_t shm2 = km ? (size_t)2 * 2 * (256 / 16) * 2 * kSubtile
+                           : (size_t)2 * 4 * (256 * 32 + 32) * sizeof(_Float16);
+    static bool attr2_done[2] = {false, false};
+    if (!attr2_done[km]) {
+      ASR_CHECK_HIP(hipFuncSetAttribute(km ? (const void*)gemm_hlx_kernel<4, 4, 2, true>
+                                           : (const void*)gemm_hlx_kernel<4, 4, 2, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
-      attr2_done = true;
+      attr2_done[km] = true;
     }
     const int total = ((a->M + 255) / 256) * ((a->N + 255) / 256) * splits;
-    hipLaunchKernelGGL((gemm_hlx_kernel<4, 4, 2>), dim3(total), dim3(512), shm2, stream, A, B,
-                       a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
+    if (km)
+      hipLaunchKernelGGL((gemm_hlx_kernel<4, 4, 2, true>), dim3(total), dim3(512), shm2, stream, A,
+                         B, a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
+    else
+      hipLaunchKernelGGL((gemm_hlx_kernel<4, 4, 2, false>), dim3(total), dim3(512), shm2, stream, A,
+                         B, a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
   } else {
-    const size_t shm1 = (size_t)2 * 4 * (128 * 32 + 32) * sizeof(_Float16);
+    const size_t shm1 = km ? (size_t)2 * 2 * (128 / 16) * 2 * kSubtile
+                           : (size_t)2 * 4 * (128 * 32 + 32) * sizeof(_Float16);
     const int total = ((a->M + 127) / 128) * ((a->N + 127) / 128) * splits;
-    hipLaunchKernelGGL((gemm_hlx_kernel<2, 2, 2>), dim3(total), dim3(256), shm1, stream, A, B,
-                       a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
+    if (km) {
+      static bool attr1_done = false;
+      if (!attr1_done) {
+        ASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hlx_kernel<2, 2, 2, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm1));
+        attr1_done = true;
+      }
+      hipLaunchKernelGGL((gemm_hlx_kernel<2, 2, 2, true>), dim3(total), dim3(256), shm1, stream, A,
+                         B, a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
+    } else {
+      hipLaunchKernelGGL((gemm_hlx_kernel<2, 2, 2, false>), dim3(total), dim3(256), shm1, stream, A,
+                         B, a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
+    }
   }
   ASR_CHECK_LAUNCH();
   if (splits > 1) {

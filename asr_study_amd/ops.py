@@ -591,10 +591,12 @@ def pack_hl(src, rows, cols, ld=None, src_off=0, mask=None, mask_period=0, absma
 
 def gemm_hl(A, B, Cm, M, N, K, a_row=0, a_k=0, b_row=0, b_k=0, c_off=0, ldc=None, alpha=1.0,
             beta=0.0, bias=None, c_scale=None, c_scale_period=0, split_k=0, ws_name='gemm',
-            tile=0):
+            tile=0, k_major=False):
     """C[M,N] (float32 storage Cm, element offset c_off) = alpha * A @ B^T (+bias)(*c_scale)
     + beta*C from packed planes: A rows [a_row, a_row+M), reduction range [a_k, a_k+K) of its
-    planes; B rows [b_row, b_row+N), range [b_k, b_k+K)."""
+    planes; B rows [b_row, b_row+N), range [b_k, b_k+K).
+    k_major: C = alpha * A^T @ B from planes whose ROWS are the reduction index: A plane rows
+    [a_row, a_row+K), columns [a_k, a_k+M); B rows [b_row, b_row+K), columns [b_k, b_k+N)."""
     lib = L.load()
     g = L.GemmHlArgs()
     g.M, g.N, g.K = int(M), int(N), int(K)
@@ -610,6 +612,7 @@ def gemm_hl(A, B, Cm, M, N, K, a_row=0, a_k=0, b_row=0, b_k=0, c_off=0, ldc=None
     g.c_scale_ld = int(c_scale.shape[-1]) if c_scale is not None else 0
     g.split_k = _resolve_split(split_k, M, N, K)
     g.tile = int(tile)
+    g.k_major = 1 if k_major else 0
     nbytes = lib.asr_gemm_hl_workspace_bytes(C.byref(g))
     ws = WS.get(ws_name, nbytes, Cm.device) if nbytes else None
     L.check(lib.asr_gemm_hl(C.byref(g), _ptr(ws), nbytes, _stream()), 'asr_gemm_hl')

@@ -184,6 +184,14 @@ typedef struct asr_gemm_hl_args {
                                                  /* 128 x 128 kernel: 4 waves, 80 KB    */
                                                  /* LDS, co-resident with a recurrent   */
                                                  /* workgroup that reserves no LDS      */
+  int k_major;                                   /* != 0: C = A^T B from planes whose   */
+                                                 /* ROWS are the reduction index: a_hl   */
+                                                 /* (K rows, lda >= M columns), b_hl (K  */
+                                                 /* rows, ldb >= N columns) -- x^T dz,   */
+                                                 /* h^T dz on the planes x@W / dz@W^T    */
+                                                 /* use (no second orientation packed);  */
+                                                 /* a sub-matrix = pointer to (first row,*/
+                                                 /* first column group of 16)            */
 } asr_gemm_hl_args;
 size_t asr_gemm_hl_workspace_bytes(const asr_gemm_hl_args* a);
 int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws_bytes,

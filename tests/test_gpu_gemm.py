@@ -286,3 +286,35 @@ def test_gemm_hl_sub_views_and_k_offsets():
         want = ys.T @ zs
         assert report('gemm_hl dU d=%d' % d, out.cpu().numpy(), want) < \
             2e-6 * np.abs(y).max() * np.abs(dz).max() * K
+
+
+@pytest.mark.parametrize('M,N,K,sk,tile', [(300, 200, 64, 0, 0), (128, 128, 32, 0, 0), (260, 132, 41, 0, 0),
+                                           (700, 512, 160, 0, 0), (1024, 768, 2048, 4, 0),
+                                           (80, 1024, 999 * 16, 0, 0), (512, 96, 703, 3, 0),
+                                           (1024, 2048, 4000, 'auto', 0), (700, 512, 160, 0, 128)])
+def test_gemm_hl_k_major_matches_float64(M, N, K, sk, tile):
+    """asr_gemm_hl with k_major: C = A^T B from the (rows = reduction index) planes that x@W and
+    dz@W^T use, fragments transposed out of LDS by ds_read_b64_tr_b16 -- what the weight gradients
+    x^T dz / h^T dz run on.  Sub-matrices by plane-row and column-group offsets (the one-frame
+    shift of dU, one direction's gate columns of dz), any K (row tail masked), split-K, both
+    tiles; bias / alpha / beta as in the row-major form."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    r0, ca, cb = 5, 32, 48                      # plane-row offset, column offsets (groups of 16)
+    A = rs.randn(K + r0 + 3, M + ca + 16).astype(np.float32)
+    B = (rs.randn(K + r0 + 3, N + cb + 32) * 0.05).astype(np.float32)
+    C0 = rs.randn(M, N).astype(np.float32)
+    pa = ops.HlPlanes(A.shape[0], A.shape[1], 'cuda:0')
+    pb = ops.HlPlanes(B.shape[0], B.shape[1], 'cuda:0')
+    Ad, Bd = to_dev(A), to_dev(B)
+    ops.pack_hl(Ad, A.shape[0], A.shape[1], absmax=ops.absmax(Ad), r=pa)
+    ops.pack_hl(Bd, B.shape[0], B.shape[1], absmax=ops.absmax(Bd), r=pb)
+    Cd = to_dev(C0)
+    ops.gemm_hl(pa, pb, Cd, M, N, K, a_row=r0, a_k=ca, b_row=r0 + 2, b_k=cb, alpha=0.75, beta=0.5,
+                split_k=sk, tile=tile, k_major=True)
+    torch.cuda.synchronize()
+    As = A[r0:r0 + K, ca:ca + M].astype(np.float64)
+    Bs = B[r0 + 2:r0 + 2 + K, cb:cb + N].astype(np.float64)
+    want = 0.75 * (As.T @ Bs) + 0.5 * C0
+    err = report('gemm_hl k_major %dx%dx%d sk=%s tile=%d' % (M, N, K, sk, tile), Cd.cpu().numpy(), want)
+    assert err < 2e-6 * np.abs(A).max() * np.abs(B).max() * K + 2e-5

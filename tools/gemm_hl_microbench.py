@@ -50,5 +50,10 @@ for name, T, n_pad, H in (('cfg3', 999, 64, 512), ('cfg2', 999, 32, 256)):
                                  b_absmax=amz))
     print('%s dU   %dx%dx%d: packed %.3f ms %.1f TF/s | per-tile %.3f ms %.1f TF/s' % (
         name, H, 4 * H, rows, t, flu / t / 1e9, t0, flu / t0 / 1e9))
+    tk = timeit(lambda: ops.gemm_hl(xr, zr, dW, 2 * H, 8 * H, rows, split_k='auto', k_major=True))
+    print('%s dW   K-major planes (ds_read_b64_tr_b16): %.3f ms %.1f TF/s' % (name, tk, fl / tk / 1e9))
+    tk = timeit(lambda: ops.gemm_hl(xr, zr, dU, H, 4 * H, rows - n_pad, b_row=n_pad, split_k='auto',
+                                    k_major=True))
+    print('%s dU   K-major planes: %.3f ms %.1f TF/s' % (name, tk, flu / tk / 1e9))
     del x, W, dz, z, dx, xr, xc, zr, zc
     torch.cuda.empty_cache()
