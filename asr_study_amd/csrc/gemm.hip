@@ -819,12 +819,8 @@ __global__ void __launch_bounds__(256)
 pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
                const float* __restrict__ mask, int mask_period, int mask_ld,
                const float* __restrict__ absmax, float* __restrict__ scale_out,
-               _Float16* __restrict__ r_hl, int ldk_r, _Float16* __restrict__ c_hl, int ldk_c,
-               const float* __restrict__ mask2, _Float16* __restrict__ r2_hl) {
-  // (r2_hl: a second row-orientation output of the SAME source under a second mask -- the two
-  // directions of a Bidirectional layer see the input under their own dropout masks; the
-  // source is read once)
-  __shared__ __attribute__((aligned(16))) _Float16 rimg[64][128], cimg[64][128], rimg2[64][128];
+               _Float16* __restrict__ r_hl, int ldk_r, _Float16* __restrict__ c_hl, int ldk_c) {
+  __shared__ __attribute__((aligned(16))) _Float16 rimg[64][128], cimg[64][128];
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -845,30 +841,12 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] = q[e];
       }
-      if (r2_hl) {
-        const float* m = mask2 + (size_t)mod_period(r, mask_period) * mask_ld + c;
-        hx4 h2, l2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = (c + e < cols ? v[e] * m[e] : 0.f) * s;
-          const _Float16 h = (_Float16)x;
-          h2[e] = h;
-          l2[e] = (_Float16)(x - (float)h);
-        }
-        _Float16* q = &rimg2[4 * ty + i][(tx >> 2) * 32 + (tx & 3) * 4];
-        *reinterpret_cast<hx4*>(q) = h2;
-        *reinterpret_cast<hx4*>(q + 16) = l2;
-      }
       if (mask) {
         // (n_pad is a multiple of 16, not necessarily a power of two: 48, 80, 96 ...)
         const float* m = mask + (size_t)mod_period(r, mask_period) * mask_ld + c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] *= m[e];
       }
-    } else if (r2_hl) {
-      _Float16* q = &rimg2[4 * ty + i][(tx >> 2) * 32 + (tx & 3) * 4];
-      *reinterpret_cast<hx4*>(q) = hx4{0, 0, 0, 0};
-      *reinterpret_cast<hx4*>(q + 16) = hx4{0, 0, 0, 0};
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -905,9 +883,6 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
     if (r_hl && r0 + rr < rows && c0 + k0 < ldk_r)       // (columns in [cols, ldk_r): zeros)
       *reinterpret_cast<hx8*>(r_hl + hl_index(r0 + rr, c0 + k0, ldk_r) + (j & 3) * 8) =
           *reinterpret_cast<const hx8*>(&rimg[rr][j * 8]);
-    if (r2_hl && r0 + rr < rows && c0 + k0 < ldk_r)
-      *reinterpret_cast<hx8*>(r2_hl + hl_index(r0 + rr, c0 + k0, ldk_r) + (j & 3) * 8) =
-          *reinterpret_cast<const hx8*>(&rimg2[rr][j * 8]);
     if (c_hl && c0 + rr < cols && r0 + k0 < ldk_c) {     // (rows in [rows, ldk_c): zeros)
       const int f = ((2 * (rr >> 2)) & 14) | (rr >> 5);
       hx8 v = *reinterpret_cast<const hx8*>(&cimg[rr][(j ^ (f >> 1)) * 8]);
@@ -1630,15 +1605,11 @@ extern "C" int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream_) {
   if (a->mask)
     ASR_CHECK_ARG(a->mask_period > 0 && a->mask_ld >= a->cols,
                   "pack_hl: a mask needs a positive row period and mask_ld >= cols");
-  if (a->r2_hl)
-    ASR_CHECK_ARG(a->r_hl && a->mask && a->mask2 && aligned16(a->r2_hl),
-                  "pack_hl: the second row output needs the first one and both masks");
   dim3 grid((a->cols + 63) / 64, (a->rows + 63) / 64);
   hipLaunchKernelGGL(pack_hl_kernel, grid, dim3(256), 0, stream, a->src, a->rows, a->cols, a->ld,
                      a->mask, a->mask ? a->mask_period : 1, a->mask_ld, a->absmax, a->scale_out,
                      reinterpret_cast<_Float16*>(a->r_hl), a->ldk_r,
-                     reinterpret_cast<_Float16*>(a->c_hl), a->ldk_c, a->mask2,
-                     reinterpret_cast<_Float16*>(a->r2_hl));
+                     reinterpret_cast<_Float16*>(a->c_hl), a->ldk_c);
   ASR_CHECK_LAUNCH();
   return ASR_OK;
 }

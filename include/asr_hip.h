@@ -162,10 +162,6 @@ typedef struct asr_pack_args {
   float* scale_out;                              /* device float, or NULL             */
   void* r_hl; int ldk_r;                         /* (rows, 2 ldk_r) halfs, or NULL    */
   void* c_hl; int ldk_c;                         /* (cols, 2 ldk_c) halfs, or NULL    */
-  const float* mask2; void* r2_hl;               /* or NULL: a second (rows, 2 ldk_r) */
-                                                 /* output of the same source under   */
-                                                 /* mask2 (same period / ld): the two */
-                                                 /* directions' input dropout masks   */
 } asr_pack_args;
 int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream);
 /* Debug: arm (enable != 0) / read the K-loop phase profile of asr_gemm_hl's workgroup 0:      */

@@ -318,25 +318,3 @@ def test_gemm_hl_k_major_matches_float64(M, N, K, sk, tile):
     want = 0.75 * (As.T @ Bs) + 0.5 * C0
     err = report('gemm_hl k_major %dx%dx%d sk=%s tile=%d' % (M, N, K, sk, tile), Cd.cpu().numpy(), want)
     assert err < 2e-6 * np.abs(A).max() * np.abs(B).max() * K + 2e-5
-
-
-@pytest.mark.parametrize('rows,cols,period', [(999 * 16, 80, 16), (330, 64, 80), (257, 40, 48)])
-def test_pack_hl_two_masks_one_pass(rows, cols, period):
-    """asr_pack_args.mask2 / r2_hl: the second direction's planes of the same source under its
-    own dropout mask, written in the same pass: bit for bit what a second call writes."""
-    from asr_study_amd import ops
-    rs = np.random.RandomState(rows + cols)
-    src = (rs.randn(rows, cols) * 0.3).astype(np.float32)
-    m1 = ((rs.rand(period, cols) > 0.2) / 0.8).astype(np.float32)
-    m2 = ((rs.rand(period, cols) > 0.2) / 0.8).astype(np.float32)
-    sd, m1d, m2d = to_dev(src), to_dev(m1), to_dev(m2)
-    one = torch.ones(1, device='cuda:0')
-    a, b, b_ref = (ops.HlPlanes(rows, cols, 'cuda:0') for _ in range(3))
-    for t in (a, b, b_ref):
-        t.hl.fill_(7.0)
-    ops.pack_hl(sd, rows, cols, mask=m1d, mask_period=period, absmax=one, r=a, mask2=m2d, r2=b)
-    ops.pack_hl(sd, rows, cols, mask=m2d, mask_period=period, absmax=one, r=b_ref)
-    torch.cuda.synchronize()
-    hi, lo = _hl_ref(src * m1[np.arange(rows) % period], np.float32(a.scale.cpu().numpy()[0]))
-    assert np.array_equal(a.hi.cpu().numpy()[:, :cols], hi) and np.array_equal(a.lo.cpu().numpy()[:, :cols], lo)
-    assert torch.equal(b.hl, b_ref.hl) and float(b.scale.cpu()[0]) == float(a.scale.cpu()[0])
