@@ -820,7 +820,12 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
                const float* __restrict__ mask, int mask_period, int mask_ld,
                const float* __restrict__ absmax, float* __restrict__ scale_out,
                _Float16* __restrict__ r_hl, int ldk_r, _Float16* __restrict__ c_hl, int ldk_c) {
-  __shared__ __attribute__((aligned(16))) _Float16 rimg[64][128], cimg[64][128];
+  // one 16 KB image per output that is asked for (dynamic LDS: a row-only pack keeps 10
+  // workgroups on a CU)
+  extern __shared__ __attribute__((aligned(16))) _Float16 pack_lds[];
+  typedef _Float16 (*Image)[128];
+  Image rimg = reinterpret_cast<Image>(pack_lds);
+  Image cimg = reinterpret_cast<Image>(pack_lds + (r_hl ? 64 * 128 : 0));
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -1606,7 +1611,8 @@ extern "C" int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream_) {
     ASR_CHECK_ARG(a->mask_period > 0 && a->mask_ld >= a->cols,
                   "pack_hl: a mask needs a positive row period and mask_ld >= cols");
   dim3 grid((a->cols + 63) / 64, (a->rows + 63) / 64);
-  hipLaunchKernelGGL(pack_hl_kernel, grid, dim3(256), 0, stream, a->src, a->rows, a->cols, a->ld,
+  const size_t pack_shm = (size_t)((a->r_hl ? 1 : 0) + (a->c_hl ? 1 : 0)) * 64 * 128 * sizeof(_Float16);
+  hipLaunchKernelGGL(pack_hl_kernel, grid, dim3(256), pack_shm, stream, a->src, a->rows, a->cols, a->ld,
                      a->mask, a->mask ? a->mask_period : 1, a->mask_ld, a->absmax, a->scale_out,
                      reinterpret_cast<_Float16*>(a->r_hl), a->ldk_r,
                      reinterpret_cast<_Float16*>(a->c_hl), a->ldk_c);
