@@ -782,10 +782,12 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
 // split happens once per tensor: pack_hl_kernel writes two fp16 planes hi = fp16(x*s),
 // lo = fp16(x*s - hi) (s = the per-tensor power of two of pow2_scale; variational-dropout
 // masks are multiplied in BEFORE the split, in fp32, so the GEMM needs no mask path) with the
-// reduction index contiguous, in either or both orientations of the source:
-//   "r" planes (rows, ldk_r): K = the source's columns  (A of x@W, A of dz@W^T)
-//   "c" planes (cols, ldk_c): K = the source's rows     (both operands of the weight
-//                                                         gradients x^T dz and h^T dz)
+// source's columns ("r" planes: (rows, ldk_r)) or rows ("c" planes: (cols, ldk_c)) contiguous:
+//   x, y (.) B_U, dz: "r" planes only.  x@W and dz@W^T reduce over their columns (row-major
+//     form of the GEMM); the weight gradients x^T dz and h^T dz reduce over their ROWS and read
+//     the same planes transposed out of LDS (k_major form, HlLoaderT) -- the second
+//     orientation was a third of the pack passes' bytes;
+//   W: both ("c" = the B operand of x@W, "r" = the B operand of dz@W^T).
 // A plane row holds ldk reduction indices (ldk % 32 == 0, zero padded).  The two planes are ONE
 // array, interleaved in groups of 16 indices: a row is 2 ldk halfs,
 //   half [32 g, 32 g + 16)      = hi[16 g .. 16 g + 15]
@@ -795,12 +797,12 @@ gemm_f16x2_fast_kernel(FastSrc A, FastSrc B, int M, int N, int K, int k_per_spli
 // by which time the 32 KB L1 had long turned over: every line crossed L2 -> L1 twice.)  A
 // reduction offset is a multiple of 16 (a group).  gemm_hlx_kernel is then a
 // plain fp16 GEMM with three MFMAs per fragment pair and fp32 accumulation: 16-byte global
-// loads -> ds_write_b128 -> ds_read_b128 -> v_mfma_f32_32x32x16_f16, no VALU in the K loop
-// besides addresses.  Tile / LDS image / epilogue are those of the fast kernel.
+// loads -> ds_write_b128 -> ds_read_b128 (ds_read_b64_tr_b16 in the k_major form) ->
+// v_mfma_f32_16x16x32_f16, no VALU in the K loop besides addresses.
 struct HlSrc {
   const _Float16* p;      // interleaved planes, offset to (first row, first reduction group)
-  int ld;                 // reduction indices per row: a row is 2 ld halfs
-  int rows;               // MN extent
+  int ld;                 // plane columns per row: a row is 2 ld halfs (hi and lo)
+  int rows;               // MN extent (plane rows in the row-major form, columns in k_major)
   unsigned extent;        // bytes addressable from p
 };
 __device__ __forceinline__ size_t hl_index(int row, int k, int ld) {      // half index of hi
