@@ -136,6 +136,7 @@ SIGNATURES = {
     'asr_lstm_seq_bwd': (C.c_int, [C.POINTER(LstmArgs), void_p, C.c_size_t, void_p]),
     'asr_lstm_status': (C.c_int, [void_p, void_p]),
     'asr_lstm_fast_chains': (C.c_int, [void_p, void_p]),
+    'asr_lstm_trace': (C.c_int, [C.POINTER(C.c_longlong), C.c_size_t, void_p]),
     'asr_lstm_profile': (C.c_int, [void_p, void_p, C.POINTER(C.c_longlong)]),
     'asr_lstm_plan': (C.c_int, [C.POINTER(LstmArgs), C.c_int, c_int_p, c_int_p, c_int_p,
                                 c_int_p]),

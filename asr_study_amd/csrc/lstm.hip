@@ -245,6 +245,9 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
 }
 
 constexpr size_t kStatusBytes = 256;
+// debug timeline (ASR_LSTM_DBG & 128, asr_lstm_trace): 256 workgroups x 4 waves x 16 steps x 2
+constexpr size_t kTraceBytes = (size_t)256 * 4 * 16 * 2 * sizeof(long long);
+long long* g_trace = nullptr;
 
 // workspace preparation of a launch that starts a sequence: 16-byte words [0, n_zero) to 0,
 // [n_zero, n_total) to all ones, *absmax (optional) to 0
@@ -348,6 +351,13 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.xstride = fwd_xstride();
   // ASR_LSTM_SPIN_MS: bound of a persistent kernel's spins in milliseconds (default 600)
   p.spin = (long long)env_int("ASR_LSTM_SPIN_MS", 600) * 100000LL;
+  p.trace = nullptr;
+  p.trace_s0 = env_int("ASR_LSTM_TRACE_STEP", 500);
+  if (p.dbg & 128) {
+    if (!g_trace) ASR_CHECK_HIP(hipMalloc(&g_trace, kTraceBytes));
+    ASR_CHECK_HIP(hipMemsetAsync(g_trace, 0, kTraceBytes, stream));
+    p.trace = g_trace;
+  }
   const int steps_per_launch = stepwise ? 1 : (r_end - r_begin);
   for (int s0 = r_begin; s0 < r_end; s0 += steps_per_launch) {
     // the XCC table is rebuilt by every persistent launch (placement may differ)
@@ -423,6 +433,17 @@ extern "C" int asr_lstm_profile(const void* workspace, asr_stream_t stream_, lon
   ASR_CHECK_HIP(hipMemcpyAsync(out24, reinterpret_cast<const char*>(workspace) + kStickyBytes + 64,
                                24 * sizeof(long long), hipMemcpyDeviceToHost, stream));
   ASR_CHECK_HIP(hipStreamSynchronize(stream));
+  return ASR_OK;
+}
+
+// Debug: the hand-off timeline of the last launch made with ASR_LSTM_DBG & 128 (forward
+// kernel_x only): out[((block * 4 + wave) * 16 + step) * 2 + {0: data arrived, 1: published}]
+// in ticks of the 100 MHz clock, steps ASR_LSTM_TRACE_STEP .. + 15, block = blockIdx.
+extern "C" int asr_lstm_trace(long long* out, size_t n_words, asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ASR_CHECK_ARG(out && g_trace && n_words * sizeof(long long) <= kTraceBytes, "lstm_trace: no trace");
+  ASR_CHECK_HIP(hipStreamSynchronize(stream));
+  ASR_CHECK_HIP(hipMemcpy(out, g_trace, n_words * sizeof(long long), hipMemcpyDeviceToHost));
   return ASR_OK;
 }
 

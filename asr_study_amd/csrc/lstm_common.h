@@ -17,6 +17,8 @@ struct LstmParams {
   int poll;                // 1: persistent (poll tags); 0: one step per launch
   int allow_fast;          // may use the same-XCD transport
   int dbg;                 // ablation switches (ASR_LSTM_DBG), 0 in production
+  long long* trace;        // debug (ASR_LSTM_DBG & 128): [block][wave][16 steps][2] ticks of the
+  int trace_s0;            // 100 MHz clock at data arrival / publish, steps trace_s0 .. + 15
   int prepoll;             // 64-clock naps before a step's first poll (see gather_groups)
   int repoll;              // 64-clock naps between poll rounds
   int xstride;             // fwd: bytes between consecutive unit-group tiles in a slot

@@ -461,9 +461,13 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
   };
   auto load_groups = [&](int x, const __amdgpu_buffer_rsrc_t& rsrc) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
+    for (int i = 0; i < NL; ++i) {
+#ifdef GATHER_PART      // timing experiment: only every GATHER_PART-th group is gathered (wrong h)
+      if (i % GATHER_PART) { v[x][i] = v[x][i - i % GATHER_PART]; continue; }
+#endif
       v[x][i] = __builtin_amdgcn_raw_buffer_load_b128(
           rsrc, goff, (unsigned)((8 * (i >> 1) + (i & 1))) * gstep, FAST ? kNt : kSc1);
+    }
   };
   auto issue = [&](int x, int ss) {
     for (int i = 0; i < p.prepoll; ++i) __builtin_amdgcn_s_sleep(1);
@@ -515,6 +519,8 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     prof.stamp(0);
     await(x, s - 1, (unsigned)((s - 1) >> 1) & 1u);
     prof.stamp(1);
+    const bool tr = p.trace && lane == 0 && (unsigned)(s - p.trace_s0) < 16u;
+    if (tr) p.trace[(((size_t)blockIdx.x * 4 + w) * 16 + (s - p.trace_s0)) * 2] = wall_clock64();
     zx_next[x] = load_zx(x, s + 1);
     // two LDS buffers by step parity (the one barrier per step keeps the waves at most one
     // step apart)
@@ -576,6 +582,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     const f32x4* all = part + (size_t)buf * 4 * 4 * 64 + (size_t)w * 64 + lane;
     const f32x4 a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
     finish_step(x, s, a, zx4);
+    if (tr) p.trace[(((size_t)blockIdx.x * 4 + w) * 16 + (s - p.trace_s0)) * 2 + 1] = wall_clock64();
     prof.stamp(4);
     issue(x, s);                                   // this tile's h of step s, for step s + 1
     prof.stamp(5);

@@ -291,6 +291,9 @@ int asr_lstm_plan(const asr_lstm_args* a, int backward, int* k_split,
 /* Synchronises `stream`; number of chains of the last call on this workspace
  * that ran on the same-XCD (L2) transport (diagnostic), or a negative status. */
 int asr_lstm_fast_chains(const void* workspace, asr_stream_t stream);
+/* Debug: hand-off timeline of the last forward launch made under ASR_LSTM_DBG & 128:       */
+/* out[((block*4 + wave)*16 + step)*2 + {0 data arrived, 1 published}], 100 MHz ticks.      */
+int asr_lstm_trace(long long* out, size_t n_words, asr_stream_t stream);
 /* Debug (env ASR_LSTM_DBG & 32): per-phase shader-clock ticks of workgroup 0 of the
  * last call's first chain, summed over its steps: 4 waves x 6 phases {arithmetic
  * before the gather, waiting for it, arithmetic behind it, barrier, products +
