@@ -161,3 +161,28 @@ int main(void) {
     assert out['lstmln'] == [C.sizeof(LN), LN.cellp.offset, LN.dparams.offset]
     GG = _lib.GateGemmArgs
     assert out['gate'] == [C.sizeof(GG), GG.zx.offset, GG.dx_beta.offset, GG.precision.offset]
+
+
+def test_gemm_hl_argument_checks_need_no_gpu(lib):
+    """asr_gemm_hl rejects bad arguments before it touches the device: the two operand forms
+    have their own leading-dimension rules (row-major planes: ld >= K; k_major planes, whose
+    rows are the reduction index: ld >= M / N columns), planes start at a 64-byte group."""
+    import ctypes as C
+    g = L.GemmHlArgs()
+    buf = (C.c_char * 4096)()
+    base = (C.addressof(buf) + 63) & ~63
+    g.M, g.N, g.K = 64, 64, 128
+    g.a_hl, g.b_hl, g.C = base, base, base
+    g.lda, g.ldb, g.ldc = 64, 64, 64            # fine for k_major (>= M, N), too short for row-major
+    g.alpha = 1.0
+    g.k_major = 0
+    assert lib.asr_gemm_hl(C.byref(g), None, 0, None) != 0
+    assert b'leading' in lib.asr_last_error()
+    g.k_major = 1
+    g.lda = 48                                  # < M
+    assert lib.asr_gemm_hl(C.byref(g), None, 0, None) != 0
+    assert b'k_major' in lib.asr_last_error()
+    g.lda = 64
+    g.a_hl = base + 16                          # not at a reduction group
+    assert lib.asr_gemm_hl(C.byref(g), None, 0, None) != 0
+    assert b'64-byte' in lib.asr_last_error()
