@@ -143,3 +143,25 @@ def test_eval_mode_model_decodes_on_the_device(monkeypatch):
     labels = [rs.randint(0, C - 1, size=3).tolist() for _ in range(N)]
     out = model.test_on_batch([('slab', slab), labels, lens])
     assert np.isfinite(out).all()
+
+
+def test_ctc_utils_decode_beam_branch_runs_on_the_device(monkeypatch):
+    """core/ctc_utils.decode(is_greedy=False) (the reference's Lambda body, ctc_utils.py:8-52):
+    the device decoder by default, the host one under ASR_BEAM=host -- same label lists, and the
+    default never touches the host decoder."""
+    from asr_study_amd import ops
+    from asr_study_amd.core import ctc_utils
+    rs = np.random.RandomState(5)
+    T, N, C = 80, 5, 28
+    n_pad = ops.pad16(N)
+    slab = torch.from_numpy((rs.randn(T, n_pad, C) * 2).astype(np.float32)).cuda()
+    lens = np.array([80, 61, 80, 7, 33], np.int32)
+    monkeypatch.setenv('ASR_BEAM', 'host')
+    host = ctc_utils.decode((slab, lens), is_greedy=False, beam_width=100)
+    monkeypatch.delenv('ASR_BEAM')
+
+    def boom(*a, **k):
+        raise AssertionError('host decoder called')
+    monkeypatch.setattr(ops, 'ctc_beam_search_host', boom)
+    dev = ctc_utils.decode((slab, lens), is_greedy=False, beam_width=100)
+    assert dev == host and any(len(h) for h in host)
