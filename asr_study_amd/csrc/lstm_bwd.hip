@@ -1063,6 +1063,8 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       mfma_settle(am[OT - 1], a1[OT - 1], a2[OT - 1]);
       finish(OT - 1, am[OT - 1], a1[OT - 1], a2[OT - 1]);
     }
+    if (p.trace && lane == 0 && (unsigned)(s - p.trace_s0) < 16u)
+      p.trace[(((size_t)blockIdx.x * 4 + w) * 16 + (s - p.trace_s0)) * 2 + 1] = wall_clock64();
     prof.stamp(4);
     if (do_issue) issue(s);
   };
@@ -1074,6 +1076,8 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     prof.stamp(0);
     await(s - 1);
     prof.stamp(1);
+    if (p.trace && lane == 0 && (unsigned)(s - p.trace_s0) < 16u)
+      p.trace[(((size_t)blockIdx.x * 4 + w) * 16 + (s - p.trace_s0)) * 2] = wall_clock64();
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {                 // (the tag bit stays in: <= 1 ulp)

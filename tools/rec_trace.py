@@ -67,3 +67,41 @@ for ch in (0, 5):
     s = 7
     print('   step %d publish times by workgroup (ns after the first):' % s,
           (pub[:, :, s].max(axis=1) - pub[:, :, s].min()).round().astype(int).tolist())
+
+
+# ---- BPTT (two-dimensional split): workgroup cw = a + 8 b of a chain gathers the 8 partial tiles
+# of its output block a // 2 from the workgroups a'' + 8 (a // 2), a'' = 0..7
+dy = rnd(T, n_pad, 2 * H, scale=0.01)
+dz = torch.empty(T, n_pad, 2, 4 * H, device=dev)
+for _ in range(3):
+    ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H)
+torch.cuda.synchronize()
+os.environ['ASR_LSTM_DBG'] = '128'
+ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H)
+os.environ.pop('ASR_LSTM_DBG')
+_lib.check(_lib.load().asr_lstm_trace(buf, n, torch.cuda.current_stream().cuda_stream), 'asr_lstm_trace')
+tr = np.frombuffer(buf, dtype=np.int64).reshape(256, 4, 16, 2).astype(np.float64) * 10.0
+for ch in (0,):
+    sel = np.where(chain == ch)[0]
+    order = sel[np.argsort(wg[sel])]
+    arr, pub = tr[order, :, :, 0], tr[order, :, :, 1]
+    period = np.diff(pub.max(axis=(0, 1))[1:]).mean()
+    spread = (pub.max(axis=(0, 1)) - pub.min(axis=(0, 1)))[1:]
+    print('BPTT chain %d: step period %.0f ns; publish spread over the 32 workgroups: mean %.0f ns, worst %.0f'
+          % (ch, period, spread.mean(), spread.max()))
+    lags = []
+    for cw in range(32):
+        a_ = cw % 8
+        prod = [a2 + 8 * (a_ // 2) for a2 in range(8)]
+        lastpub = pub[prod].max(axis=(0, 1))
+        lags.append(arr[cw, :, 1:].max(axis=0) - lastpub[:-1])
+    lags = np.stack(lags)
+    print('   lag last needed publish -> arrival (last wave): mean %.0f ns, min %.0f, p50 %.0f, p90 %.0f, max %.0f'
+          % (lags.mean(), lags.min(), np.median(lags), np.percentile(lags, 90), lags.max()))
+    chainlen = pub[:, :, 1:].max(axis=1) - arr[:, :, 1:].max(axis=1)
+    print('   arrival of the last wave -> publish (the dependent chain): mean %.0f ns, min %.0f, max %.0f'
+          % (chainlen.mean(), chainlen.min(), chainlen.max()))
+    print('   last publisher per step (workgroup):', pub[:, :, 1:].max(axis=1).argmax(axis=0).tolist())
+    firstpub = pub.min(axis=(0, 1))
+    print('   per workgroup: publish after the chain\'s first publish of the same step (ns):')
+    print('     ', (pub[:, :, 1:].max(axis=1) - firstpub[None, 1:]).mean(axis=1).round().astype(int).tolist())
