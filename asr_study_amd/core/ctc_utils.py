@@ -3,8 +3,6 @@
 In the reference these are Lambda bodies wrapping tf.nn.ctc_loss /
 ctc_greedy_decoder / ctc_beam_search_decoder; here they call the HIP kernels (loss,
 gradient, greedy, device beam search) through the C ABI, on time-major logit slabs."""
-import os
-
 import numpy as np
 import torch
 
@@ -30,11 +28,8 @@ def decode(inputs, **kwargs):
         return [dec[n, :dlen[n]].tolist() for n in range(N)]
     width = int(kwargs.get('beam_width', 100))
     merge = bool(kwargs.get('merge_repeated', True))
-    # the device decoder (same strings as the host one, tests/test_gpu_beam.py) like
-    # engine.Model.predict_on_batch: the logits stay in HBM; ASR_BEAM=host, widths beyond 1024
-    # or more than 64 classes go to the library's host decoder
-    if (y_pred.is_cuda and width <= 1024 and y_pred.shape[2] <= 64
-            and os.environ.get('ASR_BEAM', 'device') != 'host'):
+    # host or device decoder (same strings, tests/test_gpu_beam.py): ops.beam_decoder_choice
+    if ops.beam_decoder_choice(N, width, y_pred.shape[2], y_pred.is_cuda) == 'device':
         dec, dlen, _ = ops.ctc_beam_search(y_pred, torch.as_tensor(seq).to(y_pred.device), N,
                                            width, merge)
         dec, dlen = dec.cpu().numpy(), dlen.cpu().numpy()

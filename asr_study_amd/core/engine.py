@@ -124,6 +124,9 @@ class Model(object):
         self.stop_training = False
         self._bufs = {}
         self._step = 0
+        self._enqueued = self._checked = 0   # train_on_batch steps enqueued / whose flags were read
+        self._ar_ref_pad = 0            # rank-invariant reference shard (set per batch)
+        self._ar_covered = []
         # weight-gradient GEMMs run on a side stream, concurrently with the next
         # layer's persistent BPTT kernel (which occupies only H/16 x chains CUs)
         import os as _os
@@ -734,12 +737,23 @@ class Model(object):
         # recurrence fills the chip (cfg3) its spin-waiting workgroups must all be resident, and
         # an RCCL kernel that takes CUs first stalls the whole chain: there the gradients are
         # reduced by ONE collective over the flat buffer after BPTT (110.6 MB: 0.6-2.5 ms of a
-        # ~50 ms step).  1 = always overlap, 0 = never.
+        # ~50 ms step).  1 = always overlap, 0 = never.  The decision must be the SAME on every
+        # rank (mismatched collective sequences hang RCCL): it is taken on the rank-invariant
+        # reference shard pad16(ceil(n_global / world)), never on this rank's own n_pad -- the
+        # shards of a ragged last batch differ by one utterance and can straddle a multiple of 16.
         ar_mode = os.environ.get('ASR_AR_OVERLAP', 'auto')
         reduce_now = (self._dist_active() and ar_mode != '0'
-                      and os.environ.get('ASR_COMM', 'torch') != 'capi'
-                      and (ar_mode == '1' or not self._recurrence_fills_chip(n_pad)))
-        self._ar_handles, self._ar_covered = [], []
+                      and (ar_mode == '1' or not self._recurrence_fills_chip(
+                          self._ar_ref_pad if self._ar_ref_pad else n_pad)))
+        self._ar_covered = []
+        self._ar_decision = reduce_now
+
+        def reduce_async(lo, hi, after):
+            # this slice of the gradients is final once the work on stream `after` is done: its
+            # all-reduce (on the communicator's own stream) runs beside the BPTT of the layers below
+            from ..parallel import grad_comm
+            grad_comm(self.device).allreduce_after(self.grads[lo:hi], after)
+            self._ar_covered.append((lo, hi))
 
         def flush_side():
             # enqueue deferred weight-gradient work on the side stream (called right
@@ -752,13 +766,8 @@ class Model(object):
                     ev = torch.cuda.Event()
                     ev.record(self._side)
                     self._dz_free[par] = ev
-                    if reduce_now and rng is not None:
-                        # this layer's gradients are final: their all-reduce (RCCL orders
-                        # itself after the side stream) overlaps the BPTT of the layers below
-                        import torch.distributed as dist
-                        self._ar_handles.append(
-                            dist.all_reduce(self.grads[rng[0]:rng[1]], async_op=True))
-                        self._ar_covered.append(rng)
+                if reduce_now and rng is not None:
+                    reduce_async(rng[0], rng[1], self._side)
 
         skip_grads = {}        # stage index -> gradient to add to that stage's OUTPUT
         for si in range(len(self.stages) - 1, -1, -1):
@@ -966,12 +975,9 @@ class Model(object):
                     weight_grads('gemm')
                     if reduce_now and not first:
                         # no side stream (a recurrence fills the chip): this layer's gradients
-                        # are final on the main stream; their all-reduce (RCCL orders itself
-                        # after it) runs beside the layers below instead of after them all
-                        import torch.distributed as dist
-                        self._ar_handles.append(
-                            dist.all_reduce(self.grads[s.p_lo:s.p_hi], async_op=True))
-                        self._ar_covered.append((s.p_lo, s.p_hi))
+                        # are final on the main stream; their all-reduce runs beside the layers
+                        # below instead of after them all
+                        reduce_async(s.p_lo, s.p_hi, main)
                 elif first:
                     # nothing left to hide behind: share the tail between both streams
                     ready = torch.cuda.Event()
@@ -1036,16 +1042,24 @@ class Model(object):
             slab = self.to_slab(x)
         return slab, [np.asarray(l).reshape(-1) for l in labels], lens
 
-    def loss_and_grads(self, slab, labels, seq_len, training=True, masks=None, n_global=None):
+    def loss_and_grads(self, slab, labels, seq_len, training=True, masks=None, n_global=None,
+                       n_ref=None):
         """One forward + CTC + backward.  Returns per-sample CTC loss (device) and
         logits; self.grads holds d(mean ctc)/d params."""
         lab, lab_len, sl = self._prep_labels(labels, seq_len, slab.shape[0])
         return self.loss_and_grads_device(slab, lab, lab_len, sl, len(labels), training, masks,
-                                          n_global)
+                                          n_global, n_ref)
 
     def loss_and_grads_device(self, slab, lab, lab_len, sl, N, training=True, masks=None,
-                              n_global=None):
-        """Same with labels (N, l_max) / label_len / seq_len already on the device."""
+                              n_global=None, n_ref=None):
+        """Same with labels (N, l_max) / label_len / seq_len already on the device.
+        n_global: samples of the GLOBAL batch (gradient scale 1/n_global; 0 = this rank holds a
+        zero-weight dummy); n_ref: the global batch size again, for decisions every rank must
+        take alike (it survives n_global = 0)."""
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        ng = int(n_ref or n_global or N * world)
+        self._ar_ref_pad = ops.pad16((ng + world - 1) // world)
         logits = self.forward(slab, training=training, masks=masks)
         dlog = self._buf('dlogits', logits.shape)
         # n_global = 0: a zero-weight dummy shard (parallel.ShardedBatch.n_local == 0)
@@ -1101,20 +1115,30 @@ class Model(object):
         """flags: a step's snapshot of the (collective) timeout flags, gen: self._fault_gen
         when that step was enqueued.  Returns True when the step was vetoed (its update did not
         happen and its activations are invalid): the caller drops its metrics.  Bookkeeping:
-        the vetoed step is taken back from the optimiser's iteration count (Adam bias
-        correction, decay) and from the noise-stream step."""
+        the sticky flags stay set until they are cleared HERE, so every step enqueued between
+        the fault and its detection -- in the lagged (sync=False) loop: this one and the one
+        already in flight behind it -- was vetoed on the device; all of them are taken back
+        from the optimiser's iteration count (Adam bias correction, decay) and from the
+        noise-stream step AT ONCE, so no later step re-uses an iteration number.
+        Evaluation (train=False) decides on this rank's own flags: no collective may be issued
+        from test_on_batch (rank 0 alone runs the final test), and a rank that evaluates on the
+        stepwise kernels for a while computes the same arithmetic as the others."""
+        inflight = self._enqueued - self._checked       # train steps not yet checked (>= 1)
+        if train:
+            self._checked += 1
         if not bool(flags.any().item()):
             return False
         from .._lib import AsrHipError
-        if train and self.optimizer is not None:
-            self.optimizer.iterations = max(0, self.optimizer.iterations - 1)
-            self._step = max(0, self._step - 1)
-            self.vetoed_steps += 1
         if gen < self._fault_gen:
             return True                 # enqueued before the fallback took effect: known
         if self.lstm_mode == 1:
             raise AsrHipError('a recurrent LSTM kernel reported a timeout in stepwise mode: '
                               'device fault')
+        if train and self.optimizer is not None:
+            n = max(1, inflight)
+            self.optimizer.iterations = max(0, self.optimizer.iterations - n)
+            self._step = max(0, self._step - n)
+            self.vetoed_steps += n
         # A persistent kernel abandoned a bounded spin (a peer workgroup was not co-resident).
         # The update of every step enqueued since was vetoed on the device (ops.optim_guard),
         # so the weights are intact: clear the flags and go on with the stepwise kernels (one
@@ -1135,33 +1159,27 @@ class Model(object):
         return True
 
     def _allreduce(self):
-        """Sums the gradients over the ranks (RCCL).  Layers whose weight gradients were
-        finished on the side stream during BPTT were already reduced there, asynchronously
-        (backward(), only where a recurrence leaves CUs free); here the current stream waits
-        for those and the rest of the flat buffer -- everything, where BPTT fills the chip --
-        is reduced in place, TOGETHER with the two timeout-flag slots behind it."""
-        import torch.distributed as dist
+        """Sums the gradients over the ranks: RCCL through the library's C ABI (asr_comm_*,
+        parallel.CapiComm).  Layers whose weight gradients were finished during BPTT were already
+        reduced there, asynchronously on the communicator's stream (backward(), only where a
+        recurrence leaves CUs free); the rest of the flat buffer -- everything, where BPTT fills
+        the chip -- is reduced here in place, TOGETHER with the two timeout-flag slots behind
+        it, and the current stream then waits for all of them."""
         if not self._dist_active():
             return 1
+        from ..parallel import grad_comm, world_size
+        comm = grad_comm(self._gbuf.device)
         self._collect_flags()
         total = self.n_params + 4
-        if os.environ.get('ASR_COMM', 'torch') == 'capi':
-            # the library's own RCCL entry points (asr_comm_*), on the current stream
-            from ..parallel import CapiComm
-            CapiComm.get().allreduce_sum_(self._gbuf)
-            return dist.get_world_size()
-        handles, covered = getattr(self, '_ar_handles', []), sorted(getattr(self, '_ar_covered', []))
-        for h in handles:
-            h.wait()                        # the current stream waits for the collective
+        covered = sorted(getattr(self, '_ar_covered', []))
         pos = 0
         for lo, hi in covered + [(total, total)]:
             if lo > pos:
-                # RCCL orders itself after the kernels already enqueued on the current
-                # stream and the current stream after the collective
-                dist.all_reduce(self._gbuf[pos:lo])
+                comm.allreduce_after(self._gbuf[pos:lo], None)   # behind the current stream's work
             pos = max(pos, hi)
-        self._ar_handles, self._ar_covered = [], []
-        return dist.get_world_size()
+        comm.join(None)
+        self._ar_covered = []
+        return world_size()
 
     def train_on_batch(self, inputs, outputs=None, masks=None, sync=True):
         """One optimisation step on a batch ``[x, labels, inputs_length]``.
@@ -1176,14 +1194,15 @@ class Model(object):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # a rank's shard of a global batch says how many samples the GLOBAL batch had (shards
         # are unequal when the batch is not divisible by the world; parallel.ShardedBatch)
-        n_global = getattr(inputs, 'n_global', N * world)
+        n_global = n_ref = getattr(inputs, 'n_global', N * world)
         if getattr(inputs, 'n_local', N) == 0:
             n_global = 0
         gen = self._fault_gen
         ctc, logits, sl = self.loss_and_grads(slab, labels, lens, training=True, masks=masks,
-                                              n_global=n_global)
+                                              n_global=n_global, n_ref=n_ref)
         self._allreduce()
         self._step += 1
+        self._enqueued += 1
         self.optimizer.step(self)
         dec, dlen = ops.ctc_greedy(logits, sl, N)
         if not sync:
@@ -1272,14 +1291,13 @@ class Model(object):
         return [dec[n, :dlen[n]].tolist() for n in range(N)]
 
     def _beam(self, logits, seq_len_dev, N):
-        """core/ctc_utils.py:48-50 on the device (K9): the logits stay in HBM; only the decoded
-        labels are copied back.  Widths beyond the kernel's 1024 (or > 64 classes), or
-        ASR_BEAM=host, use the library's host decoder (decode_host.cpp: one utterance per host
-        thread) on a copy of the logits -- same strings either way."""
+        """core/ctc_utils.py:48-50 (K9): the library's host decoder (decode_host.cpp: one
+        utterance per host thread, on a copy of the logits) or the device decoder (beam.hip: the
+        logits stay in HBM) -- same strings either way; ops.beam_decoder_choice picks (host
+        while every utterance gets its own host thread, ASR_BEAM=device / host force one)."""
         width = int(self.decoder.get('beam_width', 100))
         merge = self.decoder.get('merge_repeated', True)
-        import os as _os
-        if width <= 1024 and logits.shape[2] <= 64 and _os.environ.get('ASR_BEAM', 'device') != 'host':
+        if ops.beam_decoder_choice(N, width, logits.shape[2]) == 'device':
             dec, dlen, _ = ops.ctc_beam_search(logits, seq_len_dev, N, width, merge)
             return dec, dlen
         lens = seq_len_dev.cpu().numpy()

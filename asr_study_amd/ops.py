@@ -315,6 +315,25 @@ def ctc_beam_search(logits, seq_len, N, beam_width=100, merge_repeated=True):
     return dec, dlen, score
 
 
+def beam_decoder_choice(N, width, classes, on_device=True):
+    """Which K9 decoder serves a batch of N utterances: 'host' (decode_host.cpp: one utterance
+    per host thread, after a D2H copy of the logits) or 'device' (beam.hip: one wave per
+    utterance, logits stay in HBM).  Both give the same strings (tests/test_gpu_beam.py); the
+    default is decided on measurements (BENCH_r03 eval_beam, 64 x 999 frames on a 256-thread
+    host): the host decoder is 4.6x faster at width 100 and 2.4x at width 400 as long as every
+    utterance gets its own host thread, so ASR_BEAM=auto (default) takes the host decoder for
+    N <= host threads and the device decoder beyond; ASR_BEAM=device / host force one.  The
+    device kernel handles widths <= 1024 and <= 64 classes."""
+    import os
+    mode = os.environ.get('ASR_BEAM', 'auto')
+    device_ok = on_device and int(width) <= 1024 and int(classes) <= 64
+    if mode == 'host' or not device_ok:
+        return 'host'
+    if mode == 'device':
+        return 'device'
+    return 'host' if int(N) <= (os.cpu_count() or 1) else 'device'
+
+
 def ctc_beam_counters(logits_shape, N, beam_width, utterance=0, device='cuda:0'):
     """Work counters of the last ctc_beam_search call of that shape (see
     asr_ctc_beam_device_counters): dict of seconds per phase and event counts."""

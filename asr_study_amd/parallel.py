@@ -9,7 +9,9 @@ backward LSTM sees the same zero tail as a single-GPU run.  Gradients are summed
 with ONE fp32 all-reduce over the model's flat gradient buffer (27.7 MB at cfg2,
 110.6 MB at cfg3) and were already scaled by 1/N_global in the CTC kernel, so the
 sum IS the gradient of the global batch mean; clip + Adam then run replicated.
-``torch.distributed`` backend 'nccl' is RCCL on ROCm; 'gloo' serves the CPU tests.
+The collective itself is issued through the library's own C ABI (``asr_comm_*``: RCCL
+resolved with dlopen); ``torch.distributed`` only ferries the communicator's 128-byte id
+(and serves the CPU tests over gloo).
 """
 import os
 
@@ -56,26 +58,42 @@ def shard_indices(index_array, rank, world):
 
 
 def allreduce_sum_(flat):
-    """In-place sum over ranks of a flat tensor (the model's gradient buffer)."""
+    """In-place sum over ranks of a flat tensor (the model's gradient buffer) through the
+    process' gradient communicator (grad_comm): the library's RCCL entry points for a tensor in
+    HBM, the host process group for a CPU tensor (the gloo tests)."""
     if world_size() > 1:
-        dist.all_reduce(flat)
+        comm = grad_comm(flat.device)
+        comm.allreduce_after(flat, None)
+        comm.join(None)
     return flat
 
 
 def broadcast_parameters(model, src=0):
+    """Every rank starts from rank `src`'s weights: the others zero theirs and the flat buffer
+    is summed (exact: x + 0 + ...) through the gradient communicator."""
     if world_size() > 1:
-        dist.broadcast(model.params, src)
+        if dist.get_rank() != src:
+            model.params.zero_()
+        allreduce_sum_(model.params)
 
 
 def reduce_metrics(sums, count):
-    """Sum (metric_sums, sample_count) over ranks -> global batch-weighted means."""
+    """Sum (metric_sums, sample_count) over ranks -> global batch-weighted means.  On the GPU
+    the sums travel through the gradient communicator as float32 (hi, lo) pairs (48 significant
+    bits), so torch.distributed carries nothing but the communicator's 128-byte id."""
     t = torch.tensor(list(sums) + [float(count)], dtype=torch.float64)
     if world_size() > 1:
-        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' \
-            else torch.device('cpu')
-        t = t.to(dev)
-        dist.all_reduce(t)
-        t = t.cpu()
+        if torch.cuda.is_available() and dist.get_backend() == 'nccl':
+            dev = torch.device('cuda', torch.cuda.current_device())
+            hi = t.float()
+            pair = torch.cat([hi, (t - hi.double()).float()]).to(dev)
+            comm = grad_comm(dev)
+            comm.allreduce_after(pair, torch.cuda.current_stream(dev))
+            comm.join(torch.cuda.current_stream(dev))
+            pair = pair.cpu().double()
+            t = pair[:t.numel()] + pair[t.numel():]
+        else:
+            dist.all_reduce(t)
     return (t[:-1] / max(float(t[-1]), 1.0)).tolist()
 
 
@@ -124,11 +142,41 @@ class ShardedFlow(object):
     next = __next__
 
 
+def grad_comm(device):
+    """The communicator the gradient all-reduce goes through: ONE path per kind of memory --
+    CapiComm (asr_comm_*: RCCL behind the C ABI) for tensors in HBM, HostGroupComm (the host
+    process group, gloo) for CPU tensors, which only the CPU tests have."""
+    device = torch.device(device)
+    return CapiComm.get() if device.type == 'cuda' else HostGroupComm.get()
+
+
+class HostGroupComm(object):
+    """CPU tensors (the world-2 gloo tests of the bookkeeping): the process group itself."""
+
+    _instance = None
+
+    @classmethod
+    def get(cls):
+        if cls._instance is None:
+            cls._instance = cls()
+        return cls._instance
+
+    def allreduce_after(self, flat, after):
+        dist.all_reduce(flat)
+        return flat
+
+    def join(self, stream):
+        pass
+
+
 class CapiComm(object):
     """The gradient all-reduce through the library's own RCCL entry points
-    (include/asr_hip.h C1, ``ASR_COMM=capi``) instead of torch.distributed's: rank 0 draws
-    the RCCL unique id, the existing process group only ferries those 128 bytes, and the
-    collective is then enqueued on torch's CURRENT stream by ``asr_comm_allreduce_sum``."""
+    (include/asr_hip.h C1): rank 0 draws the RCCL unique id, the process group only ferries
+    those 128 bytes, and every collective is enqueued by ``asr_comm_allreduce_sum`` on this
+    communicator's OWN stream: ``allreduce_after(t, s)`` orders it behind the work already
+    enqueued on stream ``s`` (None = the current one), ``join(s)`` makes ``s`` wait for every
+    collective issued so far.  One stream per communicator: the collectives execute in the
+    order they were issued, identically on every rank."""
 
     _instance = None
 
@@ -155,17 +203,34 @@ class CapiComm(object):
         _lib.check(self._lib.asr_comm_init(box[0], rank, world, C.byref(self._comm)),
                    'asr_comm_init')
         self.world = world
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.calls = 0
+
+    def allreduce_after(self, flat, after=None):
+        from . import _lib
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        after = after or torch.cuda.current_stream(flat.device)
+        self.stream.wait_stream(after)
+        flat.record_stream(self.stream)
+        _lib.check(self._lib.asr_comm_allreduce_sum(
+            self._comm, self._C.c_void_p(flat.data_ptr()), flat.numel(),
+            self._C.c_void_p(self.stream.cuda_stream)), 'asr_comm_allreduce_sum')
+        self.calls += 1
+        return flat
+
+    def join(self, stream=None):
+        (stream or torch.cuda.current_stream(self.device)).wait_stream(self.stream)
 
     def allreduce_sum_(self, flat):
-        from . import _lib
-        stream = torch.cuda.current_stream(flat.device).cuda_stream
-        _lib.check(self._lib.asr_comm_allreduce_sum(self._comm, self._C.c_void_p(flat.data_ptr()),
-                                                    flat.numel(), self._C.c_void_p(stream)),
-                   'asr_comm_allreduce_sum')
+        """Blocking form (in stream order): reduce, then the current stream waits."""
+        self.allreduce_after(flat, None)
+        self.join(None)
         return flat
 
     def close(self):
         if self._comm:
+            torch.cuda.synchronize(self.device)
             self._lib.asr_comm_destroy(self._comm)
             self._comm = self._C.c_void_p()
         CapiComm._instance = None

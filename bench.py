@@ -249,6 +249,11 @@ def eval_beam(dev, model, slab, n_valid, frames):
         out['same_strings_width_%d' % width] = bool(
             all(d[n, :l[n]].tolist() == host[n] for n in range(n_valid)))
     out['host_threads'] = min(int(n_valid), os.cpu_count() or 1)
+    # what eval.py / ctc_utils.decode actually run (ops.beam_decoder_choice, ASR_BEAM=auto): the
+    # host decoder while every utterance gets its own host thread, the device decoder beyond
+    out['default_decoder'] = ops.beam_decoder_choice(n_valid, 100, int(logits.shape[2]))
+    for width in (100, 400):
+        out['default_width_%d_s' % width] = out['%s_width_%d_s' % (out['default_decoder'], width)]
     return out
 
 
@@ -453,8 +458,10 @@ def main():
     timeouts = int(ops.lstm_timeout_flags(dev).ne(0).sum().item()) + int(model.fallbacks)
     ranks_seen = 1
     if world > 1 or force_dist:
-        t = torch.tensor([float(timeouts), 1.0], dtype=torch.float64, device=dev)
-        dist.all_reduce(t)
+        # through the product's own communicator (asr_comm_*): what the gradients travel on
+        from asr_study_amd import parallel
+        t = torch.tensor([float(timeouts), 1.0], dtype=torch.float32, device=dev)
+        parallel.grad_comm(dev).allreduce_sum_(t)
         timeouts, ranks_seen = int(t[0].item()), int(t[1].item())
         assert ranks_seen == world, 'RCCL saw %d ranks, WORLD_SIZE is %d' % (ranks_seen, world)
     assert timeouts == 0, ('%d recurrent-kernel timeout(s) / fallback(s) during the timed steps: '
@@ -478,15 +485,17 @@ def main():
         # ---- bus bandwidth of the gradient all-reduce (outside the timed region): the flat
         # fp32 gradient buffer, as one collective; bus = 2 (n-1)/n * bytes / time
         g = model._gbuf
+        from asr_study_amd import parallel
+        comm = parallel.grad_comm(dev)          # asr_comm_*: RCCL behind the C ABI
         for _ in range(2):
-            dist.all_reduce(g)
+            comm.allreduce_sum_(g)
         torch.cuda.synchronize()
         dist.barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         reps = 5
         for _ in range(reps):
-            dist.all_reduce(g)
+            comm.allreduce_sum_(g)
         e1.record()
         torch.cuda.synchronize()
         ar_ms = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=dev)
@@ -496,7 +505,7 @@ def main():
         extra['allreduce'] = {
             'bytes': nbytes, 'ms': round(float(ar_ms.item()), 4),
             'bus_GBps': round(2.0 * (world - 1) / world * nbytes / (float(ar_ms.item()) * 1e-3) / 1e9, 2),
-            'backend': 'rccl (torch.distributed nccl)', 'note': 'one fp32 all-reduce of the flat '
+            'backend': 'rccl through the C ABI (asr_comm_allreduce_sum)', 'note': 'one fp32 all-reduce of the flat '
             'gradient buffer (+ the timeout-flag slots), exactly as the step issues it'}
     if rank == 0:
         # ---- secondary roofline figures (outside the timed region): the gate GEMM of
@@ -558,6 +567,7 @@ def main():
             'bound': 'hbm', 'achieved': round(cb / tc / 1e6, 2), 'peak': PEAK_HBM_GBS,
             'unit': 'GB/s', 'frac': round(cb / tc / 1e6 / PEAK_HBM_GBS, 5),
             'avg_ms': round(tc, 4), 'share_of_step': round(tc / (dt / args.steps * 1e3), 4),
+            'algorithmic_bytes': cb, 'traffic': _pmc_traffic(args.config).get('ctc'),
             'note': 'LATENCY-bound, not HBM-bound: a 999-step dependent recursion per utterance '
                     '(>= 1 log-sum-exp per step); the north-star 60 % HBM target is not '
                     'reachable for a sequential recursion (DESIGN.md 8) and the kernel is '
@@ -588,29 +598,43 @@ def main():
                      'bwd': slab_b + 4 * slab_b + slab_b + 4 * slab_b}
         pmc = _pmc_traffic(args.config)
 
+        rec_exact = os.environ.get('ASR_LSTM_PREC', '1') == '0'
+
         def roof(kind, times, kernel):
+            # The recurrences are LATENCY-bound (T dependent steps, one cross-workgroup hand-off
+            # each): the figure of merit is us_per_timestep.  `achieved` / `peak` / `frac` are the
+            # flop/s the matrix pipe EXECUTES against the peak of the pipe it runs on -- split
+            # fp16: 3 v_mfma_f32_16x16x32_f16 per fp32 product vs the 2.5 PF dense-fp16 peak,
+            # which is what the PMC's SQ_VALU_MFMA_BUSY_CYCLES measures (profiles/*_pmc_step_*);
+            # the algorithmic fp32 rate against the fp32-MFMA peak (SURVEY 8d's yardstick, 3x
+            # easier to "reach" on fp16 pipes) is kept under its own, explicitly named keys.
+            mult, peak = (1, PEAK_F32_MFMA_TFLOPS) if rec_exact else (3, PEAK_F16_MFMA_TFLOPS)
             per_launch_ms, tot_ms, tot_steps = times
             if not tot_ms:
-                return {'kernel': kernel, 'bound': 'mfma', 'achieved': None,
-                        'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
-                        'traffic': None}
+                return {'kernel': kernel, 'bound': 'latency (hand-off)', 'achieved': None,
+                        'peak': peak, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None}
             # a launch covers steps_per_launch of the layer's T dependent steps: its share
             # of the layer's algorithmic flops / bytes / PMC traffic is that fraction
             share = tot_steps / T / (tot_ms / per_launch_ms)      # avg fraction of a layer
-            ach = flops * (tot_steps / T) / (tot_ms * 1e-3) / 1e12
-            return {'kernel': kernel, 'bound': 'mfma', 'achieved': round(ach, 3),
-                    'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            alg = flops * (tot_steps / T) / (tot_ms * 1e-3) / 1e12
+            return {'kernel': kernel, 'bound': 'latency (hand-off)',
+                    'achieved': round(mult * alg, 3), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(mult * alg / peak, 4),
+                    'pipe': 'fp32 MFMA' if rec_exact else 'fp16 MFMA (3 per fp32 product)',
+                    'algorithmic_fp32_tflops': round(alg, 3),
+                    'algorithmic_vs_fp32_mfma_peak': round(alg / PEAK_F32_MFMA_TFLOPS, 4),
                     'traffic': round(pmc[kind] * share, 1) if kind in pmc else None,
                     'algorithmic_bytes': round(alg_bytes[kind] * share, 1),
+                    'hbm_GBps': round(alg_bytes[kind] * (tot_steps / T) / (tot_ms * 1e-3) / 1e9, 1),
                     'avg_launch_ms': round(per_launch_ms, 4),
                     'steps_per_launch': round(tot_steps / (tot_ms / per_launch_ms), 1),
                     'us_per_timestep': round(tot_ms * 1e3 / tot_steps, 3),
                     'flops_per_launch': flops * share,
                     'note': 'latency-bound recurrence (T dependent steps, cross-workgroup '
                             'hand-off per step; a layer may be launched in slices when its '
-                            'neighbouring GEMMs are pipelined): DESIGN.md 5; achieved = '
-                            'algorithmic fp32 flop/s vs the fp32-MFMA peak (SURVEY 8d)'}
+                            'neighbouring GEMMs are pipelined): DESIGN.md 5.  achieved = executed '
+                            'MFMA flop/s on the pipe in use; traffic = PMC bytes per launch '
+                            '(profiles/pmc_traffic.json)'}
         split = os.environ.get('ASR_GEMM_PREC', '1') != '0' or os.environ.get('ASR_LSTM_PREC', '1') != '0'
 
         def gemm_roof():

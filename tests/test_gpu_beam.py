@@ -121,9 +121,11 @@ def test_shuffle_variant_of_the_shift_gives_the_same_beams():
 
 
 def test_eval_mode_model_decodes_on_the_device(monkeypatch):
-    """engine.Model with a beam decoder (load_model(mode='eval') semantics): predict and
-    test_on_batch never copy the logits to the host (ops.ctc_beam_search_host is not called)."""
+    """engine.Model with a beam decoder (load_model(mode='eval') semantics) under
+    ASR_BEAM=device: predict and test_on_batch never copy the logits to the host
+    (ops.ctc_beam_search_host is not called)."""
     from asr_study_amd import ops
+    monkeypatch.setenv('ASR_BEAM', 'device')
     from asr_study_amd.core import models
     rs = np.random.RandomState(0)
     N, T, F, C = 5, 40, 12, 9
@@ -147,8 +149,9 @@ def test_eval_mode_model_decodes_on_the_device(monkeypatch):
 
 def test_ctc_utils_decode_beam_branch_runs_on_the_device(monkeypatch):
     """core/ctc_utils.decode(is_greedy=False) (the reference's Lambda body, ctc_utils.py:8-52):
-    the device decoder by default, the host one under ASR_BEAM=host -- same label lists, and the
-    default never touches the host decoder."""
+    the device decoder under ASR_BEAM=device, the host one under ASR_BEAM=host -- same label
+    lists, and the device branch never touches the host decoder; the default (auto) picks by
+    batch size against the host's thread count (ops.beam_decoder_choice)."""
     from asr_study_amd import ops
     from asr_study_amd.core import ctc_utils
     rs = np.random.RandomState(5)
@@ -159,9 +162,16 @@ def test_ctc_utils_decode_beam_branch_runs_on_the_device(monkeypatch):
     monkeypatch.setenv('ASR_BEAM', 'host')
     host = ctc_utils.decode((slab, lens), is_greedy=False, beam_width=100)
     monkeypatch.delenv('ASR_BEAM')
+    auto = ctc_utils.decode((slab, lens), is_greedy=False, beam_width=100)
+    monkeypatch.setenv('ASR_BEAM', 'device')
 
     def boom(*a, **k):
         raise AssertionError('host decoder called')
     monkeypatch.setattr(ops, 'ctc_beam_search_host', boom)
     dev = ctc_utils.decode((slab, lens), is_greedy=False, beam_width=100)
-    assert dev == host and any(len(h) for h in host)
+    assert dev == host == auto and any(len(h) for h in host)
+    monkeypatch.delenv('ASR_BEAM')
+    threads = os.cpu_count() or 1
+    assert ops.beam_decoder_choice(min(5, threads), 100, C) == 'host'
+    assert ops.beam_decoder_choice(threads + 1, 100, C) == 'device'
+    assert ops.beam_decoder_choice(threads + 1, 2048, C) == 'host'      # beyond the kernel's width

@@ -124,3 +124,35 @@ def test_lagged_metrics_drop_vetoed_steps_and_take_their_iterations_back():
     r3 = model.train_on_batch(batch, sync=False)          # stepwise kernels: a real update
     assert model._lagged((r3, labels, 4)) is not None
     assert not torch.equal(model.params, before) and model.optimizer.iterations == 2
+
+
+def test_lagged_veto_never_reuses_an_iteration_number():
+    """The order fit_generator really produces: step k times out, step k+1 is enqueued, k is
+    checked (fallback), step k+2 is ENQUEUED BEFORE k+1 is checked.  Both vetoed steps are
+    taken back at the detection, so k+2 and k+3 are applied with consecutive Adam iterations
+    and noise-stream steps (they used to share one)."""
+    import torch
+    from asr_study_amd import ops
+    from asr_study_amd.core import models, optimizers
+    rs = np.random.RandomState(2)
+    model = models.brsmv1(num_features=9, num_classes=7, num_hiddens=16, num_layers=1,
+                          dropout=0.0, seed=1)
+    model.compile(optimizer=optimizers.Adam(lr=1e-2, clipnorm=1.0))
+    x = rs.randn(4, 20, 9).astype(np.float32)
+    labels = [rs.randint(0, 6, size=3).tolist() for _ in range(4)]
+    batch = [x, labels, [20] * 4]
+    r0 = model.train_on_batch(batch, sync=False)
+    assert model._lagged((r0, labels, 4)) is not None
+    ops.WS.get('lstm_bwd', 0, model.device)[:4].view(torch.int32)[0] = 1
+    r1 = model.train_on_batch(batch, sync=False)          # k: vetoed
+    r2 = model.train_on_batch(batch, sync=False)          # k+1: vetoed too (flag still set)
+    assert model._lagged((r1, labels, 4)) is None         # detection: both taken back
+    assert model.optimizer.iterations == 1 and model._step == 1 and model.vetoed_steps == 2
+    r3 = model.train_on_batch(batch, sync=False)          # k+2, enqueued before k+1 is checked
+    used = [(model.optimizer.iterations, model._step)]
+    assert model._lagged((r2, labels, 4)) is None
+    r4 = model.train_on_batch(batch, sync=False)
+    used.append((model.optimizer.iterations, model._step))
+    assert model._lagged((r3, labels, 4)) is not None and model._lagged((r4, labels, 4)) is not None
+    assert used == [(2, 2), (3, 3)] and model.fallbacks == 1 and model.vetoed_steps == 2
+

@@ -49,9 +49,8 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from asr_study_amd.core import models, optimizers
 out = {}
-for mode in ("1", "0", "capi", "noside", "noside0"):
-    os.environ["ASR_AR_OVERLAP"] = {"capi": "0", "noside": "1", "noside0": "0"}.get(mode, mode)
-    os.environ["ASR_COMM"] = "capi" if mode == "capi" else "torch"
+for mode in ("1", "0", "noside", "noside0"):
+    os.environ["ASR_AR_OVERLAP"] = {"noside": "1", "noside0": "0"}.get(mode, mode)
     os.environ["ASR_OVERLAP"] = "0" if mode.startswith("noside") else "auto"
     model = models.brsmv1(num_features=9, num_classes=7, num_hiddens=16, num_layers=3,
                           dropout=0.0, weight_decay=1e-4, seed=1)
@@ -66,7 +65,7 @@ for mode in ("1", "0", "capi", "noside", "noside0"):
     out["layers_reduced_during_bptt_" + mode] = len(model._ar_covered)
 # ASR_AR_OVERLAP=auto (the default): per-layer asynchronous all-reduces only while a recurrence
 # leaves CUs free; 2 x 4 batch tiles x 32 workgroups (BiLSTM(512), batch 64) fill the chip
-os.environ.pop("ASR_AR_OVERLAP"); os.environ["ASR_COMM"] = "torch"; os.environ["ASR_OVERLAP"] = "auto"
+os.environ.pop("ASR_AR_OVERLAP"); os.environ["ASR_OVERLAP"] = "auto"
 out["layers_reduced_during_bptt_auto_small"] = None
 model.loss_and_grads(model.to_slab(x), labels, [40] * 6, training=False)
 out["layers_reduced_during_bptt_auto_small"] = len(model._ar_covered)
@@ -76,6 +75,17 @@ xb = rs.randn(64, 6, 16).astype(np.float32)
 lb = [rs.randint(0, 6, size=2).tolist() for _ in range(64)]
 big.loss_and_grads(big.to_slab(xb), lb, [6] * 64, training=False)
 out["layers_reduced_during_bptt_auto_chipfill"] = len(big._ar_covered)
+# the decision is taken on the rank-invariant reference shard pad16(ceil(n_global / world)),
+# not on this rank's own n_pad: a 48-row local shard of a global batch whose reference shard
+# pads to 64 rows (fills the chip) must NOT start per-layer collectives
+x48 = rs.randn(48, 6, 16).astype(np.float32)
+l48 = [rs.randint(0, 6, size=2).tolist() for _ in range(48)]
+big.loss_and_grads(big.to_slab(x48), l48, [6] * 48, training=False, n_global=49, n_ref=49)
+out["layers_reduced_ragged_ref64_local48"] = len(big._ar_covered)
+big.loss_and_grads(big.to_slab(x48), l48, [6] * 48, training=False, n_global=48, n_ref=48)
+out["layers_reduced_ragged_ref48_local48"] = len(big._ar_covered)
+from asr_study_amd import parallel
+out["collectives_through_capi"] = parallel.CapiComm.get().calls
 # the veto of an update is collective: the flags travel behind the gradients through the
 # all-reduce and the guard reads the reduced slots
 from asr_study_amd import ops
@@ -99,8 +109,9 @@ print("RESULT " + json.dumps(out))
 @pytest.mark.timeout(300)
 def test_layerwise_allreduce_overlap_equals_single_allreduce():
     """The per-layer asynchronous all-reduces issued during BPTT (ASR_AR_OVERLAP=1; the default
-    `auto` issues them only where a recurrence leaves CUs free; from the side stream, or from the
-    main stream when there is none) and one all-reduce of the
+    `auto` issues them only where a recurrence leaves CUs free; behind the side stream, or behind
+    the main stream when there is none; all through asr_comm_* on the communicator's stream) and
+    one all-reduce of the
     whole buffer after it give the same training trajectory (world size 1 on the box's single GPU: the collective is an
     identity, what is tested is stream ordering and buffer coverage)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', ASR_FORCE_ALLREDUCE='1',
@@ -111,7 +122,11 @@ def test_layerwise_allreduce_overlap_equals_single_allreduce():
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('RESULT ')][0]
     res = json.loads(line[7:])
-    assert res['1'] == res['0'] == res['capi']      # capi: asr_comm_* instead of torch
+    assert res['1'] == res['0']
+    # every collective of the run went through the library's own RCCL entry points
+    assert res['collectives_through_capi'] > 10
+    assert res['layers_reduced_ragged_ref64_local48'] == 0
+    assert res['layers_reduced_ragged_ref48_local48'] == 2
     # no side stream (cfg3's schedule): per-layer all-reduces from the main stream == one at the
     # end; against the side-stream schedule only the frame-range pipelining differs (the
     # gradient GEMMs' power-of-two pre-scale is taken per slice there): last-bit differences

@@ -143,13 +143,15 @@ def _ar_worker(rank, world, port, out):
         gbuf[n:] = torch.tensor([0.0, 1.0 if rank == 1 else 0.0, 0.0, 0.0])
     fake = types.SimpleNamespace(n_params=n, _gbuf=gbuf, grads=gbuf[:n], _collect_flags=collect,
                                  _dist_active=lambda: True)
-    # what backward() does for the layers whose gradients finish early: asynchronous
-    # all-reduces of their slices, in the order the layers finish (top layer first)
-    fake._ar_handles, fake._ar_covered = [], []
+    # what backward() does for the layers whose gradients finish early: all-reduces of their
+    # slices through the gradient communicator, in the order the layers finish (top layer first)
+    comm = parallel.grad_comm(gbuf.device)
+    assert isinstance(comm, parallel.HostGroupComm)       # CPU tensors: the host process group
+    fake._ar_covered = []
     for lo, hi in ((700, 900), (300, 700), (120, 300)):
-        fake._ar_handles.append(dist.all_reduce(fake.grads[lo:hi], async_op=True))
+        comm.allreduce_after(fake.grads[lo:hi], None)
         fake._ar_covered.append((lo, hi))
-    w = engine.Model._allreduce(fake)      # waits, then reduces [0,120) and [900,1000) + flags
+    w = engine.Model._allreduce(fake)      # reduces [0,120) and [900,1000) + flags, joins
     # the veto flags arrive on EVERY rank (the guard of rank 0 must see rank 1's timeout)
     assert engine.Model.veto_flags(fake).tolist() == [0.0, 1.0]
     if rank == 0:

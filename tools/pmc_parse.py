@@ -9,6 +9,9 @@ import sys
 
 
 def short(n):
+    m = re.match(r'_ZN12_GLOBAL__N_1(\d+)', n)      # an un-demangled anonymous-namespace kernel
+    if m:
+        n = n[m.end():m.end() + int(m.group(1))]
     n = re.sub(r'\(anonymous namespace\)::', '', n)
     n = re.sub(r'^void ', '', n)
     m = re.match(r'([A-Za-z0-9_:]+(<[^>]*>)?)', n)

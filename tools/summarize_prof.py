@@ -8,6 +8,9 @@ import sys
 
 
 def short(name):
+    m = re.match(r'_ZN12_GLOBAL__N_1(\d+)', name)      # an un-demangled anonymous-namespace kernel
+    if m:
+        name = name[m.end():m.end() + int(m.group(1))]
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     name = re.sub(r'^void ', '', name)
     m = re.match(r'([A-Za-z0-9_:]+(<[^>]*>)?)', name)
