@@ -55,7 +55,17 @@ class GemmHlArgs(C.Structure):
                 ('alpha', C.c_float), ('beta', C.c_float),
                 ('bias', void_p),
                 ('c_scale', void_p), ('c_scale_period', C.c_int), ('c_scale_ld', C.c_int),
-                ('split_k', C.c_int), ('tile', C.c_int), ('k_major', C.c_int)]
+                ('split_k', C.c_int), ('tile', C.c_int), ('k_major', C.c_int),
+                ('a_seg_k', C.c_int), ('a_seg_row', C.c_longlong * 16)]
+
+
+class Conv2dArgs(C.Structure):
+    _fields_ = [('T_in', C.c_int), ('n_pad', C.c_int), ('F_in', C.c_int), ('C_in', C.c_int),
+                ('C_out', C.c_int), ('kt', C.c_int), ('kf', C.c_int), ('st', C.c_int),
+                ('sf', C.c_int), ('clip', C.c_float),
+                ('x', void_p), ('W', void_p), ('bias', void_p), ('z', void_p), ('y', void_p),
+                ('dy', void_p), ('dx', void_p), ('dW', void_p), ('db', void_p),
+                ('reuse_x', C.c_int), ('reuse_dz', C.c_int)]
 
 
 class LstmArgs(C.Structure):
@@ -114,6 +124,11 @@ SIGNATURES = {
     'asr_gemm_hl_workspace_bytes': (C.c_size_t, [C.POINTER(GemmHlArgs)]),
     'asr_gemm_hl': (C.c_int, [C.POINTER(GemmHlArgs), void_p, C.c_size_t, void_p]),
     'asr_gemm_hl_profile': (C.c_int, [C.c_int, C.POINTER(C.c_longlong), void_p]),
+    'asr_conv2d_out_shape': (C.c_int, [C.POINTER(Conv2dArgs), c_int_p, c_int_p]),
+    'asr_conv2d_workspace_bytes': (C.c_size_t, [C.POINTER(Conv2dArgs)]),
+    'asr_conv2d_fwd': (C.c_int, [C.POINTER(Conv2dArgs), void_p, C.c_size_t, void_p]),
+    'asr_conv2d_dgrad': (C.c_int, [C.POINTER(Conv2dArgs), void_p, C.c_size_t, void_p]),
+    'asr_conv2d_wgrad': (C.c_int, [C.POINTER(Conv2dArgs), void_p, C.c_size_t, void_p]),
     'asr_absmax': (C.c_int, [void_p, C.c_int64, void_p, void_p]),
     'asr_dropout_masks': (C.c_int, [void_p, C.c_int64, C.c_float, C.c_float, C.c_uint64,
                                     C.c_uint32, C.c_uint32, void_p]),

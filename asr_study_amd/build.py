@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libasr_hip.so')
-SOURCES = ['capi.cpp', 'ctc.hip', 'beam.hip', 'frontend.hip', 'gemm.hip', 'lstm.hip', 'lstm_fwd.hip', 'lstm_bwd.hip', 'lstm_ln.hip',
+SOURCES = ['capi.cpp', 'ctc.hip', 'beam.hip', 'frontend.hip', 'conv.hip', 'gemm.hip', 'lstm.hip', 'lstm_fwd.hip', 'lstm_bwd.hip', 'lstm_ln.hip',
            'optim.hip', 'random.hip', 'decode_host.cpp', 'comm.cpp', 'roles.cpp']
 ARCH = 'gfx950'
 

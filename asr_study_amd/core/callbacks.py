@@ -60,9 +60,13 @@ def keras_layers(model, weights):
     """[(layer name, [(weight name, array), ...])] in Keras-1.2.2 naming for the model's
     weight-bearing stages (get_weights() order); every array of ``weights`` is consumed."""
     it = iter(weights)
-    out, nb, nd = [], 0, 0
+    out, nb, nd, nc = [], 0, 0, 0
     for s in model.stages:
-        if s.kind == 'bilstm':
+        if s.kind == 'conv':        # keras.layers.Convolution2D: '<name>_W', '<name>_b'
+            nc += 1
+            out.append(('convolution2d_%d' % nc, [('convolution2d_%d_W:0' % nc, next(it)),
+                                                  ('convolution2d_%d_b:0' % nc, next(it))]))
+        elif s.kind == 'bilstm':
             nb += 1
             ws = []
             for d in ('forward', 'backward'):

@@ -194,6 +194,28 @@ class Model(object):
             s.f_in, s.f_in_pad = f_real, f_pad
             if s.kind in ('noise', 'dropout'):
                 s.value = st['value']
+            elif s.kind == 'reshape':
+                s.target = [int(v) for v in st['target']]
+            elif s.kind == 'conv':
+                # 2-D convolution front-end (K13): W (kt, kf, C_in, C_out) + b (C_out), Keras
+                # 'tf' kernel layout; the slab keeps its channel-minor rows (F * C)
+                for k in ('F_in', 'C_in', 'C_out', 'kt', 'kf', 'st', 'sf'):
+                    setattr(s, k, int(st[k]))
+                s.clip, s.l2 = float(st['clip']), float(st.get('l2', 0.0))
+                s.F_out = -(-s.F_in // s.sf)
+                if f_real != s.F_in * s.C_in or f_pad != f_real:
+                    raise ValueError('conv stage: %d input features (a multiple of 4) expected, '
+                                     'got %d (padded %d)' % (s.F_in * s.C_in, f_real, f_pad))
+                if (s.F_out * s.C_out) % 4:
+                    raise ValueError('conv stage: F_out * C_out must be a multiple of 4')
+                nw = s.kt * s.kf * s.C_in * s.C_out
+                s.oW = take(nw)
+                s.ob = take(s.C_out)
+                segs += [(s.oW, _pad4(nw), s.l2), (s.ob, _pad4(s.C_out), 0.0)]
+                lim = math.sqrt(6.0 / (s.kt * s.kf * (s.C_in + s.C_out)))      # glorot_uniform
+                W = rs.uniform(-lim, lim, size=(s.kt, s.kf, s.C_in, s.C_out))
+                init.append((s, 'conv', [W.astype(np.float32), np.zeros(s.C_out, np.float32)]))
+                f_real = f_pad = s.F_out * s.C_out
             elif s.kind == 'dense':
                 s.n_out = st['n_out']
                 s.l2 = st.get('l2', 0.0)
@@ -267,6 +289,8 @@ class Model(object):
         self.packed = (_os.environ.get('ASR_GEMM_PREC', '1') != '0' and
                        (self._packed_mode == '1' or (self._packed_mode == 'auto' and widest >= 512)))
         self.num_classes = f_real
+        self.time_strides = [st.st for st in self.stages if st.kind == 'conv' and st.st > 1]
+        self._convs = {}
         self.n_params = off
         self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
         # gradients + 4 trailing floats: [0:2] carry this rank's recurrent-kernel timeout flags
@@ -288,7 +312,7 @@ class Model(object):
         for st in self.stages:
             if st is s:
                 break
-            if st.kind in ('dense', 'bilstm'):
+            if st.kind in ('dense', 'bilstm', 'conv'):
                 prev = st
         if prev is not None and prev.kind == 'bilstm' and prev.Hp != prev.H:
             idx = np.concatenate([np.arange(prev.H), prev.Hp + np.arange(prev.H)])
@@ -301,7 +325,12 @@ class Model(object):
         host = self.params.detach().cpu().numpy().copy()
         it = iter(weights)
         for s in self.stages:
-            if s.kind == 'dense':
+            if s.kind == 'conv':
+                W, b = np.asarray(next(it), np.float32), np.asarray(next(it), np.float32)
+                assert W.shape == (s.kt, s.kf, s.C_in, s.C_out), W.shape
+                host[s.oW:s.oW + W.size] = W.ravel()
+                host[s.ob:s.ob + s.C_out] = b
+            elif s.kind == 'dense':
                 W, b = np.asarray(next(it), np.float32), np.asarray(next(it), np.float32)
                 rows = self._real_rows(s)
                 Wp = np.zeros((s.f_in_pad, s.n_out), np.float32)
@@ -348,7 +377,11 @@ class Model(object):
     def _unpack(self, flat):
         out = []
         for s in self.stages:
-            if s.kind == 'dense':
+            if s.kind == 'conv':
+                nw = s.kt * s.kf * s.C_in * s.C_out
+                out += [flat[s.oW:s.oW + nw].reshape(s.kt, s.kf, s.C_in, s.C_out).copy(),
+                        flat[s.ob:s.ob + s.C_out].copy()]
+            elif s.kind == 'dense':
                 rows = self._real_rows(s)
                 W = flat[s.oW:s.oW + s.f_in_pad * s.n_out].reshape(s.f_in_pad, s.n_out)[rows]
                 out += [W.copy(), flat[s.ob:s.ob + s.n_out].copy()]
@@ -511,12 +544,12 @@ class Model(object):
             self.overlap = not self._recurrence_fills_chip(n_pad)
         self._pipe_now = self._pipeline_on(n_pad)
         # (the packed-operand GEMMs take whole slabs: no frame-range pipelining with them)
-        pipe = (self._pipe_now and self._pipe is not None and self.lstm_mode == 0 and T >= 16
+        t_rec = self.out_frames(T)              # frames the recurrent stack sees
+        pipe = (self._pipe_now and self._pipe is not None and self.lstm_mode == 0 and t_rec >= 16
                 and not self.packed)
         self._pipe_now = self._pipe_now and not self.packed
         if n_valid == 1 and not need_grad:      # one utterance: the tile-free kernel, whole layers
             pipe = False
-        S = (self._pipe_split16 * T) // 16
         pre = {}
         if any(self._stage_packed(st) for st in self.stages):
             self._pack_weights()
@@ -532,7 +565,21 @@ class Model(object):
             return None, None
         for si, s in enumerate(self.stages):
             rec = {'in': a}
-            if s.kind == 'noise':
+            T = a.shape[0]                      # (a time-strided convolution shortens the slab)
+            rows = T * n_pad
+            S = (self._pipe_split16 * T) // 16
+            if s.kind == 'reshape':
+                pass
+            elif s.kind == 'conv':
+                op = self._conv_op(si, s, T, n_pad)
+                z = self._buf('convz%d' % si, (op.T_out, n_pad, s.F_out * s.C_out))
+                y = self._buf('convy%d' % si, (op.T_out, n_pad, s.F_out * s.C_out)) \
+                    if s.clip > 0 else z
+                nw = s.kt * s.kf * s.C_in * s.C_out
+                op.fwd(a.contiguous(), self._view(s.oW, nw), self._view(s.ob, s.C_out), z, y)
+                rec.update(op=op, z=z)
+                a = y
+            elif s.kind == 'noise':
                 if training and s.value > 0:
                     out = self._buf('noise%d' % si, a.shape)
                     a = ops.gaussian_noise(a, out, s.value, self.rng_seed, 4 * si, self._step)
@@ -621,6 +668,33 @@ class Model(object):
             rec['out'] = a
             self._acts.append(rec)
         return a
+
+    def _conv_op(self, si, s, T, n_pad):
+        """The ops.Conv2d of stage si for this slab shape (owns the layer's workspace: the
+        packed planes of x and dz live there between the forward and backward calls)."""
+        key = (si, int(T), int(n_pad))
+        op = self._convs.get(key)
+        if op is None:
+            for k in [k for k in self._convs if k[0] == si]:
+                del self._convs[k]
+            op = self._convs[key] = ops.Conv2d(T, n_pad, s.F_in, s.C_in, s.C_out, s.kt, s.kf,
+                                               s.st, s.sf, s.clip, self.device)
+        return op
+
+    def out_frames(self, T):
+        """Frames of the logits for T input frames (ceil(T / st) per time-strided layer)."""
+        for st in self.time_strides:
+            T = -(-int(T) // st)
+        return int(T)
+
+    def out_lengths(self, lens):
+        """inputs_length -> lengths on the logits' time axis (host array or device tensor)."""
+        for st in self.time_strides:
+            if torch.is_tensor(lens):
+                lens = torch.div(lens + (st - 1), st, rounding_mode='floor').to(lens.dtype)
+            else:
+                lens = -(-np.asarray(lens) // st)
+        return lens
 
     def _recurrence_fills_chip(self, n_pad):
         if self.device.type != 'cuda':
@@ -782,8 +856,23 @@ class Model(object):
                     da = ops.axpby(s.coef, da, 0.0, da, self._buf('dmerge%d' % si, da.shape))
                 skip_grads[s.skip] = da
                 continue
-            first = not any(st.kind in ('dense', 'bilstm') for st in self.stages[:si])
-            if s.kind == 'noise':
+            first = not any(st.kind in ('dense', 'bilstm', 'conv') for st in self.stages[:si])
+            if s.kind in ('noise', 'reshape'):
+                continue
+            if s.kind == 'conv':
+                op, z = rec['op'], rec['z']
+                nw = s.kt * s.kf * s.C_in * s.C_out
+                da = da.contiguous()
+                dz_ready = False
+                if not first:
+                    dx = self._buf('da_s%d' % si, a_in.shape)
+                    op.dgrad(da, z, self._view(s.oW, nw), dx)
+                    dz_ready = True
+                # (x planes: still in the layer's workspace from the forward call)
+                op.wgrad(a_in, da, z, self._gview(s.oW, nw), self._gview(s.ob, s.C_out),
+                         reuse_x=True, reuse_dz=dz_ready)
+                if not first:
+                    da = dx
                 continue
             if s.kind == 'dropout':
                 if first:               # nothing trainable upstream: no gradient needed there
@@ -1002,6 +1091,7 @@ class Model(object):
         N = len(labels)
         lmax = max([len(l) for l in labels] + [1])
         lab = np.zeros((N, lmax), np.int32)
+        seq_len = self.out_lengths(np.asarray(seq_len).reshape(-1))   # on the logits' time axis
         for n, l in enumerate(labels):
             l = np.asarray(l, np.int64).reshape(-1)
             need = len(l) + int(np.sum(l[1:] == l[:-1])) if len(l) else 0
@@ -1073,6 +1163,7 @@ class Model(object):
         synchronisation: forward, CTC, BPTT, (RCCL all-reduce), clip + update, greedy
         decode for the LER metric.  Returns device tensors (ctc, decoded, lengths)."""
         self._maybe_retry_persistent()
+        sl = self.out_lengths(sl)
         ctc, logits, sl = self.loss_and_grads_device(slab, lab, lab_len, sl, N, training=True,
                                                      n_global=N * world)
         self._allreduce()
@@ -1281,7 +1372,7 @@ class Model(object):
         logits = self.forward(slab, training=False, need_grad=False, n_valid=N)
         if self.decoder is None:
             return logits[:, :N].permute(1, 0, 2).contiguous().cpu().numpy()
-        sl = torch.as_tensor(lens.astype(np.int32)).to(self.device)
+        sl = torch.as_tensor(np.asarray(self.out_lengths(lens)).astype(np.int32)).to(self.device)
         if self.decoder.get('is_greedy', True):
             dec, dlen = ops.ctc_greedy(logits, sl, N)
             dec, dlen = dec.cpu().numpy(), dlen.cpu().numpy()

@@ -20,13 +20,16 @@ class l2(object):
 
 
 class Sym(object):
-    """A symbolic (N, T, features) tensor: knows the stage that produced it."""
+    """A symbolic (N, T, features) tensor: knows the stage that produced it.  ``fc`` is set
+    while the tensor is viewed as an (N, T, F, C) image (between ``Reshape`` and the flattening
+    ``Reshape`` of the convolution front-end): features = F * C, channel minor."""
 
-    def __init__(self, features, producer=None, parent=None, name=None):
+    def __init__(self, features, producer=None, parent=None, name=None, fc=None):
         self.features = features
         self.producer = producer
         self.parent = parent
         self.name = name
+        self.fc = fc
 
     def chain(self):
         out, cur = [], self
@@ -43,7 +46,10 @@ def Input(name=None, shape=None, dtype='float32', sparse=False):
 
 class Layer(object):
     def __call__(self, x):
-        return Sym(self.out_features(x.features), producer=self, parent=x)
+        return Sym(self.out_features(x.features), producer=self, parent=x, fc=self.out_fc(x))
+
+    def out_fc(self, x):
+        return x.fc
 
     def out_features(self, f):
         return f
@@ -144,3 +150,70 @@ def merge(inputs, mode=None):
     if a.features != b.features:
         raise ValueError('merge: widths differ (%s vs %s)' % (a.features, b.features))
     return Merge(mode, b)(a)
+
+
+
+def clipped_relu(max_value=20.0):
+    """The reference's activation of its (dead) Deep Speech factories: ``relu(x,
+    max_value=max_value)`` = min(max(x, 0), max_value) (core/models.py:116-117)."""
+    return ('clipped_relu', float(max_value))
+
+
+class Reshape(Layer):
+    """keras.layers.Reshape on the feature axes only: ``Reshape((-1, F, C))`` views the
+    (N, T, F*C) features as an (N, T, F, C) image for Convolution2D, ``Reshape((-1, F*C))``
+    flattens it again.  Channel-minor memory order either way: no data moves."""
+
+    def __init__(self, target_shape):
+        self.target = tuple(int(v) for v in target_shape)
+        if len(self.target) not in (2, 3) or self.target[0] != -1:
+            raise NotImplementedError('Reshape(%r): only (-1, F, C) and (-1, F*C)' % (target_shape,))
+
+    def out_features(self, f):
+        n = int(np_prod(self.target[1:]))
+        if n != f:
+            raise ValueError('Reshape: %d features into %r' % (f, self.target))
+        return f
+
+    def out_fc(self, x):
+        return (self.target[1], self.target[2]) if len(self.target) == 3 else None
+
+
+def np_prod(t):
+    out = 1
+    for v in t:
+        out *= int(v)
+    return out
+
+
+class Convolution2D(Layer):
+    """keras.layers.Convolution2D(nb_filter, nb_row, nb_col, subsample=(st, sf),
+    border_mode='same', dim_ordering='tf', activation=clipped_relu(...)) over (time, frequency)
+    of an (N, T, F, C) tensor.  NO REFERENCE COUNTERPART (README.md:118 lists Deep Speech 2 as
+    TODO): the layer of BASELINE.json configs[2]'s "2 conv front-end", defined in
+    include/asr_hip.h (K13) and oracle/conv.py."""
+
+    def __init__(self, nb_filter, nb_row, nb_col, subsample=(1, 1), border_mode='same',
+                 activation=None, W_regularizer=None, dim_ordering='tf', **kwargs):
+        if border_mode != 'same' or dim_ordering != 'tf':
+            raise NotImplementedError("Convolution2D: border_mode='same', dim_ordering='tf' only")
+        if activation is None or activation == 'linear':
+            self.clip = 0.0
+        elif isinstance(activation, tuple) and activation[0] == 'clipped_relu':
+            self.clip = float(activation[1])
+        else:
+            raise NotImplementedError('Convolution2D activation %r' % (activation,))
+        self.nb_filter, self.kt, self.kf = int(nb_filter), int(nb_row), int(nb_col)
+        self.st, self.sf = int(subsample[0]), int(subsample[1])
+        self.l2 = W_regularizer.l2 if W_regularizer is not None else 0.0
+
+    def out_fc(self, x):
+        if x.fc is None:
+            raise ValueError('Convolution2D needs an (N, T, F, C) input: Reshape((-1, F, C)) first')
+        return (-(-x.fc[0] // self.sf), self.nb_filter)
+
+    def __call__(self, x):
+        fc = self.out_fc(x)
+        self.in_fc = x.fc
+        return Sym(fc[0] * fc[1], producer=self, parent=x, fc=fc)
+

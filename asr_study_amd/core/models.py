@@ -11,7 +11,7 @@ surface; here that object is core.engine.Model, which runs on the HIP kernels.
 from . import ctc_utils
 from .engine import Model
 from .layers import (Input, GaussianNoise, TimeDistributed, Dense, LSTM, Bidirectional,
-                     Dropout, Merge, merge, l2)
+                     Dropout, Merge, merge, l2, Reshape, Convolution2D, clipped_relu)
 
 
 def ctc_model(inputs, output, **kwargs):
@@ -40,6 +40,12 @@ def ctc_model(inputs, output, **kwargs):
             if not src:
                 raise ValueError('merge: the skip input is not on the path from inputs')
             spec.append({'type': 'merge', 'mode': layer.mode, 'skip': src[0]})
+        elif isinstance(layer, Reshape):
+            spec.append({'type': 'reshape', 'target': list(layer.target)})   # a view: no data moves
+        elif isinstance(layer, Convolution2D):
+            spec.append({'type': 'conv', 'F_in': layer.in_fc[0], 'C_in': layer.in_fc[1],
+                         'C_out': layer.nb_filter, 'kt': layer.kt, 'kf': layer.kf,
+                         'st': layer.st, 'sf': layer.sf, 'clip': layer.clip, 'l2': layer.l2})
         elif isinstance(layer, GaussianNoise):
             spec.append({'type': 'noise', 'value': layer.sigma})
         elif isinstance(layer, Dropout):
@@ -130,3 +136,41 @@ def brsmv1(num_features=39, num_classes=28, num_hiddens=256, num_layers=5,
         input_std_noise=input_std_noise, weight_decay=weight_decay, residual=residual,
         layer_norm=layer_norm, mi=mi, activation=activation)}
     return model
+
+
+def deep_speech2(num_features=80, num_classes=28, num_hiddens=512, num_layers=5,
+                 conv_filters=32, conv_kernels=((11, 41), (11, 21)), conv_strides=((2, 2), (1, 2)),
+                 max_value=20, dropout=0.2, weight_decay=1e-4, input_std_noise=.0, **kw):
+    """BASELINE.json configs[2]: "DeepSpeech2-style 5xBiLSTM(512) + 2 conv front-end, 80-dim
+    log-mel".  NO REFERENCE COUNTERPART: the reference lists Deep Speech 2 as TODO
+    (README.md:118) and its ``deep_speech`` factory (core/models.py:148-214) is dead code
+    (un-imported Keras names) without convolutions.  Built from the reference's own pieces:
+    brsmv1's recurrent stack and regularisers (core/models.py:217-281), the ``clipped_relu``
+    of its Deep Speech factories (:116-117), and two Keras Convolution2D layers over (time,
+    frequency) with DeepSpeech2's filter shapes -- 32 x (11 x 41) stride (2, 2) and
+    32 x (11 x 21) stride (1, 2), 'same' padding -- so the recurrent stack sees T/2 frames of
+    F/4 * 32 features.  ``inputs_length`` is mapped to ceil(len / 2) inside the model."""
+    x = Input(name='inputs', shape=(None, num_features))
+    o = x
+    if input_std_noise is not None:
+        o = GaussianNoise(input_std_noise)(o)
+    o = Reshape((-1, num_features, 1))(o)
+    for (kt, kf), (st, sf) in zip(conv_kernels, conv_strides):
+        o = Convolution2D(conv_filters, kt, kf, subsample=(st, sf), border_mode='same',
+                          activation=clipped_relu(max_value),
+                          W_regularizer=l2(weight_decay))(o)
+    o = Reshape((-1, o.features))(o)
+    for _ in range(num_layers):
+        o = Bidirectional(LSTM(num_hiddens, return_sequences=True,
+                               W_regularizer=l2(weight_decay), U_regularizer=l2(weight_decay),
+                               dropout_W=dropout, dropout_U=dropout))(o)
+    o = TimeDistributed(Dense(num_classes, W_regularizer=l2(weight_decay)))(o)
+    model = ctc_model(x, o, **kw)
+    model.config = {'name': 'deep_speech2', 'kwargs': dict(
+        num_features=num_features, num_classes=num_classes, num_hiddens=num_hiddens,
+        num_layers=num_layers, conv_filters=conv_filters,
+        conv_kernels=[list(k) for k in conv_kernels], conv_strides=[list(k) for k in conv_strides],
+        max_value=max_value, dropout=dropout, weight_decay=weight_decay,
+        input_std_noise=input_std_noise)}
+    return model
+

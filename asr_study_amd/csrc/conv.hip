@@ -1,0 +1,449 @@
+// K13  2-D convolution front-end (BASELINE.json configs[2]: "2 conv front-end") -- gfx950.
+//
+// NO REFERENCE COUNTERPART: the reference lists Deep Speech 2 as TODO (README.md:118) and its
+// deep_speech factory (core/models.py:148-214) has no convolution.  The op is Keras-1.2.2
+// Convolution2D(border_mode='same', dim_ordering='tf') + the reference's clipped ReLU
+// (core/models.py:116) on the (N, T, F, C) view of the time-major feature slab; see
+// include/asr_hip.h (K13) for the contract.
+//
+// How the convolution becomes the packed split-fp16 GEMM of K4 without an im2col buffer:
+//   * over FREQUENCY it is folded into one banded matrix per time tap,
+//       band[dt][(fi, ci)][(fo, co)] = W[dt][fi - sf fo + pf][ci][co]   (0 outside the filter),
+//     rebuilt from W every step by conv_band_kernel (a few MB) and packed into planes;
+//   * over TIME it is the SEGMENTED reduction range of asr_gemm_hl: output row (t', n) of tap dt
+//     reads the packed input planes of frame st t' + dt - pt -- the same planes, dt frames on.
+//     conv_pack_kernel writes the input planes in a "phase" layout (frames t = st s + r of phase
+//     r are consecutive slots s, zero slots where t is outside the slab: the 'same' padding), so
+//     that every tap is a constant row shift of the planes for any time stride;
+//   * the weight gradient is one K-major GEMM per tap on the SAME planes (x^T dz reduces over
+//     the plane rows), giving the gradient of the band, which conv_band_reduce_kernel folds
+//     back onto the filter taps.
+// The band is ~kf / F_in dense (21 of 40, 41 of 80 here), so the matrix pipes execute about
+// twice the algorithmic flops of the convolution -- at the rate of the tuned 256 x 256 kernel
+// (bench.py reports the ALGORITHMIC rate).  All kernels besides the GEMMs are HBM-bound
+// element-wise passes over the activation slabs.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 hx8 __attribute__((ext_vector_type(8)));
+
+struct Geo {
+  int T_in, n_pad, F_in, C_in, C_out, kt, kf, st, sf;
+  int T_out, F_out, pt, pf;       // 'same' padding before (TensorFlow's rule)
+  int Ki, Ko, Ki_p, Ko_p;         // row widths of x / z and their plane widths (multiples of 32)
+  int qmin, S;                    // phase layout of the x planes: slots s - qmin in [0, S)
+  int padb, pada;                 // zero frames before / behind the dz planes
+  long long M;                    // output rows T_out * n_pad
+};
+
+__host__ __device__ inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+bool make_geo(const asr_conv2d_args* a, Geo* g) {
+  if (!a || a->T_in <= 0 || a->n_pad <= 0 || a->n_pad % 16 || a->F_in <= 0 || a->C_in <= 0 ||
+      a->C_out <= 0 || a->kt <= 0 || a->kt > 16 || a->kf <= 0 || a->st <= 0 || a->sf <= 0)
+    return false;
+  g->T_in = a->T_in; g->n_pad = a->n_pad; g->F_in = a->F_in; g->C_in = a->C_in;
+  g->C_out = a->C_out; g->kt = a->kt; g->kf = a->kf; g->st = a->st; g->sf = a->sf;
+  g->T_out = (a->T_in + a->st - 1) / a->st;
+  g->F_out = (a->F_in + a->sf - 1) / a->sf;
+  int tot = (g->T_out - 1) * a->st + a->kt - a->T_in;
+  g->pt = (tot > 0 ? tot : 0) / 2;
+  tot = (g->F_out - 1) * a->sf + a->kf - a->F_in;
+  g->pf = (tot > 0 ? tot : 0) / 2;
+  g->Ki = a->F_in * a->C_in; g->Ko = g->F_out * a->C_out;
+  if (g->Ki % 4 || g->Ko % 4) return false;        // 16-byte rows (pack, GEMM epilogue)
+  g->Ki_p = (g->Ki + 31) / 32 * 32; g->Ko_p = (g->Ko + 31) / 32 * 32;
+  g->qmin = floordiv(0 - g->pt, a->st);
+  const int qmax = floordiv(a->kt - 1 - g->pt, a->st);
+  g->S = g->T_out + qmax - g->qmin;
+  g->padb = a->kt - 1 - g->pt; g->pada = g->pt;
+  if (g->padb < 0) g->padb = 0;
+  g->M = (long long)g->T_out * a->n_pad;
+  return true;
+}
+
+// plane row of tap dt's first operand row (output frame 0, sample 0) in the phase layout
+inline long long tap_row(const Geo& g, int dt) {
+  const int q = floordiv(dt - g.pt, g.st), r = (dt - g.pt) - q * g.st;
+  return ((long long)r * g.S + (q - g.qmin)) * g.n_pad;
+}
+
+struct Ws {                       // byte offsets into the caller's workspace
+  size_t scal, xpl, dzpl, dzf, band_f, band_dg, bandf_pl, banddg_pl, bias_band, dband, gemm, colsum, end;
+  size_t gemm_bytes, colsum_bytes;
+};
+
+int wgrad_splits(const Geo& g) {
+  const int tiles = ((g.Ki + 255) / 256) * ((g.Ko + 255) / 256);
+  long long s = (1024 + tiles - 1) / tiles;
+  if (s > 64) s = 64;
+  if (s > g.M / 256) s = g.M / 256;
+  return s < 1 ? 1 : (int)s;
+}
+
+Ws make_ws(const Geo& g) {
+  Ws w;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += asr_align_up(bytes, 256); return at; };
+  w.scal = take(64 * sizeof(float));
+  w.xpl = take((size_t)g.st * g.S * g.n_pad * g.Ki_p * 4);
+  w.dzpl = take((size_t)(g.padb + g.T_out + g.pada) * g.n_pad * g.Ko_p * 4);
+  w.dzf = take((size_t)g.M * g.Ko * 4);
+  w.band_f = take((size_t)g.kt * g.Ki_p * g.Ko * 4);
+  w.band_dg = take((size_t)g.Ki * g.kt * g.Ko_p * 4);
+  w.bandf_pl = take((size_t)g.Ko * g.kt * g.Ki_p * 4);
+  w.banddg_pl = take((size_t)g.Ki * g.kt * g.Ko_p * 4);
+  w.bias_band = take((size_t)g.Ko * 4);
+  w.dband = take((size_t)g.kt * g.Ki * g.Ko * 4);
+  w.gemm_bytes = asr_align_up((size_t)wgrad_splits(g) * g.Ki * g.Ko * sizeof(float), 256);
+  w.gemm = take(w.gemm_bytes);
+  w.colsum_bytes = asr_colsum_workspace_bytes((int)g.M, g.Ko);
+  w.colsum = take(w.colsum_bytes);
+  w.end = o;
+  return w;
+}
+
+// the power-of-two pre-scale of asr_pack_hl (gemm.hip, pow2_scale): max |x| -> [2^8, 2^9)
+__device__ __forceinline__ float pow2_scale_of(const float* absmax) {
+  if (absmax == nullptr) return 1.f;
+  const unsigned b = __float_as_uint(*absmax);
+  int e = (int)((b >> 23) & 0xff) - 126;
+  if ((b & 0x7fffffffu) == 0u) return 1.f;
+  int k = 9 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  return __uint_as_float((unsigned)(127 + k) << 23);
+}
+
+// ---- band[dt][(fi,ci)][(fo,co)] from W, in the two arrangements the GEMMs read:
+//   band_f  (kt * Ki_p rows, Ko cols)      row dt Ki_p + (fi,ci)    -> B of the forward GEMM
+//   band_dg (Ki rows, kt * Ko_p cols)      col dt Ko_p + (fo,co)    -> B of the dgrad GEMM
+// plus bias_band[(fo,co)] = bias[co].  One thread per (dt, k, j) of band_f (pad rows -> 0).
+__global__ void __launch_bounds__(256)
+conv_band_kernel(Geo g, const float* __restrict__ W, const float* __restrict__ bias,
+                 float* __restrict__ band_f, float* __restrict__ band_dg,
+                 float* __restrict__ bias_band) {
+  const size_t total = (size_t)g.kt * g.Ki_p * g.Ko;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % g.Ko);
+    const size_t rk = idx / g.Ko;
+    const int k = (int)(rk % g.Ki_p), dt = (int)(rk / g.Ki_p);
+    float v = 0.f;
+    if (k < g.Ki) {
+      const int fi = k / g.C_in, ci = k % g.C_in, fo = j / g.C_out, co = j % g.C_out;
+      const int df = fi - g.sf * fo + g.pf;
+      if (df >= 0 && df < g.kf) v = W[(((size_t)dt * g.kf + df) * g.C_in + ci) * g.C_out + co];
+      band_dg[(size_t)k * g.kt * g.Ko_p + (size_t)dt * g.Ko_p + j] = v;
+    }
+    band_f[idx] = v;
+    if (idx < (size_t)g.Ko) bias_band[idx] = bias ? bias[idx % g.C_out] : 0.f;
+  }
+}
+
+// ---- activation slab -> interleaved split-fp16 planes (the r-plane format of asr_pack_hl: a
+// row is K_p / 16 groups of [16 hi][16 lo]); one thread per (plane row, group of 16).
+//   MODE 0: x planes in the phase layout (row = (phase r, slot s, sample n) <- frame
+//           st (s + qmin) + r, zeros outside the slab);
+//   MODE 1: dz planes, dz = dy (.) act'(z), rows (padb + t', n) with zero frames before and
+//           behind; also writes dz as fp32 (bias gradient).
+template <int MODE>
+__global__ void __launch_bounds__(256)
+conv_pack_kernel(Geo g, const float* __restrict__ src, const float* __restrict__ zpre,
+                 float clip, const float* __restrict__ absmax, float* __restrict__ scale_out,
+                 _Float16* __restrict__ planes, float* __restrict__ dzf) {
+  const int K = MODE == 0 ? g.Ki : g.Ko, K_p = MODE == 0 ? g.Ki_p : g.Ko_p;
+  const int groups = K_p / 16;
+  const long long frames = MODE == 0 ? (long long)g.st * g.S : (long long)g.padb + g.T_out + g.pada;
+  const size_t total = (size_t)frames * g.n_pad * groups;
+  const float s = pow2_scale_of(absmax);
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int grp = (int)(idx % groups);
+    const size_t row = idx / groups;
+    const int n = (int)(row % g.n_pad);
+    const long long fr = (long long)(row / g.n_pad);
+    long long t;                                   // source frame, or out of range
+    if (MODE == 0) {
+      const int r = (int)(fr / g.S), sl = (int)(fr % g.S);
+      t = (long long)g.st * (sl + g.qmin) + r;
+      if (t >= g.T_in) t = -1;
+    } else {
+      t = fr - g.padb;
+      if (t >= g.T_out) t = -1;
+    }
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.f;
+    const int c0 = grp * 16;
+    if (t >= 0 && c0 < K) {
+      const size_t base = ((size_t)t * g.n_pad + n) * K + c0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (c0 + 4 * q < K) {                      // K % 4 == 0: whole quads
+          const float4 a = *reinterpret_cast<const float4*>(src + base + 4 * q);
+          v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+          if (MODE == 1) {
+            if (clip > 0.f) {
+              const float4 zz = *reinterpret_cast<const float4*>(zpre + base + 4 * q);
+              if (!(zz.x > 0.f && zz.x < clip)) v[4 * q] = 0.f;
+              if (!(zz.y > 0.f && zz.y < clip)) v[4 * q + 1] = 0.f;
+              if (!(zz.z > 0.f && zz.z < clip)) v[4 * q + 2] = 0.f;
+              if (!(zz.w > 0.f && zz.w < clip)) v[4 * q + 3] = 0.f;
+            }
+            *reinterpret_cast<float4*>(dzf + base + 4 * q) =
+                make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+          }
+        }
+      }
+    }
+    hx8 hi0, hi1, lo0, lo1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x0 = v[e] * s, x1 = v[8 + e] * s;
+      const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+      hi0[e] = h0; hi1[e] = h1;
+      lo0[e] = (_Float16)(x0 - (float)h0); lo1[e] = (_Float16)(x1 - (float)h1);
+    }
+    _Float16* dst = planes + (row * (size_t)(2 * K_p) + (size_t)grp * 32);
+    *reinterpret_cast<hx8*>(dst) = hi0;
+    *reinterpret_cast<hx8*>(dst + 8) = hi1;
+    *reinterpret_cast<hx8*>(dst + 16) = lo0;
+    *reinterpret_cast<hx8*>(dst + 24) = lo1;
+  }
+}
+
+// y = min(max(z, 0), clip)
+__global__ void __launch_bounds__(256)
+conv_act_kernel(const float* __restrict__ z, float* __restrict__ y, size_t n4, float clip) {
+  const float4* z4 = reinterpret_cast<const float4*>(z);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = z4[i];
+    v.x = fminf(fmaxf(v.x, 0.f), clip); v.y = fminf(fmaxf(v.y, 0.f), clip);
+    v.z = fminf(fmaxf(v.z, 0.f), clip); v.w = fminf(fmaxf(v.w, 0.f), clip);
+    y4[i] = v;
+  }
+}
+
+// dW[dt][df][ci][co] = sum_fo dband[dt][(sf fo + df - pf, ci)][(fo, co)] (float64 accumulation,
+// fixed order); db[co] = sum_fo colsum[(fo, co)].  One thread per filter element.
+__global__ void __launch_bounds__(256)
+conv_band_reduce_kernel(Geo g, const float* __restrict__ dband, const float* __restrict__ colsum,
+                        float* __restrict__ dW, float* __restrict__ db) {
+  const size_t total = (size_t)g.kt * g.kf * g.C_in * g.C_out;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) {
+    const int co = (int)(idx % g.C_out);
+    size_t r = idx / g.C_out;
+    const int ci = (int)(r % g.C_in); r /= g.C_in;
+    const int df = (int)(r % g.kf), dt = (int)(r / g.kf);
+    double acc = 0.0;
+    for (int fo = 0; fo < g.F_out; ++fo) {
+      const int fi = g.sf * fo + df - g.pf;
+      if (fi < 0 || fi >= g.F_in) continue;
+      acc += (double)dband[((size_t)dt * g.Ki + (size_t)fi * g.C_in + ci) * g.Ko +
+                           (size_t)fo * g.C_out + co];
+    }
+    dW[idx] = (float)acc;
+  }
+  if (db && idx < (size_t)g.C_out) {
+    double acc = 0.0;
+    for (int fo = 0; fo < g.F_out; ++fo) acc += (double)colsum[(size_t)fo * g.C_out + idx];
+    db[idx] = (float)acc;
+  }
+}
+
+int grid_for(size_t items) {
+  size_t b = (items + 255) / 256;
+  if (b > 16384) b = 16384;
+  return b < 1 ? 1 : (int)b;
+}
+
+bool ws_ok(const Ws& w, void* workspace, size_t ws_bytes) {
+  if (workspace && ws_bytes >= w.end && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0) return true;
+  asr_set_error("conv2d: workspace %zu < %zu bytes (or not 256-byte aligned)", ws_bytes, w.end);
+  return false;
+}
+
+// W -> band matrices -> packed planes (both arrangements), bias_band
+int build_band(const Geo& g, const asr_conv2d_args* a, const Ws& w, char* ws, bool need_f,
+               bool need_dg, hipStream_t stream) {
+  float* scal = reinterpret_cast<float*>(ws + w.scal);
+  float* band_f = reinterpret_cast<float*>(ws + w.band_f);
+  float* band_dg = reinterpret_cast<float*>(ws + w.band_dg);
+  ASR_CHECK_HIP(hipMemsetAsync(band_dg, 0, (size_t)g.Ki * g.kt * g.Ko_p * 4, stream));
+  hipLaunchKernelGGL(conv_band_kernel, dim3(grid_for((size_t)g.kt * g.Ki_p * g.Ko)), dim3(256), 0,
+                     stream, g, a->W, a->bias, band_f, band_dg,
+                     reinterpret_cast<float*>(ws + w.bias_band));
+  ASR_CHECK_LAUNCH();
+  int rc = asr_absmax(a->W, (int64_t)g.kt * g.kf * g.C_in * g.C_out, scal + 2, stream);
+  if (rc) return rc;
+  asr_pack_args p;
+  if (need_f) {
+    p = asr_pack_args{};
+    p.src = band_f; p.rows = g.kt * g.Ki_p; p.cols = g.Ko; p.ld = g.Ko;
+    p.absmax = scal + 2; p.scale_out = scal + 10;
+    p.c_hl = ws + w.bandf_pl; p.ldk_c = g.kt * g.Ki_p;
+    rc = asr_pack_hl(&p, stream);
+    if (rc) return rc;
+  }
+  if (need_dg) {
+    p = asr_pack_args{};
+    p.src = band_dg; p.rows = g.Ki; p.cols = g.kt * g.Ko_p; p.ld = g.kt * g.Ko_p;
+    p.absmax = scal + 2; p.scale_out = scal + 11;
+    p.r_hl = ws + w.banddg_pl; p.ldk_r = g.kt * g.Ko_p;
+    rc = asr_pack_hl(&p, stream);
+    if (rc) return rc;
+  }
+  return ASR_OK;
+}
+
+int pack_x(const Geo& g, const asr_conv2d_args* a, const Ws& w, char* ws, hipStream_t stream) {
+  float* scal = reinterpret_cast<float*>(ws + w.scal);
+  const int rc = asr_absmax(a->x, (int64_t)g.T_in * g.n_pad * g.Ki, scal + 0, stream);
+  if (rc) return rc;
+  const size_t items = (size_t)g.st * g.S * g.n_pad * (g.Ki_p / 16);
+  hipLaunchKernelGGL(conv_pack_kernel<0>, dim3(grid_for(items)), dim3(256), 0, stream, g, a->x,
+                     (const float*)nullptr, 0.f, scal + 0, scal + 8,
+                     reinterpret_cast<_Float16*>(ws + w.xpl), (float*)nullptr);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}
+
+int pack_dz(const Geo& g, const asr_conv2d_args* a, const Ws& w, char* ws, hipStream_t stream) {
+  float* scal = reinterpret_cast<float*>(ws + w.scal);
+  const int rc = asr_absmax(a->dy, (int64_t)g.M * g.Ko, scal + 1, stream);   // |dz| <= |dy|
+  if (rc) return rc;
+  const size_t items = (size_t)(g.padb + g.T_out + g.pada) * g.n_pad * (g.Ko_p / 16);
+  hipLaunchKernelGGL(conv_pack_kernel<1>, dim3(grid_for(items)), dim3(256), 0, stream, g, a->dy,
+                     a->z, a->clip, scal + 1, scal + 9,
+                     reinterpret_cast<_Float16*>(ws + w.dzpl), reinterpret_cast<float*>(ws + w.dzf));
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}
+
+}  // namespace
+
+extern "C" int asr_conv2d_out_shape(const asr_conv2d_args* a, int* T_out, int* F_out) {
+  Geo g;
+  ASR_CHECK_ARG(make_geo(a, &g), "conv2d: bad geometry (n_pad %% 16, kt <= 16, F*C %% 4 == 0)");
+  if (T_out) *T_out = g.T_out;
+  if (F_out) *F_out = g.F_out;
+  return ASR_OK;
+}
+
+extern "C" size_t asr_conv2d_workspace_bytes(const asr_conv2d_args* a) {
+  Geo g;
+  if (!make_geo(a, &g)) return 0;
+  return make_ws(g).end;
+}
+
+extern "C" int asr_conv2d_fwd(const asr_conv2d_args* a, void* workspace, size_t ws_bytes,
+                              asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  Geo g;
+  ASR_CHECK_ARG(make_geo(a, &g), "conv2d: bad geometry (n_pad %% 16, kt <= 16, F*C %% 4 == 0)");
+  ASR_CHECK_ARG(a->x && a->W && a->z && (a->y || a->clip <= 0.f), "conv2d fwd: null pointer");
+  const Ws w = make_ws(g);
+  if (!ws_ok(w, workspace, ws_bytes)) return ASR_ERR_WORKSPACE;
+  char* ws = reinterpret_cast<char*>(workspace);
+  float* scal = reinterpret_cast<float*>(ws + w.scal);
+  int rc = build_band(g, a, w, ws, true, false, stream);
+  if (rc) return rc;
+  if (!a->reuse_x) { rc = pack_x(g, a, w, ws, stream); if (rc) return rc; }
+  asr_gemm_hl_args h = {};
+  h.M = (int)g.M; h.N = g.Ko; h.K = g.kt * g.Ki_p;
+  h.a_hl = ws + w.xpl; h.lda = g.Ki_p;
+  h.b_hl = ws + w.bandf_pl; h.ldb = g.kt * g.Ki_p;
+  h.a_scale = scal + 8; h.b_scale = scal + 10;
+  h.C = a->z; h.ldc = g.Ko; h.alpha = 1.f; h.beta = 0.f;
+  h.bias = reinterpret_cast<float*>(ws + w.bias_band);
+  h.a_seg_k = g.Ki_p;
+  for (int dt = 0; dt < g.kt; ++dt) h.a_seg_row[dt] = tap_row(g, dt);
+  rc = asr_gemm_hl(&h, nullptr, 0, stream);
+  if (rc) return rc;
+  if (a->clip > 0.f) {
+    const size_t n4 = (size_t)g.M * g.Ko / 4;
+    hipLaunchKernelGGL(conv_act_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, a->z, a->y, n4,
+                       a->clip);
+    ASR_CHECK_LAUNCH();
+  } else if (a->y && a->y != a->z) {
+    ASR_CHECK_HIP(hipMemcpyAsync(a->y, a->z, (size_t)g.M * g.Ko * 4, hipMemcpyDeviceToDevice, stream));
+  }
+  return ASR_OK;
+}
+
+extern "C" int asr_conv2d_dgrad(const asr_conv2d_args* a, void* workspace, size_t ws_bytes,
+                                asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  Geo g;
+  ASR_CHECK_ARG(make_geo(a, &g), "conv2d: bad geometry (n_pad %% 16, kt <= 16, F*C %% 4 == 0)");
+  ASR_CHECK_ARG(a->W && a->z && a->dy && a->dx, "conv2d dgrad: null pointer");
+  // the time-strided layer of the front-end is its first: nothing trainable lies upstream
+  ASR_CHECK_ARG(a->st == 1, "conv2d dgrad: time stride %d is not implemented (only the first "
+                "layer of the front-end is strided in time, and its input is data)", a->st);
+  const Ws w = make_ws(g);
+  if (!ws_ok(w, workspace, ws_bytes)) return ASR_ERR_WORKSPACE;
+  char* ws = reinterpret_cast<char*>(workspace);
+  float* scal = reinterpret_cast<float*>(ws + w.scal);
+  int rc = build_band(g, a, w, ws, false, true, stream);
+  if (rc) return rc;
+  if (!a->reuse_dz) { rc = pack_dz(g, a, w, ws, stream); if (rc) return rc; }
+  // dx[(t, n)] = sum_dt dz[(t - dt + pt, n)] band[dt]^T: tap dt reads the dz planes
+  // (kt - 1 - dt) frames below their first (zero-padded) frame
+  asr_gemm_hl_args h = {};
+  h.M = (int)g.M; h.N = g.Ki; h.K = g.kt * g.Ko_p;
+  h.a_hl = ws + w.dzpl; h.lda = g.Ko_p;
+  h.b_hl = ws + w.banddg_pl; h.ldb = g.kt * g.Ko_p;
+  h.a_scale = scal + 9; h.b_scale = scal + 11;
+  h.C = a->dx; h.ldc = g.Ki; h.alpha = 1.f; h.beta = 0.f;
+  h.a_seg_k = g.Ko_p;
+  for (int dt = 0; dt < g.kt; ++dt)
+    h.a_seg_row[dt] = (long long)(g.padb - (g.kt - 1 - g.pt) + (g.kt - 1 - dt)) * g.n_pad;
+  return asr_gemm_hl(&h, nullptr, 0, stream);
+}
+
+extern "C" int asr_conv2d_wgrad(const asr_conv2d_args* a, void* workspace, size_t ws_bytes,
+                                asr_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  Geo g;
+  ASR_CHECK_ARG(make_geo(a, &g), "conv2d: bad geometry (n_pad %% 16, kt <= 16, F*C %% 4 == 0)");
+  ASR_CHECK_ARG(a->x && a->z && a->dy && a->dW, "conv2d wgrad: null pointer");
+  const Ws w = make_ws(g);
+  if (!ws_ok(w, workspace, ws_bytes)) return ASR_ERR_WORKSPACE;
+  char* ws = reinterpret_cast<char*>(workspace);
+  float* scal = reinterpret_cast<float*>(ws + w.scal);
+  int rc;
+  if (!a->reuse_x) { rc = pack_x(g, a, w, ws, stream); if (rc) return rc; }
+  if (!a->reuse_dz) { rc = pack_dz(g, a, w, ws, stream); if (rc) return rc; }
+  float* dband = reinterpret_cast<float*>(ws + w.dband);
+  // d band[dt] (Ki x Ko) = X_dt^T dZ: both operands reduce over their plane ROWS (k_major)
+  for (int dt = 0; dt < g.kt; ++dt) {
+    asr_gemm_hl_args h = {};
+    h.M = g.Ki; h.N = g.Ko; h.K = (int)g.M;
+    h.a_hl = ws + w.xpl + (size_t)tap_row(g, dt) * g.Ki_p * 4; h.lda = g.Ki_p;
+    h.b_hl = ws + w.dzpl + (size_t)g.padb * g.n_pad * g.Ko_p * 4; h.ldb = g.Ko_p;
+    h.a_scale = scal + 8; h.b_scale = scal + 9;
+    h.C = dband + (size_t)dt * g.Ki * g.Ko; h.ldc = g.Ko; h.alpha = 1.f; h.beta = 0.f;
+    h.split_k = wgrad_splits(g);
+    h.k_major = 1;
+    rc = asr_gemm_hl(&h, ws + w.gemm, w.gemm_bytes, stream);
+    if (rc) return rc;
+  }
+  float* cs = nullptr;
+  if (a->db) {
+    // column sums of dz (fp32 copy written by the pack), folded over fo by the reduce kernel
+    cs = reinterpret_cast<float*>(ws + w.band_f);          // (free during wgrad: Ko floats)
+    rc = asr_colsum(reinterpret_cast<float*>(ws + w.dzf), (int)g.M, g.Ko, g.Ko, cs, 0.f,
+                    ws + w.colsum, w.colsum_bytes, stream);
+    if (rc) return rc;
+  }
+  const size_t items = (size_t)g.kt * g.kf * g.C_in * g.C_out;
+  hipLaunchKernelGGL(conv_band_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
+                     stream, g, dband, cs, a->dW, a->db);
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
+}

@@ -805,6 +805,17 @@ struct HlSrc {
   int rows;               // MN extent (plane rows in the row-major form, columns in k_major)
   unsigned extent;        // bytes addressable from p
 };
+// Segmented reduction range of the row-major A operand (asr_gemm_hl_args.a_seg_k): the K range
+// is the concatenation of segments of seg_k indices (a multiple of 32: whole slabs), segment i
+// read from the planes shifted by a byte offset -- the implicit im2col over time of
+// asr_conv2d_*: tap dt of a filter reads the activation planes dt frames further on.  The
+// loader adds adj[slab / slabs_per_segment] (= the segment's byte shift minus the bytes the
+// running reduction offset has advanced by then) to its offset; slab / sps is a multiply-shift
+// with a magic the host verified over the launch's slab range.  magic = 0: no segments.
+struct HlSeg {
+  unsigned magic;
+  unsigned adj[16];
+};
 __device__ __forceinline__ size_t hl_index(int row, int k, int ld) {      // half index of hi
   return (size_t)row * (2 * (size_t)ld) + (size_t)(k >> 4) * 32 + (k & 15);
 }
@@ -920,7 +931,7 @@ __device__ __forceinline__ int hl256_slot(int row, int kc) {      // half index 
   return row * 32 + ((kc ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 3);    // 0, 2, 3, 1
 }
 
-template <int NT>
+template <int NT, bool SEG = false>
 struct HlLoaderX {
   // One operand's share of a K slab: (NT / 2) rows x 128 bytes (the row's line: hi and lo of 32
   // reduction indices) = 4 NT 16-byte chunks; thread t takes chunks t + NT i, i < 4: row
@@ -935,7 +946,10 @@ struct HlLoaderX {
   int kq;                  // first reduction index of the thread's chunk within a slab
   int depth;               // reduction indices from the first slab on
   int rows_left;           // operand rows from the thread's first one on
-  __device__ __forceinline__ void init(const HlSrc& s, int row0, int kb, int ke) {
+  int g0;                  // index of the first slab (kb / 32): segments count from k = 0
+  const HlSeg* sg;         // segmented reduction range (kernel argument), or its magic is 0
+  __device__ __forceinline__ void init(const HlSrc& s, int row0, int kb, int ke,
+                                       const HlSeg* seg = nullptr) {
     const int tid = threadIdx.x;
     rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(s.p), 0, s.extent, 0x00020000);
     const int c = tid & 7;
@@ -944,10 +958,15 @@ struct HlLoaderX {
     rows_left = s.rows - row0 - (tid >> 3);
     off = (unsigned)((hl_index(row0 + (tid >> 3), kb, s.ld) + 8 * c) * 2);
     row_step = (unsigned)(NT / 8) * (unsigned)s.ld * 4u;
+    g0 = kb / HBK;
+    sg = seg;
   }
   // (the address arithmetic apart from the loads: VALU at the head of an MFMA phase is slow)
   __device__ __forceinline__ void offsets(int kt, unsigned (&o)[4]) const {
-    const unsigned ok = kt * HBK + kq < depth ? off + (unsigned)(kt * HBK * 4) : kOob;
+    unsigned base = off + (unsigned)(kt * HBK * 4);
+    if constexpr (SEG)                         // uniform: scalar multiply-shift + one scalar load
+      base += sg->adj[((unsigned)(g0 + kt) * sg->magic) >> 20];
+    const unsigned ok = kt * HBK + kq < depth ? base : kOob;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = i * (NT / 8) < rows_left ? ok : kOob;
   }
@@ -1059,16 +1078,19 @@ struct HlLoaderT {
 __device__ int g_hl_prof_on = 0;
 __device__ long long g_hl_prof[8][8];
 
-template <int WN, int MI, int NJ, bool KM>
+template <int WN, int MI, int NJ, bool KM, bool SEG = false>
 __global__ void __launch_bounds__(128 * WN)
 gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int splits,
                 Epilogue ep, const float* __restrict__ a_scale,
-                const float* __restrict__ b_scale) {
+                const float* __restrict__ b_scale, HlSeg seg) {
   constexpr int NT = 128 * WN, TM2 = 64 * MI, TN2 = 32 * NJ * WN;
   constexpr int RB = 2 * MI, CB = 2 * NJ;           // 16 x 16 tiles per wave: rows x columns
   static_assert(TM2 == TN2 && TM2 * 8 == 4 * NT, "square tile, four chunks per thread and operand");
   // KM: the operands are K-major planes (rows = reduction index), HlLoaderT; else HlLoaderX
+  // SEG: A's reduction range is segmented (HlSeg; the conv2d entry points) -- its own
+  // instantiation, so that the plain kernels' K loop is untouched
   using Loader = std::conditional_t<KM, HlLoaderT<NT>, HlLoaderX<NT>>;
+  using LoaderA = std::conditional_t<KM, HlLoaderT<NT>, HlLoaderX<NT, SEG>>;
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
   constexpr int kOpBytes = (TM2 / 16) * 2 * kSubtile;          // KM: one operand's slab image
   auto opimg = [&](int buf, int which) {
@@ -1105,8 +1127,10 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
       plast = now;
     }
   };
-  Loader la, lb;
-  la.init(A, m0, k_begin, k_end);
+  LoaderA la;
+  Loader lb;
+  if constexpr (KM) la.init(A, m0, k_begin, k_end);
+  else la.init(A, m0, k_begin, k_end, &seg);
   lb.init(B, n0, k_begin, k_end);
   // One register set, two slabs ahead: at the top of step kt the registers hold slab kt+1
   // (issued a whole step earlier, so it has landed); it is written to the LDS buffer the
@@ -1659,8 +1683,9 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
     ASR_CHECK_ARG(a->lda >= a->M && a->ldb >= a->N && a->lda % 16 == 0 && a->ldb % 16 == 0 &&
                   a->ldc >= a->N, "gemm_hl (k_major): bad leading dimensions");
   else
-  ASR_CHECK_ARG(a->lda >= a->K && a->ldb >= a->K && a->lda % 8 == 0 && a->ldb % 8 == 0 &&
-                a->ldc >= a->N, "gemm_hl: bad leading dimensions");
+  ASR_CHECK_ARG((a->lda >= a->K || a->a_seg_k > 0) && a->ldb >= a->K && a->lda % 16 == 0 &&
+                a->ldb % 16 == 0 && a->ldc >= a->N,
+                "gemm_hl: bad leading dimensions (multiples of 16: whole (hi, lo) groups)");
   ASR_CHECK_ARG((reinterpret_cast<uintptr_t>(a->a_hl) & 63) == 0 &&
                 (reinterpret_cast<uintptr_t>(a->b_hl) & 63) == 0,
                 "gemm_hl: planes must start at a reduction group (64-byte aligned)");
@@ -1688,49 +1713,62 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
     }
     ep.partial = reinterpret_cast<float*>(workspace);
   }
+  HlSeg seg;
+  seg.magic = 0u;
+  for (int i = 0; i < 16; ++i) seg.adj[i] = 0u;
+  size_t ext_a_seg = ext_a;
+  if (a->a_seg_k > 0) {
+    // A's reduction range = n segments of a_seg_k indices, segment i shifted by a_seg_row[i]
+    // plane rows (>= 0: the caller points a_hl at the lowest row any segment reads)
+    ASR_CHECK_ARG(!km && a->a_seg_k % HBK == 0 && a->K % a->a_seg_k == 0 &&
+                  a->K / a->a_seg_k <= 16 && a->lda >= a->a_seg_k,
+                  "gemm_hl: segments need the row-major form, a_seg_k %% 32 == 0, K = n * a_seg_k, n <= 16");
+    const int nseg = a->K / a->a_seg_k, sps = a->a_seg_k / HBK;
+    seg.magic = (1u << 20) / (unsigned)sps + 1u;
+    for (int g = 0; g < a->K / HBK; ++g)
+      ASR_CHECK_ARG((int)(((unsigned)g * seg.magic) >> 20) == g / sps, "gemm_hl: segment magic");
+    long long max_row = 0;
+    for (int i = 0; i < nseg; ++i) {
+      ASR_CHECK_ARG(a->a_seg_row[i] >= 0, "gemm_hl: negative segment row shift");
+      if (a->a_seg_row[i] > max_row) max_row = a->a_seg_row[i];
+      // bytes: the segment's row shift minus what the running reduction offset has advanced
+      const long long adj = a->a_seg_row[i] * (long long)a->lda * 4 - (long long)i * a->a_seg_k * 4;
+      seg.adj[i] = (unsigned)(unsigned long long)adj;
+    }
+    ext_a_seg = ((size_t)(a->M - 1 + max_row) * 2 * a->lda + (size_t)(a->a_seg_k / 16) * 32) * 2;
+    ASR_CHECK_ARG(ext_a_seg + (size_t)1024 * a->lda * 4 < lim, "gemm_hl: operand larger than 4 GiB");
+  }
   HlSrc A, B;
   A.p = reinterpret_cast<const _Float16*>(a->a_hl);
-  A.ld = a->lda; A.rows = a->M; A.extent = (unsigned)ext_a;
+  A.ld = a->lda; A.rows = a->M; A.extent = (unsigned)ext_a_seg;
   B.p = reinterpret_cast<const _Float16*>(a->b_hl);
   B.ld = a->ldb; B.rows = a->N; B.extent = (unsigned)ext_b;
   // tile: 256 x 256 (512 threads, 128 KB LDS) for outputs of at least that size, else 128 x 128
   // (256 threads, 64 KB; asr_gemm_hl_args.tile = 128 or ASR_GEMM_HL_TILE=128 force it)
   static const int tile_env = [] { const char* v = getenv("ASR_GEMM_HL_TILE"); return v ? atoi(v) : 256; }();
-  if (tile_env >= 256 && a->tile != 128 && a->M >= 256 && a->N >= 256) {
-    const size_t shm2 = km ? (size_t)2 * 2 * (256 / 16) * 2 * kSubtile
-                           : (size_t)2 * 4 * (256 * 32 + 32) * sizeof(_Float16);
-    static bool attr2_done[2] = {false, false};
-    if (!attr2_done[km]) {
-      ASR_CHECK_HIP(hipFuncSetAttribute(km ? (const void*)gemm_hlx_kernel<4, 4, 2, true>
-                                           : (const void*)gemm_hlx_kernel<4, 4, 2, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
-      attr2_done[km] = true;
-    }
-    const int total = ((a->M + 255) / 256) * ((a->N + 255) / 256) * splits;
-    if (km)
-      hipLaunchKernelGGL((gemm_hlx_kernel<4, 4, 2, true>), dim3(total), dim3(512), shm2, stream, A,
-                         B, a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
-    else
-      hipLaunchKernelGGL((gemm_hlx_kernel<4, 4, 2, false>), dim3(total), dim3(512), shm2, stream, A,
-                         B, a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
-  } else {
-    const size_t shm1 = km ? (size_t)2 * 2 * (128 / 16) * 2 * kSubtile
-                           : (size_t)2 * 4 * (128 * 32 + 32) * sizeof(_Float16);
-    const int total = ((a->M + 127) / 128) * ((a->N + 127) / 128) * splits;
-    if (km) {
-      static bool attr1_done = false;
-      if (!attr1_done) {
-        ASR_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_hlx_kernel<2, 2, 2, true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm1));
-        attr1_done = true;
-      }
-      hipLaunchKernelGGL((gemm_hlx_kernel<2, 2, 2, true>), dim3(total), dim3(256), shm1, stream, A,
-                         B, a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
-    } else {
-      hipLaunchKernelGGL((gemm_hlx_kernel<2, 2, 2, false>), dim3(total), dim3(256), shm1, stream, A,
-                         B, a->M, a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale);
-    }
+  const bool big = tile_env >= 256 && a->tile != 128 && a->M >= 256 && a->N >= 256;
+  const int tl = big ? 256 : 128;
+  const size_t shm = km ? (size_t)2 * 2 * (tl / 16) * 2 * kSubtile
+                        : (size_t)2 * 4 * (tl * 32 + 32) * sizeof(_Float16);
+  const int total = ((a->M + tl - 1) / tl) * ((a->N + tl - 1) / tl) * splits;
+  const bool segd = seg.magic != 0u;
+  // kernel variants: [tile 256 / 128][row-major / k-major / row-major with a segmented A]
+  typedef void (*hlx_t)(HlSrc, HlSrc, int, int, int, int, int, Epilogue, const float*, const float*,
+                        HlSeg);
+  static const hlx_t kern[2][3] = {
+      {gemm_hlx_kernel<4, 4, 2, false>, gemm_hlx_kernel<4, 4, 2, true>,
+       gemm_hlx_kernel<4, 4, 2, false, true>},
+      {gemm_hlx_kernel<2, 2, 2, false>, gemm_hlx_kernel<2, 2, 2, true>,
+       gemm_hlx_kernel<2, 2, 2, false, true>}};
+  static bool attr_done[2][3] = {{false, false, false}, {false, false, false}};
+  const int vi = big ? 0 : 1, vj = km ? 1 : (segd ? 2 : 0);
+  if (!attr_done[vi][vj]) {
+    ASR_CHECK_HIP(hipFuncSetAttribute((const void*)kern[vi][vj],
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_done[vi][vj] = true;
   }
+  hipLaunchKernelGGL(kern[vi][vj], dim3(total), dim3(big ? 512 : 256), shm, stream, A, B, a->M,
+                     a->N, a->K, kps, splits, ep, a->a_scale, a->b_scale, seg);
   ASR_CHECK_LAUNCH();
   if (splits > 1) {
     Epilogue ep2 = ep;

@@ -610,7 +610,7 @@ def pack_hl(src, rows, cols, ld=None, src_off=0, mask=None, mask_period=0, absma
 
 def gemm_hl(A, B, Cm, M, N, K, a_row=0, a_k=0, b_row=0, b_k=0, c_off=0, ldc=None, alpha=1.0,
             beta=0.0, bias=None, c_scale=None, c_scale_period=0, split_k=0, ws_name='gemm',
-            tile=0, k_major=False):
+            tile=0, k_major=False, a_seg_k=0, a_seg_rows=None):
     """C[M,N] (float32 storage Cm, element offset c_off) = alpha * A @ B^T (+bias)(*c_scale)
     + beta*C from packed planes: A rows [a_row, a_row+M), reduction range [a_k, a_k+K) of its
     planes; B rows [b_row, b_row+N), range [b_k, b_k+K).
@@ -632,9 +632,58 @@ def gemm_hl(A, B, Cm, M, N, K, a_row=0, a_k=0, b_row=0, b_k=0, c_off=0, ldc=None
     g.split_k = _resolve_split(split_k, M, N, K)
     g.tile = int(tile)
     g.k_major = 1 if k_major else 0
+    if a_seg_k:         # segmented reduction range of A (include/asr_hip.h): K = len(rows) * a_seg_k
+        g.a_seg_k = int(a_seg_k)
+        for i, r in enumerate(a_seg_rows):
+            g.a_seg_row[i] = int(r)
     nbytes = lib.asr_gemm_hl_workspace_bytes(C.byref(g))
     ws = WS.get(ws_name, nbytes, Cm.device) if nbytes else None
     L.check(lib.asr_gemm_hl(C.byref(g), _ptr(ws), nbytes, _stream()), 'asr_gemm_hl')
+
+
+# --------------------------------------------------------------------------- conv front-end
+class Conv2d(object):
+    """One layer of the 2-D convolution front-end (K13, include/asr_hip.h asr_conv2d_*) on
+    time-major slabs: x (T_in, n_pad, F_in * C_in) -> y (T_out, n_pad, F_out * C_out),
+    'same' padding, strides (st, sf), clipped ReLU.  Owns its workspace (the packed planes of x
+    and of dz live there between the forward and the backward calls of a step)."""
+
+    def __init__(self, T_in, n_pad, F_in, C_in, C_out, kt, kf, st, sf, clip, device):
+        lib = L.load()
+        a = self.args = L.Conv2dArgs()
+        a.T_in, a.n_pad, a.F_in, a.C_in = int(T_in), int(n_pad), int(F_in), int(C_in)
+        a.C_out, a.kt, a.kf, a.st, a.sf = int(C_out), int(kt), int(kf), int(st), int(sf)
+        a.clip = float(clip)
+        t, f = C.c_int(), C.c_int()
+        L.check(lib.asr_conv2d_out_shape(C.byref(a), C.byref(t), C.byref(f)), 'asr_conv2d_out_shape')
+        self.T_out, self.F_out = t.value, f.value
+        self.ws_bytes = lib.asr_conv2d_workspace_bytes(C.byref(a))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.device = device
+
+    def _call(self, fn, name, **ptrs):
+        a = self.args
+        for k in ('x', 'W', 'bias', 'z', 'y', 'dy', 'dx', 'dW', 'db'):
+            t = ptrs.get(k)
+            setattr(a, k, t.data_ptr() if t is not None else None)
+        a.reuse_x, a.reuse_dz = int(ptrs.get('reuse_x', 0)), int(ptrs.get('reuse_dz', 0))
+        L.check(fn(C.byref(a), _ptr(self.ws), self.ws_bytes, _stream()), name)
+
+    def fwd(self, x, W, bias, z, y):
+        _check_f32(x, W, bias, z, y)
+        self._call(L.load().asr_conv2d_fwd, 'asr_conv2d_fwd', x=x, W=W, bias=bias, z=z, y=y)
+        return y
+
+    def dgrad(self, dy, z, W, dx, reuse_dz=False):
+        _check_f32(dy, z, W, dx)
+        self._call(L.load().asr_conv2d_dgrad, 'asr_conv2d_dgrad', dy=dy, z=z, W=W, dx=dx,
+                   reuse_dz=reuse_dz)
+        return dx
+
+    def wgrad(self, x, dy, z, dW, db, reuse_x=False, reuse_dz=False):
+        _check_f32(x, dy, z, dW, db)
+        self._call(L.load().asr_conv2d_wgrad, 'asr_conv2d_wgrad', x=x, dy=dy, z=z, dW=dW, db=db,
+                   reuse_x=reuse_x, reuse_dz=reuse_dz)
 
 
 # --------------------------------------------------------------------------- random streams

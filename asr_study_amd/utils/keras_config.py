@@ -101,6 +101,21 @@ def model_config(model):
                 'name': name, 'trainable': True, 'merge_mode': 'concat',
                 'layer': {'class_name': 'LSTM',
                           'config': _lstm_config('lstm_%d' % counts['bidirectional'], s)}}, [prev])
+        elif s.kind == 'reshape':
+            name = nm('reshape')
+            add('Reshape', name, {'name': name, 'trainable': True,
+                                  'target_shape': [int(v) for v in s.target]}, [prev])
+        elif s.kind == 'conv':
+            name = nm('convolution2d')
+            add('Convolution2D', name, {
+                'name': name, 'trainable': True, 'nb_filter': int(s.C_out), 'nb_row': int(s.kt),
+                'nb_col': int(s.kf), 'subsample': [int(s.st), int(s.sf)], 'border_mode': 'same',
+                'dim_ordering': 'tf', 'init': 'glorot_uniform',
+                # (a Python closure in the reference's style: named, not marshalled)
+                'activation': 'clipped_relu' if s.clip > 0 else 'linear',
+                'max_value': float(s.clip), 'W_regularizer': _regularizer(s.l2),
+                'b_regularizer': None, 'activity_regularizer': None, 'W_constraint': None,
+                'b_constraint': None, 'bias': True}, [prev])
         elif s.kind == 'merge':
             name = nm('merge')
             add('Merge', name, {'name': name, 'mode': s.mode, 'mode_type': 'raw',
@@ -195,6 +210,15 @@ def topology_from_config(text):
         kind = l['class_name']
         if kind == 'GaussianNoise':
             o = L.GaussianNoise(c['sigma'])(o)
+        elif kind == 'Reshape':
+            o = L.Reshape(tuple(c['target_shape']))(o)
+        elif kind == 'Convolution2D':
+            act = L.clipped_relu(c.get('max_value', 20.0)) if c.get('activation') == 'clipped_relu' \
+                else None
+            o = L.Convolution2D(c['nb_filter'], c['nb_row'], c['nb_col'],
+                                subsample=tuple(c['subsample']), border_mode=c['border_mode'],
+                                activation=act, W_regularizer=reg(c.get('W_regularizer')),
+                                dim_ordering=c.get('dim_ordering', 'tf'))(o)
         elif kind == 'Dropout':
             o = L.Dropout(c['p'])(o)
         elif kind == 'TimeDistributed':

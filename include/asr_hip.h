@@ -153,7 +153,8 @@ int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes,
 /* from A planes (M, lda) and B planes (N, ldb), reduction index contiguous in  */
 /* both, fp32 accumulation (2^-22 relative per product: the arithmetic of       */
 /* asr_gemm precision 1 without its per-tile conversions).  A sub-matrix is a   */
-/* pointer offset (16-byte aligned) with the same leading dimension; K % 8 == 0.*/
+/* pointer offset (64-byte aligned: a whole (hi, lo) group) with the same       */
+/* leading dimension; K % 8 == 0; lda % 16 == 0 and ldb % 16 == 0.              */
 /* ------------------------------------------------------------------------ */
 typedef struct asr_pack_args {
   const float* src; int rows, cols, ld;
@@ -192,10 +193,70 @@ typedef struct asr_gemm_hl_args {
                                                  /* use (no second orientation packed);  */
                                                  /* a sub-matrix = pointer to (first row,*/
                                                  /* first column group of 16)            */
+  /* Segmented reduction range of A (row-major form only; 0 = none): K = n * a_seg_k, n <= 16,  */
+  /* a_seg_k % 32 == 0; reduction indices [i a_seg_k, (i+1) a_seg_k) are read from columns      */
+  /* [0, a_seg_k) of the planes a_seg_row[i] (>= 0) rows further down: C = sum_i A_i B_i^T with */
+  /* A_i = a_hl shifted by a_seg_row[i] rows -- the implicit im2col over time of asr_conv2d_*   */
+  /* (tap i of a filter reads the activation slab i frames on).  lda >= a_seg_k.                 */
+  int a_seg_k;
+  long long a_seg_row[16];
 } asr_gemm_hl_args;
 size_t asr_gemm_hl_workspace_bytes(const asr_gemm_hl_args* a);
 int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws_bytes,
                 asr_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* K13  2-D convolution front-end of BASELINE.json configs[2] ("DeepSpeech2-   */
+/* style 5xBiLSTM(512) + 2 conv front-end").  NO REFERENCE COUNTERPART: the    */
+/* reference lists Deep Speech 2 as TODO (README.md:118) and its deep_speech   */
+/* factory (core/models.py:148-214) is dead code without convolutions; the op  */
+/* is defined here as Keras-1.2.2 Convolution2D(nb_filter, nb_row, nb_col,     */
+/* subsample=(st, sf), border_mode='same', dim_ordering='tf') on the           */
+/* (N, T, F, C) view of the feature slab, followed by a clipped ReLU           */
+/* min(max(z, 0), clip) (the reference's clipped_relu, core/models.py:116).    */
+/* 'same' = TensorFlow's rule: out = ceil(in / stride), pad_total =            */
+/* max((out - 1) stride + k - in, 0), pad_before = pad_total / 2.              */
+/*                                                                              */
+/* Layout: activations are time-major slabs (T, n_pad, F*C), channel minor     */
+/* (feature index f*C + c) -- Reshape((T, F*C)) of the Keras tensor is the     */
+/* identity; W is (kt, kf, C_in, C_out) row-major (Keras 'tf' kernel), bias    */
+/* (C_out).  The convolution over FREQUENCY is folded into a banded matrix     */
+/* per time tap (band[dt][(fi,ci)][(fo,co)] = W[dt][fi - sf fo + pf][ci][co]), */
+/* the convolution over TIME is the segmented reduction of asr_gemm_hl: tap dt */
+/* reads the packed activation planes dt frames further on (implicit im2col);  */
+/* the products run on the packed split-fp16 MFMA kernel of K4.  kt <= 16.     */
+/*   fwd  : z = conv(x, W) + b   (kept for the backward pass),  y = act(z)     */
+/*   dgrad: dx = conv^T(dy (.) act'(z), W)                                      */
+/*   wgrad: dW = x (*) (dy (.) act'(z)),  db = sum over rows and fo            */
+/* The workspace keeps the packed planes of x (written by fwd) and of           */
+/* dz = dy (.) act'(z) (written by whichever of dgrad / wgrad runs first);     */
+/* reuse_x / reuse_dz = 1 tell a later call on the SAME workspace to skip the  */
+/* pack (the host runs fwd ... dgrad, wgrad per layer with its own workspace). */
+/* ------------------------------------------------------------------------ */
+typedef struct asr_conv2d_args {
+  int T_in, n_pad, F_in, C_in;   /* input slab (T_in, n_pad, F_in*C_in)              */
+  int C_out, kt, kf, st, sf;     /* filter and strides (time, frequency)            */
+  float clip;                    /* clipped-ReLU ceiling (20); <= 0: linear output  */
+  const float* x;                /* fwd, wgrad                                      */
+  const float* W;                /* (kt, kf, C_in, C_out)                           */
+  const float* bias;             /* (C_out)                                         */
+  float* z;                      /* (T_out, n_pad, F_out*C_out): fwd out, bwd in    */
+  float* y;                      /* fwd out (may be NULL when clip <= 0: y = z)     */
+  const float* dy;               /* dgrad / wgrad in, shape of z                    */
+  float* dx;                     /* dgrad out, shape of x                           */
+  float* dW;                     /* wgrad out, shape of W                           */
+  float* db;                     /* wgrad out (C_out)                               */
+  int reuse_x, reuse_dz;
+} asr_conv2d_args;
+/* T_out = ceil(T_in / st), F_out = ceil(F_in / sf). */
+int asr_conv2d_out_shape(const asr_conv2d_args* a, int* T_out, int* F_out);
+size_t asr_conv2d_workspace_bytes(const asr_conv2d_args* a);
+int asr_conv2d_fwd(const asr_conv2d_args* a, void* workspace, size_t ws_bytes,
+                   asr_stream_t stream);
+int asr_conv2d_dgrad(const asr_conv2d_args* a, void* workspace, size_t ws_bytes,
+                     asr_stream_t stream);
+int asr_conv2d_wgrad(const asr_conv2d_args* a, void* workspace, size_t ws_bytes,
+                     asr_stream_t stream);
 
 /* out[0] = max |x[i]| over a 16-byte aligned flat tensor (HBM-bound).         */
 int asr_absmax(const float* x, int64_t n, float* out, asr_stream_t stream);

@@ -21,6 +21,7 @@ Cross-checked against torch.autograd in tests/test_oracle_lstm.py.
 """
 import numpy as np
 
+from . import conv as _conv
 from . import ctc as _ctc
 
 
@@ -226,11 +227,20 @@ def init_dense(rs, n_in, n_out, dtype=np.float32):
 
 
 def init_model(seed=0, num_features=39, num_hiddens=256, num_layers=5,
-               num_classes=28, dtype=np.float32, in_dense=None):
-    """Parameter pytree for brsmv1 / graves2006 (in_dense=None) or eyben."""
+               num_classes=28, dtype=np.float32, in_dense=None, conv=None):
+    """Parameter pytree for brsmv1 / graves2006 (in_dense=None), eyben, or -- conv = list of
+    (C_out, kt, kf, st, sf, clip) -- the deep_speech2 topology with its convolution front-end."""
     rs = np.random.RandomState(seed)
     params = {'layers': []}
     n_in = num_features
+    if conv:
+        params['conv'] = []
+        F, Ci = num_features, 1
+        for (Co, kt, kf, st, sf, clip) in conv:
+            W, b = _conv.init_conv(rs, kt, kf, Ci, Co, dtype)
+            params['conv'].append({'W': W, 'b': b, 'stride': (st, sf), 'clip': clip})
+            F, Ci = -(-F // sf), Co
+        n_in = F * Ci
     if in_dense:
         params['in_dense'] = init_dense(rs, n_in, in_dense, dtype)
         n_in = in_dense
@@ -250,6 +260,11 @@ def model_forward(params, x, masks=None, zone=None):
     parameter dict may carry 'mi' = [alpha, beta1, beta2] (multiplicative integration)."""
     caches = {'layers': []}
     o = x
+    # build-defined 2-D convolution front-end (oracle/conv.py; BASELINE configs[2]): a list of
+    # dict(W, b, stride=(st, sf), clip) applied to the (T, N, F*C) slab before everything else
+    for cp in params.get('conv', []):
+        o, cc = _conv.conv2d_forward(o, cp['W'], cp['b'], cp['stride'], cp['clip'])
+        caches.setdefault('conv', []).append(cc)
     if 'in_dense' in params:
         caches['in_dense_x'] = o
         o = o @ params['in_dense']['W'] + params['in_dense']['b']
@@ -318,6 +333,11 @@ def model_backward(params, caches, dlogits):
         grads['in_dense'] = {'W': xi.reshape(T * N, D).T @ do.reshape(T * N, -1),
                              'b': do.sum(axis=(0, 1))}
         do = do @ params['in_dense']['W'].T
+    if 'conv' in params:
+        grads['conv'] = [None] * len(params['conv'])
+        for ci in range(len(params['conv']) - 1, -1, -1):
+            do, dW, db = _conv.conv2d_backward(do, caches['conv'][ci])
+            grads['conv'][ci] = {'W': dW, 'b': db}
     grads['input'] = do
     return grads
 
@@ -332,6 +352,8 @@ def l2_penalty(params, weight_decay, in_dense_l2=False):
                 tot += weight_decay * (np.sum(layer[d]['W'].astype(np.float64) ** 2) +
                                        np.sum(layer[d]['U'].astype(np.float64) ** 2))
         tot += weight_decay * np.sum(params['dense']['W'].astype(np.float64) ** 2)
+        for cp in params.get('conv', []):
+            tot += weight_decay * np.sum(cp['W'].astype(np.float64) ** 2)
     return tot
 
 
@@ -342,6 +364,8 @@ def loss_and_grads(params, x, labels, seq_len, weight_decay=0.0, masks=None, zon
     """
     logits, caches = model_forward(params, x, masks, zone)
     T, N, C = logits.shape
+    for cp in params.get('conv', []):           # a sequence keeps ceil(len / st) frames
+        seq_len = _conv.out_lengths(seq_len, cp['stride'][0])
     ctc_n, dlog = _ctc.ctc_loss_grad(logits, labels, seq_len, dtype=logits.dtype)
     dlog = dlog / N                       # mean over the batch
     grads = model_backward(params, caches, dlog.astype(logits.dtype))
@@ -351,6 +375,8 @@ def loss_and_grads(params, x, labels, seq_len, weight_decay=0.0, masks=None, zon
                 grads['layers'][li][d]['W'] += 2 * weight_decay * layer[d]['W']
                 grads['layers'][li][d]['U'] += 2 * weight_decay * layer[d]['U']
         grads['dense']['W'] += 2 * weight_decay * params['dense']['W']
+        for ci, cp in enumerate(params.get('conv', [])):
+            grads['conv'][ci]['W'] += 2 * weight_decay * cp['W']
     loss = float(np.mean(ctc_n)) + l2_penalty(params, weight_decay)
     return dict(loss=loss, ctc=ctc_n, logits=logits, grads=grads, caches=caches)
 
@@ -358,6 +384,8 @@ def loss_and_grads(params, x, labels, seq_len, weight_decay=0.0, masks=None, zon
 def flatten(tree):
     """Deterministic flat list of (name, array) in checkpoint order."""
     out = []
+    for ci, cp in enumerate(tree.get('conv', [])):
+        out += [('conv%d/W' % ci, cp['W']), ('conv%d/b' % ci, cp['b'])]
     if 'in_dense' in tree:
         out += [('in_dense/W', tree['in_dense']['W']),
                 ('in_dense/b', tree['in_dense']['b'])]
