@@ -75,8 +75,12 @@ struct Ws {                       // byte offsets into the caller's workspace
 };
 
 int wgrad_splits(const Geo& g) {
-  const int tiles = ((g.Ki + 255) / 256) * ((g.Ko + 255) / 256);
-  long long s = (1024 + tiles - 1) / tiles;
+  // one K-major GEMM per time tap, (Ki x Ko) output: split the long row reduction until about
+  // one workgroup per CU exists -- more splits only add partial-sum traffic (a 64-way split of
+  // the second layer wrote and re-read 210 MB of partials per tap: 2.7 ms per step of reduce)
+  const int tl = (g.Ki >= 256 && g.Ko >= 256) ? 256 : 128;
+  const int tiles = ((g.Ki + tl - 1) / tl) * ((g.Ko + tl - 1) / tl);
+  long long s = (288 + tiles - 1) / tiles;
   if (s > 64) s = 64;
   if (s > g.M / 256) s = g.M / 256;
   return s < 1 ? 1 : (int)s;

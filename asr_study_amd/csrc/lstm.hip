@@ -97,6 +97,8 @@ int fwd_xstride() {
   return v;
 }
 
+bool fwd_progressive(int H) { return env_int("ASR_LSTM_PROG", H <= 256 ? 1 : 0) != 0; }
+
 int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   const int H = a->H;
   const int chains = 2 * (a->n_pad / 16);
@@ -153,7 +155,9 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
         // plain cell, persistent mode, H = 128 NKW: K split over the waves, U fragments in
         // AGPRs (fwd_body_x)
         pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
-        k = ASR_PICK(asr_lstm_pick_fwd_x(H, false));
+        // the progressive step (slabs polled and multiplied separately, lstm_fwd.hip) where it
+        // measured faster: H = 256 (ASR_LSTM_PROG=0 / 1 force the single-gather / progressive form)
+        k = ASR_PICK(asr_lstm_pick_fwd_x(H, false, fwd_progressive(H)));
       } else {
         // any H, the cell variants, stepwise mode: h staged in LDS once per step (fwd_body_h)
         pl.shm = (size_t)4 * 16 * (32 * pl.NKK + 8) * 2;
@@ -345,8 +349,10 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.dbg = env_int("ASR_LSTM_DBG", 0);
   // measured optimum on MI355X (tools/sweep_poll.sh, tools/sweep_r2c.sh): forward 8-16 naps
   // (~0.4 us; flat in that range), BPTT 4
+  // (the progressive forward step polls at once: a partly stale poll still delivers work)
+  const bool prog_f = !bwd && pl.prec == 1 && (a->H == 256 || a->H == 512) && fwd_progressive(a->H);
   p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.form_c ? 2 : 4)
-                  : env_int("ASR_LSTM_PREPOLL_F", pl.P <= 16 ? 12 : 16);
+                  : env_int("ASR_LSTM_PREPOLL_F", prog_f ? 0 : (pl.P <= 16 ? 12 : 16));
   p.repoll = bwd ? env_int("ASR_LSTM_REPOLL_B", 1) : env_int("ASR_LSTM_REPOLL_F", 1);
   p.xstride = fwd_xstride();
   // ASR_LSTM_SPIN_MS: bound of a persistent kernel's spins in milliseconds (default 600)

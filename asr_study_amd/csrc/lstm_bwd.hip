@@ -846,9 +846,6 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     const long long t0 = wall_clock64();
     bool gave_up = false;
     while (stale) {
-#ifdef POLLCOUNT
-      if (prof.on) prof.pt[0] += 1000000;
-#endif
       for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
       load_groups(rsrc);
       stale = !all_tagged<NL>(v, flip);

@@ -365,7 +365,47 @@ template <> struct FwdMfma<4> {
   }
 };
 
-template <int NKW, bool FAST, bool EXACT>
+// PROGRESSIVE step (fwd_body_x<.., SLAB>; the default at H = 256): the 32-deep slabs of a wave's K
+// slice are polled SEPARATELY.  A slab whose two producer workgroups have published is
+// multiplied at once, the others are polled again -- their loads only: a finished slab's offset
+// is sent out of the descriptor's range, which costs no memory traffic and keeps every load
+// unconditional (rule (3) of DESIGN.md 5).  No nap before the first poll: a poll that comes
+// back partly stale has still delivered work, and a wave that missed one slab re-reads 2 KB,
+// not its whole slice, so the four waves reach the step's barrier closer together (measured at
+// H = 256: 1.53 -> 1.40 us per step, the barrier wait 494 -> 175 clocks; at H = 512 the extra
+// VALU of the per-slab bookkeeping -- ~100 instructions on a one-wave-per-SIMD critical path --
+// costs more than the polling gains: 1.73 -> 2.05, so H = 512 keeps the single gather).
+// One slab = four gate tiles x (uh bl, uh bh, then + ul bh): twelve MFMAs on eight
+// accumulators, each reused eight MFMAs later.  The slab's contribution is r_j = am_j +
+// ac_j / 2048; the slabs' r are added in the FIXED order (r0 + r1) + (r2 + r3) whatever order
+// they arrived in: the result is deterministic (and differs from the chained form of the
+// single-gather kernel by the summation order only, < 4e-7).
+__device__ __forceinline__ void fwd_slab_mfma(f32x4 (&am)[4], f32x4 (&ac)[4], const f32x4& uh0,
+                                              const f32x4& uh1, const f32x4& uh2, const f32x4& uh3,
+                                              const f32x4& ul0, const f32x4& ul1, const f32x4& ul2,
+                                              const f32x4& ul3, const h8& bh, const h8& bl) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_16x16x32_f16 %4, %8, %17, 0\n\t"        // ac_j  = uh_j bl
+      "v_mfma_f32_16x16x32_f16 %5, %9, %17, 0\n\t"
+      "v_mfma_f32_16x16x32_f16 %6, %10, %17, 0\n\t"
+      "v_mfma_f32_16x16x32_f16 %7, %11, %17, 0\n\t"
+      "v_mfma_f32_16x16x32_f16 %0, %8, %16, 0\n\t"        // am_j  = uh_j bh
+      "v_mfma_f32_16x16x32_f16 %1, %9, %16, 0\n\t"
+      "v_mfma_f32_16x16x32_f16 %2, %10, %16, 0\n\t"
+      "v_mfma_f32_16x16x32_f16 %3, %11, %16, 0\n\t"
+      "v_mfma_f32_16x16x32_f16 %4, %12, %16, %4\n\t"      // ac_j += ul_j bh
+      "v_mfma_f32_16x16x32_f16 %5, %13, %16, %5\n\t"
+      "v_mfma_f32_16x16x32_f16 %6, %14, %16, %6\n\t"
+      "v_mfma_f32_16x16x32_f16 %7, %15, %16, %7\n\t"
+      "s_nop 11"
+      : "=&v"(am[0]), "=&v"(am[1]), "=&v"(am[2]), "=&v"(am[3]), "=&v"(ac[0]), "=&v"(ac[1]),
+        "=&v"(ac[2]), "=&v"(ac[3])
+      : "a"(uh0), "a"(uh1), "a"(uh2), "a"(uh3), "a"(ul0), "a"(ul1), "a"(ul2), "a"(ul3), "v"(bh),
+        "v"(bl));
+}
+
+template <int NKW, bool FAST, bool EXACT, bool SLAB = false>
 __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg, float* lds) {
   // Requires H == 128 * NKW (every lane's gather groups and units exist)
   constexpr int NT = 1;                            // batch tiles per workgroup
@@ -462,9 +502,6 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
   auto load_groups = [&](int x, const __amdgpu_buffer_rsrc_t& rsrc) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-#ifdef GATHER_PART      // timing experiment: only every GATHER_PART-th group is gathered (wrong h)
-      if (i % GATHER_PART) { v[x][i] = v[x][i - i % GATHER_PART]; continue; }
-#endif
       v[x][i] = __builtin_amdgcn_raw_buffer_load_b128(
           rsrc, goff, (unsigned)((8 * (i >> 1) + (i & 1))) * gstep, FAST ? kNt : kSc1);
     }
@@ -482,9 +519,6 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     const long long t0 = wall_clock64();
     bool gave_up = false;
     while (stale) {
-#ifdef POLLCOUNT
-      if (prof.on) prof.pt[0] += 1000000;
-#endif
       for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
       load_groups(x, rsrc);
       stale = !all_tagged<NL>(v[x], flip);
@@ -587,6 +621,83 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     issue(x, s);                                   // this tile's h of step s, for step s + 1
     prof.stamp(5);
   };
+  auto phase_prog = [&](int s) {
+    const float4 zx4 = zx_next[0];
+    prof.stamp(0);
+    const unsigned flip = 0u - ((unsigned)((s - 1) >> 1) & 1u);
+    const __amdgpu_buffer_rsrc_t rsrc = slot(0, s - 1);
+    f32x4 r[NKW][4];
+    unsigned pend = (1u << NKW) - 1u;              // wave-uniform: slabs not yet multiplied
+    long long t0 = 0;
+    int round = 0;
+    for (int i = 0; i < p.prepoll; ++i) __builtin_amdgcn_s_sleep(1);
+    while (pend != 0u) {
+#pragma unroll
+      for (int kk = 0; kk < NKW; ++kk) {
+        const unsigned o = (pend >> kk) & 1u ? goff : 0xFFFFFFF0u;
+        v[0][2 * kk] = __builtin_amdgcn_raw_buffer_load_b128(
+            rsrc, o, (unsigned)(8 * kk) * gstep, FAST ? kNt : kSc1);
+        v[0][2 * kk + 1] = __builtin_amdgcn_raw_buffer_load_b128(
+            rsrc, o, (unsigned)(8 * kk + 1) * gstep, FAST ? kNt : kSc1);
+      }
+#pragma unroll
+      for (int kk = 0; kk < NKW; ++kk) {
+        if (!((pend >> kk) & 1u)) continue;
+        const u32x4 q0 = v[0][2 * kk], q1 = v[0][2 * kk + 1];
+        const unsigned x = (((q0[0] ^ flip) | (q0[1] ^ flip)) | ((q0[2] ^ flip) | (q0[3] ^ flip))) |
+                           (((q1[0] ^ flip) | (q1[1] ^ flip)) | ((q1[2] ^ flip) | (q1[3] ^ flip)));
+        if (__builtin_amdgcn_ballot_w64((x & 1u) != 0u) != 0ull && p.poll && !dead) continue;
+        u32x4 hi, lo;
+        hi[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x07060302u);
+        hi[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x07060302u);
+        hi[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x07060302u);
+        hi[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x07060302u);
+        lo[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x05040100u);
+        lo[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x05040100u);
+        lo[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x05040100u);
+        lo[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x05040100u);
+        f32x4 am[4], ac[4];
+        fwd_slab_mfma(am, ac, ufh[0][kk], ufh[1][kk], ufh[2][kk], ufh[3][kk], ufl[0][kk],
+                      ufl[1][kk], ufl[2][kk], ufl[3][kk], __builtin_bit_cast(h8, hi),
+                      __builtin_bit_cast(h8, lo));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[kk][j][e] = __builtin_fmaf(ac[j][e], 1.f / kLoScale, am[j][e]);
+        pend &= ~(1u << kk);
+      }
+      if (pend != 0u) {
+        ++round;
+        if (round == 2) t0 = wall_clock64();
+        if (round > 2 && wall_clock64() - t0 > p.spin) {
+          dead = true;                             // give up: finish without polling
+          mark_timeout(p.status);
+        }
+        for (int i = 0; i < p.repoll; ++i) __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    prof.stamp(1);
+    const bool tr = p.trace && lane == 0 && (unsigned)(s - p.trace_s0) < 16u;
+    if (tr) p.trace[(((size_t)blockIdx.x * 4 + w) * 16 + (s - p.trace_s0)) * 2] = wall_clock64();
+    zx_next[0] = load_zx(0, s + 1);
+    const int buf = s & 1;
+    f32x4* mine = part + ((size_t)buf * 4 + w) * 4 * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 t;
+      if constexpr (NKW == 4) t = (r[0][j] + r[1][j]) + (r[2][j] + r[3][j]);
+      else t = r[0][j] + r[1][j];
+      mine[j * 64 + lane] = t;
+    }
+    prof.stamp(2);
+    __syncthreads();
+    prof.stamp(3);
+    const f32x4* all = part + (size_t)buf * 4 * 4 * 64 + (size_t)w * 64 + lane;
+    const f32x4 a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
+    finish_step(0, s, a, zx4);
+    if (tr) p.trace[(((size_t)blockIdx.x * 4 + w) * 16 + (s - p.trace_s0)) * 2 + 1] = wall_clock64();
+    prof.stamp(4);
+  };
   using T0 = std::integral_constant<int, 0>;
   int s = p.s_begin;
   if (s == 0) {
@@ -601,14 +712,18 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     s = 1;
   }
   prof.init((p.dbg & 32) && wg == 0 && unit == p.chain_begin);
-  if (s < s_end) {
-    issue(0, s - 1);
-    for (; s < s_end; ++s) phase(T0{}, s);
+  if constexpr (SLAB && !EXACT) {
+    for (; s < s_end; ++s) phase_prog(s);
+  } else {
+    if (s < s_end) {
+      issue(0, s - 1);
+      for (; s < s_end; ++s) phase(T0{}, s);
+    }
   }
   prof.flush(p.status, w);
 }
 
-template <int NKW, bool EXACT>
+template <int NKW, bool EXACT, bool SLAB = false>
 __global__ void __launch_bounds__(kThreads)
 lstm_fwd_kernel_x(LstmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -616,8 +731,8 @@ lstm_fwd_kernel_x(LstmParams p) {
   if (!map_block(p, unit_local, wg)) return;
   const int unit = p.chain_begin + unit_local;
   const bool fast = chain_on_one_xcd(p, unit, wg, reinterpret_cast<int*>(lds));
-  if (fast) fwd_body_x<NKW, true, EXACT>(p, unit, wg, lds);
-  else fwd_body_x<NKW, false, EXACT>(p, unit, wg, lds);
+  if (fast) fwd_body_x<NKW, true, EXACT, SLAB>(p, unit, wg, lds);
+  else fwd_body_x<NKW, false, EXACT, SLAB>(p, unit, wg, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -743,7 +858,10 @@ asr_lstm_kern_t asr_lstm_pick_fwd_h(int nkk, bool variants) {
     default: return variants ? ASR_KERN(lstm_fwd_kernel_hv<16>) : ASR_KERN(lstm_fwd_kernel_h<16>);
   }
 }
-asr_lstm_kern_t asr_lstm_pick_fwd_x(int H, bool exact) {
+asr_lstm_kern_t asr_lstm_pick_fwd_x(int H, bool exact, bool slab) {
+  if (slab && !exact)
+    return H == 256 ? ASR_KERN((lstm_fwd_kernel_x<2, false, true>))
+                    : ASR_KERN((lstm_fwd_kernel_x<4, false, true>));
   if (H == 256) return exact ? ASR_KERN((lstm_fwd_kernel_x<2, true>)) : ASR_KERN((lstm_fwd_kernel_x<2, false>));
   return exact ? ASR_KERN((lstm_fwd_kernel_x<4, true>)) : ASR_KERN((lstm_fwd_kernel_x<4, false>));
 }
