@@ -56,7 +56,8 @@ class GemmHlArgs(C.Structure):
                 ('bias', void_p),
                 ('c_scale', void_p), ('c_scale_period', C.c_int), ('c_scale_ld', C.c_int),
                 ('split_k', C.c_int), ('tile', C.c_int), ('k_major', C.c_int),
-                ('a_seg_k', C.c_int), ('a_seg_row', C.c_longlong * 16)]
+                ('a_seg_k', C.c_int), ('a_seg_row', C.c_longlong * 16),
+                ('batch', C.c_int), ('a_batch_row', C.c_longlong * 16)]
 
 
 class Conv2dArgs(C.Structure):

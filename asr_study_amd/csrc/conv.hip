@@ -75,12 +75,13 @@ struct Ws {                       // byte offsets into the caller's workspace
 };
 
 int wgrad_splits(const Geo& g) {
-  // one K-major GEMM per time tap, (Ki x Ko) output: split the long row reduction until about
-  // one workgroup per CU exists -- more splits only add partial-sum traffic (a 64-way split of
-  // the second layer wrote and re-read 210 MB of partials per tap: 2.7 ms per step of reduce)
+  // kt K-major GEMMs (one per time tap, (Ki x Ko) outputs) in one batched launch: split the
+  // long row reduction only until about one workgroup per CU exists -- more splits add
+  // partial-sum traffic (a 64-way split per tap wrote and re-read 210 MB of partials per tap:
+  // 2.7 ms per step of reduce kernels)
   const int tl = (g.Ki >= 256 && g.Ko >= 256) ? 256 : 128;
-  const int tiles = ((g.Ki + tl - 1) / tl) * ((g.Ko + tl - 1) / tl);
-  long long s = (288 + tiles - 1) / tiles;
+  const int tiles = ((g.Ki + tl - 1) / tl) * ((g.Ko + tl - 1) / tl) * g.kt;   // all taps: one launch
+  long long s = (320 + tiles - 1) / tiles;
   if (s > 64) s = 64;
   if (s > g.M / 256) s = g.M / 256;
   return s < 1 ? 1 : (int)s;
@@ -100,7 +101,7 @@ Ws make_ws(const Geo& g) {
   w.banddg_pl = take((size_t)g.Ki * g.kt * g.Ko_p * 4);
   w.bias_band = take((size_t)g.Ko * 4);
   w.dband = take((size_t)g.kt * g.Ki * g.Ko * 4);
-  w.gemm_bytes = asr_align_up((size_t)wgrad_splits(g) * g.Ki * g.Ko * sizeof(float), 256);
+  w.gemm_bytes = asr_align_up((size_t)wgrad_splits(g) * g.kt * g.Ki * g.Ko * sizeof(float), 256);
   w.gemm = take(w.gemm_bytes);
   w.colsum_bytes = asr_colsum_workspace_bytes((int)g.M, g.Ko);
   w.colsum = take(w.colsum_bytes);
@@ -424,16 +425,19 @@ extern "C" int asr_conv2d_wgrad(const asr_conv2d_args* a, void* workspace, size_
   if (!a->reuse_x) { rc = pack_x(g, a, w, ws, stream); if (rc) return rc; }
   if (!a->reuse_dz) { rc = pack_dz(g, a, w, ws, stream); if (rc) return rc; }
   float* dband = reinterpret_cast<float*>(ws + w.dband);
-  // d band[dt] (Ki x Ko) = X_dt^T dZ: both operands reduce over their plane ROWS (k_major)
-  for (int dt = 0; dt < g.kt; ++dt) {
+  // d band[dt] (Ki x Ko) = X_dt^T dZ: both operands reduce over their plane ROWS (k_major); the
+  // kt taps share dZ and differ in the row shift of the x planes only: ONE batched launch
+  {
     asr_gemm_hl_args h = {};
     h.M = g.Ki; h.N = g.Ko; h.K = (int)g.M;
-    h.a_hl = ws + w.xpl + (size_t)tap_row(g, dt) * g.Ki_p * 4; h.lda = g.Ki_p;
+    h.a_hl = ws + w.xpl; h.lda = g.Ki_p;
     h.b_hl = ws + w.dzpl + (size_t)g.padb * g.n_pad * g.Ko_p * 4; h.ldb = g.Ko_p;
     h.a_scale = scal + 8; h.b_scale = scal + 9;
-    h.C = dband + (size_t)dt * g.Ki * g.Ko; h.ldc = g.Ko; h.alpha = 1.f; h.beta = 0.f;
+    h.C = dband; h.ldc = g.Ko; h.alpha = 1.f; h.beta = 0.f;
     h.split_k = wgrad_splits(g);
     h.k_major = 1;
+    h.batch = g.kt;
+    for (int dt = 0; dt < g.kt; ++dt) h.a_batch_row[dt] = tap_row(g, dt);
     rc = asr_gemm_hl(&h, ws + w.gemm, w.gemm_bytes, stream);
     if (rc) return rc;
   }

@@ -814,7 +814,8 @@ struct HlSrc {
 // with a magic the host verified over the launch's slab range.  magic = 0: no segments.
 struct HlSeg {
   unsigned magic;
-  unsigned adj[16];
+  unsigned batch;          // k_major only: > 1 = a batch of GEMMs sharing B (asr_gemm_hl_args.batch):
+  unsigned adj[16];        //   adj[b] = byte offset of A_b; else the segments' offset corrections
 };
 __device__ __forceinline__ size_t hl_index(int row, int k, int ld) {      // half index of hi
   return (size_t)row * (2 * (size_t)ld) + (size_t)(k >> 4) * 32 + (k & 15);
@@ -1104,12 +1105,24 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;          // 2 x WN waves, (32 MI) x (32 NJ) each
-  const TileId tb = tile_of_block((M + TM2 - 1) / TM2, (N + TN2 - 1) / TN2, splits);
+  // (K-major batches: z = split * batch + b, so that the split-K partials of all batch members
+  // form ONE ([split][batch * M][N]) array and the plain reduce kernel folds them)
+  const int nbatch = (KM && seg.batch > 1u) ? (int)seg.batch : 1;
+  const TileId tb = tile_of_block((M + TM2 - 1) / TM2, (N + TN2 - 1) / TN2, splits * nbatch);
   const int m0 = tb.tm * TM2, n0 = tb.tn * TN2;
-  const int k_begin = tb.z * k_per_split;
+  const int zb = tb.z % nbatch;
+  const int k_begin = (tb.z / nbatch) * k_per_split;
   int k_end = k_begin + k_per_split;
   if (k_end > K) k_end = K;
   const float sa = a_scale ? *a_scale : 1.f, sb = b_scale ? *b_scale : 1.f;
+  if constexpr (KM) {
+    if (nbatch > 1) {       // member zb: A shifted by its byte offset, C by zb x M rows
+      const unsigned o = seg.adj[zb];
+      A.p = reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(A.p) + o);
+      A.extent -= o;
+      ep.C += (size_t)zb * M * ep.ldc;
+    }
+  }
 
   f32x4 am[RB][CB];
 #pragma unroll
@@ -1669,7 +1682,8 @@ extern "C" size_t asr_gemm_hl_workspace_bytes(const asr_gemm_hl_args* a) {
   if (!a) return 0;
   const int splits = hl_splits(a, nullptr);
   if (splits <= 1) return 0;
-  return asr_align_up((size_t)splits * a->M * a->N * sizeof(float), 256);
+  const size_t nbatch = a->batch > 1 ? a->batch : 1;
+  return asr_align_up((size_t)splits * nbatch * a->M * a->N * sizeof(float), 256);
 }
 
 extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws_bytes,
@@ -1706,7 +1720,7 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
   ep.c_scale = a->c_scale; ep.c_period = a->c_scale_period > 0 ? a->c_scale_period : 1;
   ep.c_ld = a->c_scale_ld; ep.partial = nullptr;
   if (splits > 1) {
-    const size_t need = (size_t)splits * a->M * a->N * sizeof(float);
+    const size_t need = (size_t)splits * (a->batch > 1 ? a->batch : 1) * a->M * a->N * sizeof(float);
     if (!workspace || ws_bytes < need) {
       asr_set_error("gemm_hl: split-K workspace %zu < %zu bytes", ws_bytes, need);
       return ASR_ERR_WORKSPACE;
@@ -1715,8 +1729,24 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
   }
   HlSeg seg;
   seg.magic = 0u;
+  seg.batch = 0u;
   for (int i = 0; i < 16; ++i) seg.adj[i] = 0u;
   size_t ext_a_seg = ext_a;
+  const int nbatch = a->batch > 1 ? a->batch : 1;
+  if (nbatch > 1) {
+    // batch of k_major GEMMs sharing B: C_b = A_b^T B, A_b = a_hl shifted by a_batch_row[b] rows
+    ASR_CHECK_ARG(km && nbatch <= 16 && a->a_seg_k == 0 && a->beta == 0.f && !a->bias && !a->c_scale,
+                  "gemm_hl: a batch needs the k_major form, <= 16 members, no beta / bias / mask");
+    long long max_row = 0;
+    for (int b = 0; b < nbatch; ++b) {
+      ASR_CHECK_ARG(a->a_batch_row[b] >= 0, "gemm_hl: negative batch row shift");
+      if (a->a_batch_row[b] > max_row) max_row = a->a_batch_row[b];
+      seg.adj[b] = (unsigned)((unsigned long long)a->a_batch_row[b] * (unsigned long long)a->lda * 4ull);
+    }
+    seg.batch = (unsigned)nbatch;
+    ext_a_seg = ext_a + (size_t)max_row * a->lda * 4;
+    ASR_CHECK_ARG(ext_a_seg + (size_t)1024 * a->lda * 4 < lim, "gemm_hl: operand larger than 4 GiB");
+  }
   if (a->a_seg_k > 0) {
     // A's reduction range = n segments of a_seg_k indices, segment i shifted by a_seg_row[i]
     // plane rows (>= 0: the caller points a_hl at the lowest row any segment reads)
@@ -1750,7 +1780,7 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
   const int tl = big ? 256 : 128;
   const size_t shm = km ? (size_t)2 * 2 * (tl / 16) * 2 * kSubtile
                         : (size_t)2 * 4 * (tl * 32 + 32) * sizeof(_Float16);
-  const int total = ((a->M + tl - 1) / tl) * ((a->N + tl - 1) / tl) * splits;
+  const int total = ((a->M + tl - 1) / tl) * ((a->N + tl - 1) / tl) * splits * nbatch;
   const bool segd = seg.magic != 0u;
   // kernel variants: [tile 256 / 128][row-major / k-major / row-major with a segmented A]
   typedef void (*hlx_t)(HlSrc, HlSrc, int, int, int, int, int, Epilogue, const float*, const float*,
@@ -1773,12 +1803,12 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
   if (splits > 1) {
     Epilogue ep2 = ep;
     ep2.partial = nullptr;
-    const size_t tot = (size_t)a->M * a->N;
+    const size_t tot = (size_t)a->M * nbatch * a->N;
     int blocks = (int)((tot + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256),
                        lds_ballast((const void*)gemm_splitk_reduce_kernel), stream,
-                       reinterpret_cast<const float*>(workspace), splits, a->M, a->N, ep2);
+                       reinterpret_cast<const float*>(workspace), splits, a->M * nbatch, a->N, ep2);
     ASR_CHECK_LAUNCH();
   }
   return ASR_OK;

@@ -610,7 +610,7 @@ def pack_hl(src, rows, cols, ld=None, src_off=0, mask=None, mask_period=0, absma
 
 def gemm_hl(A, B, Cm, M, N, K, a_row=0, a_k=0, b_row=0, b_k=0, c_off=0, ldc=None, alpha=1.0,
             beta=0.0, bias=None, c_scale=None, c_scale_period=0, split_k=0, ws_name='gemm',
-            tile=0, k_major=False, a_seg_k=0, a_seg_rows=None):
+            tile=0, k_major=False, a_seg_k=0, a_seg_rows=None, batch_rows=None):
     """C[M,N] (float32 storage Cm, element offset c_off) = alpha * A @ B^T (+bias)(*c_scale)
     + beta*C from packed planes: A rows [a_row, a_row+M), reduction range [a_k, a_k+K) of its
     planes; B rows [b_row, b_row+N), range [b_k, b_k+K).
@@ -632,6 +632,10 @@ def gemm_hl(A, B, Cm, M, N, K, a_row=0, a_k=0, b_row=0, b_k=0, c_off=0, ldc=None
     g.split_k = _resolve_split(split_k, M, N, K)
     g.tile = int(tile)
     g.k_major = 1 if k_major else 0
+    if batch_rows is not None:      # k_major batch sharing B: C_b = A_b^T B, rows b*M.. of Cm
+        g.batch = len(batch_rows)
+        for i, r in enumerate(batch_rows):
+            g.a_batch_row[i] = int(r)
     if a_seg_k:         # segmented reduction range of A (include/asr_hip.h): K = len(rows) * a_seg_k
         g.a_seg_k = int(a_seg_k)
         for i, r in enumerate(a_seg_rows):

@@ -200,6 +200,13 @@ typedef struct asr_gemm_hl_args {
   /* (tap i of a filter reads the activation slab i frames on).  lda >= a_seg_k.                 */
   int a_seg_k;
   long long a_seg_row[16];
+  /* Batch (k_major form only; 0 / 1 = none): `batch` <= 16 GEMMs that share B in one launch,  */
+  /* C_b = A_b^T B with A_b = a_hl shifted by a_batch_row[b] (>= 0) plane rows and C_b = C +   */
+  /* b * M * ldc (the members' outputs are consecutive row blocks); no beta / bias / mask.     */
+  /* The per-tap weight gradients of asr_conv2d_wgrad.  split_k applies to every member; the   */
+  /* workspace is split_k * batch * M * N floats.                                              */
+  int batch;
+  long long a_batch_row[16];
 } asr_gemm_hl_args;
 size_t asr_gemm_hl_workspace_bytes(const asr_gemm_hl_args* a);
 int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws_bytes,

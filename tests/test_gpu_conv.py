@@ -41,6 +41,29 @@ def test_gemm_hl_segmented_reduction_range():
         assert err < 2e-6 * np.abs(a).max() * np.abs(b).max() * seg_k * len(shifts)
 
 
+def test_gemm_hl_k_major_batch_sharing_b():
+    """asr_gemm_hl batch: C_b = A_b^T B for up to 16 row-shifted views A_b of one plane array and
+    ONE B, in a single launch (the per-tap weight gradients of the convolution), with and
+    without split-K, 256 and 128 tiles."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(1)
+    for (M, N, K, shifts, split) in ((256, 300, 700, [0, 32, 16, 80], 0),
+                                     (80, 132, 500, [3, 0, 11], 3),
+                                     (512, 256, 1000, [0, 16, 32, 48, 64, 5, 7, 9, 100, 1, 2], 2)):
+        rows = K + max(shifts)
+        a = rs.randn(rows, M)
+        b = rs.randn(K, N)
+        pa, pb = ops.HlPlanes(rows, M, dev()), ops.HlPlanes(K, N, dev())
+        ta, tb = to_dev(a, torch.float32), to_dev(b, torch.float32)
+        ops.pack_hl(ta, rows, M, absmax=ops.absmax(ta), r=pa)
+        ops.pack_hl(tb, K, N, absmax=ops.absmax(tb), r=pb)
+        c = torch.full((len(shifts) * M, N), 9.0, device=dev())
+        ops.gemm_hl(pa, pb, c, M, N, K, k_major=True, batch_rows=shifts, split_k=split)
+        want = np.concatenate([a[s:s + K].T @ b for s in shifts])
+        err = report('batched k-major %dx%dx%d x%d' % (M, N, K, len(shifts)), c.cpu().numpy(), want)
+        assert err < 2e-6 * np.abs(a).max() * np.abs(b).max() * K
+
+
 CASES = [
     # T, N, F, Ci, Co, kt, kf, st, sf, clip
     (13, 5, 12, 1, 4, 5, 7, 2, 2, 1.0),        # layer-1 class: C_in = 1, stride (2, 2), odd T
