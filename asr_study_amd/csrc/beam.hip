@@ -395,10 +395,10 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
 
 typedef void (*beam_kern_t)(BeamParams);
 
-beam_kern_t pick(int W, bool dpp) {
-  if (W <= 128) return dpp ? ctc_beam_kernel<2, true> : ctc_beam_kernel<2, false>;
-  if (W <= 448) return dpp ? ctc_beam_kernel<7, true> : ctc_beam_kernel<7, false>;
-  return dpp ? ctc_beam_kernel<16, true> : ctc_beam_kernel<16, false>;
+beam_kern_t pick(int W) {           // (the lane shift of the sorted beam: DPP wave_shr:1)
+  if (W <= 128) return ctc_beam_kernel<2, true>;
+  if (W <= 448) return ctc_beam_kernel<7, true>;
+  return ctc_beam_kernel<16, true>;
 }
 
 size_t ws_per_utt(int T, int C, int W, int* max_blocks) {
@@ -447,8 +447,7 @@ extern "C" int asr_ctc_beam_device(const float* logits, const int* seq_len, int 
   p.ws = reinterpret_cast<char*>(workspace);
   p.ws_per_utt = ws_per_utt(T, C, beam_width, &p.max_blocks);
   ASR_CHECK_ARG(ws_bytes >= p.ws_per_utt * (size_t)N, "beam: workspace too small");
-  static const int use_shfl = [] { const char* v = getenv("ASR_BEAM_SHFL"); return v && *v == '1'; }();
-  beam_kern_t k = pick(beam_width, !use_shfl);
+  beam_kern_t k = pick(beam_width);
   const size_t shm = lds_bytes(beam_width);
   if (shm > 64 * 1024)
     ASR_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -1483,10 +1483,8 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // Dynamic-LDS "ballast" for the small helper kernels that run on the weight-gradient
 // stream beside a BPTT kernel: a recurrent workgroup reserves 96 KB of its CU's 160 KB,
 // so a helper asking for 80 KB can never be placed on the same CU and steal issue slots
-// from its one-wave-per-SIMD critical path (ASR_LDS_BALLAST=0 disables).
+// from its one-wave-per-SIMD critical path.
 static size_t lds_ballast(const void* kernel) {
-  static const int on = [] { const char* v = getenv("ASR_LDS_BALLAST"); return v ? atoi(v) : 1; }();
-  if (!on) return 0;
   const size_t bytes = 80 * 1024;
   (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   return bytes;
@@ -1516,8 +1514,7 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
   ASR_CHECK_ARG(a->lda >= (a->trans_a ? a->M : a->K), "gemm: lda too small");
   ASR_CHECK_ARG(a->ldb >= (a->trans_b ? a->K : a->N), "gemm: ldb too small");
   ASR_CHECK_ARG(a->ldc >= a->N, "gemm: ldc too small");
-  static const int bk_env = [] { const char* v = getenv("ASR_GEMM_BK"); return v ? atoi(v) : 16; }();
-  const int BK = bk_env == 16 ? 16 : 32;
+  constexpr int BK = 16;                       // K slab of the exact-fp32 kernel
   int splits = a->split_k > 1 ? a->split_k : 1;
   int k_per_split = (a->K + splits - 1) / splits;
   k_per_split = (k_per_split + BK - 1) / BK * BK;
@@ -1564,8 +1561,7 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
     const bool pow2 = (A.period & (A.period - 1)) == 0;
     const size_t mask_ext = A.scale ? ((size_t)(A.period - 1) * A.scale_ld +
                                        (A.mn_contig ? A.mn_total : A.k_total)) * 4 : 0;
-    static const int fast_env = [] { const char* v = getenv("ASR_GEMM_FAST"); return v ? atoi(v) : 1; }();
-    const bool fast = fast_env && A.vec_ok && B.vec_ok && a->K % 4 == 0 &&
+    const bool fast = A.vec_ok && B.vec_ok && a->K % 4 == 0 &&
                       (!A.mn_contig || a->M % 4 == 0) && (!B.mn_contig || a->N % 4 == 0) &&
                       extent(A) < lim && extent(B) < lim &&
                       (!A.scale || (A.scale_vec && pow2 && mask_ext < lim));
@@ -1577,7 +1573,6 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
       fb_.p = B.p; fb_.ld = B.ld; fb_.mn_total = B.mn_total; fb_.extent = (unsigned)extent(B);
       fb_.scale = nullptr; fb_.pmask = 0; fb_.scale_ld = 0; fb_.scale_extent = 0;
       const int total = tiles_mn * sp;
-      static const int nbuf = [] { const char* v = getenv("ASR_GEMM_NBUF"); return v ? atoi(v) : 2; }();
       const int key = (A.mn_contig ? 4 : 0) | (B.mn_contig ? 2 : 0) | (A.scale ? 1 : 0);
 #define ASR_FAST_CASE(KEY, AMN, BMN, MASK)                                                    \
       case KEY: {                                                                              \
@@ -1588,14 +1583,9 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                          \
           done = true;                                                                         \
         }                                                                                      \
-        if (nbuf == 1)                                                                         \
-          hipLaunchKernelGGL((gemm_f16x2_fast_kernel<AMN, BMN, MASK, 1>), dim3(total),         \
-                             dim3(256), shm / 2, stream, fa_, fb_, a->M, a->N, a->K, kps, sp,  \
-                             ep, hs);                                                          \
-        else                                                                                   \
-          hipLaunchKernelGGL((gemm_f16x2_fast_kernel<AMN, BMN, MASK, 2>), dim3(total),         \
-                             dim3(256), shm, stream, fa_, fb_, a->M, a->N, a->K, kps, sp, ep,  \
-                             hs);                                                              \
+        hipLaunchKernelGGL((gemm_f16x2_fast_kernel<AMN, BMN, MASK, 2>), dim3(total),           \
+                           dim3(256), shm, stream, fa_, fb_, a->M, a->N, a->K, kps, sp, ep,    \
+                           hs);                                                                \
       } break;
       switch (key) {
         ASR_FAST_CASE(0, false, false, false)
@@ -1613,11 +1603,8 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
                          kps, ep, hs);
     }
     splits = sp;
-  } else if (BK == 16)
+  } else
     hipLaunchKernelGGL(gemm_f32_mfma_kernel<16>, grid, dim3(256), 0, stream, A, B, a->M, a->N,
-                       a->K, k_per_split, ep);
-  else
-    hipLaunchKernelGGL(gemm_f32_mfma_kernel<32>, grid, dim3(256), 0, stream, A, B, a->M, a->N,
                        a->K, k_per_split, ep);
   ASR_CHECK_LAUNCH();
   if (splits > 1) {
@@ -1774,9 +1761,8 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
   B.p = reinterpret_cast<const _Float16*>(a->b_hl);
   B.ld = a->ldb; B.rows = a->N; B.extent = (unsigned)ext_b;
   // tile: 256 x 256 (512 threads, 128 KB LDS) for outputs of at least that size, else 128 x 128
-  // (256 threads, 64 KB; asr_gemm_hl_args.tile = 128 or ASR_GEMM_HL_TILE=128 force it)
-  static const int tile_env = [] { const char* v = getenv("ASR_GEMM_HL_TILE"); return v ? atoi(v) : 256; }();
-  const bool big = tile_env >= 256 && a->tile != 128 && a->M >= 256 && a->N >= 256;
+  // (256 threads, 64 KB; asr_gemm_hl_args.tile = 128 forces it)
+  const bool big = a->tile != 128 && a->M >= 256 && a->N >= 256;
   const int tl = big ? 256 : 128;
   const size_t shm = km ? (size_t)2 * 2 * (tl / 16) * 2 * kSubtile
                         : (size_t)2 * 4 * (tl * 32 + 32) * sizeof(_Float16);

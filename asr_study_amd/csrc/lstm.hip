@@ -45,7 +45,7 @@
 //  * Kernel choice is asr_lstm_plan's (make_plan): _x / _c for the plain cell at
 //    H = 256 / 512 in persistent mode, _h / _hv otherwise (any H <= 512, variants,
 //    stepwise); ASR_LSTM_GENERIC=1 forces _h (the tests compare the two).
-//  * A step's first poll is preceded by a short nap (ASR_LSTM_PREPOLL_F/_B): a poll
+//  * A step's first poll is preceded by a short nap (LstmParams::prepoll): a poll
 //    that reaches the L2 before the producers' stores costs a whole extra round trip.
 //  * The optional cell variants (multiplicative integration, zoneout) are the VAR
 //    template paths, compiled into their own kernels (lstm_*_kernel_hv); layer
@@ -91,11 +91,7 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-int fwd_xstride() {
-  int v = env_int("ASR_LSTM_XSTRIDE", 256);
-  if (v < 256 || (v & 255)) v = 256;
-  return v;
-}
+int fwd_xstride() { return 256; }   // bytes between consecutive unit-group tiles of a slot
 
 bool fwd_progressive(int H) { return env_int("ASR_LSTM_PROG", H <= 256 ? 1 : 0) != 0; }
 
@@ -117,7 +113,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   pl.n1 = 0;
   pl.form_c = 0;
   if (!bwd && a->n_valid == 1 && a->mode == 0 && (H == 256 || H == 512) &&
-      !(a->mi || a->zone_c || a->zone_h || a->uh) && env_int("ASR_LSTM_N1", 1)) {
+      !(a->mi || a->zone_c || a->zone_h || a->uh)) {
     // one utterance: the tile-free exact-fp32 kernel (fwd_body_n1); 2 chains = 2 directions
     pl.R = 0; pl.TPW = 0; pl.NKK = 0; pl.n1 = 1;
     pl.shm = (size_t)(H + 256) * 4;
@@ -210,13 +206,12 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   if (pl.shm < (size_t)pl.P * 4 + 16) pl.shm = (size_t)pl.P * 4 + 16;
   // Own the CU: a latency-bound workgroup must not share its SIMDs / LDS pipe with the
   // GEMM workgroups (80 KB LDS each) that the host overlaps on a second stream, so it
-  // reserves enough LDS that none of those fits beside it (ASR_LSTM_EXCL=0 disables).
+  // reserves enough LDS that none of those fits beside it.
   // (asr_lstm_args.lds_reserve_kb = 80 lets exactly TWO recurrent workgroups share a CU and
   // still keeps every 80 KB GEMM workgroup out: the caller then confines the launch to half
   // of the CUs with a CU-masked stream and leaves the other half to the GEMM streams)
-  static const int excl = env_int("ASR_LSTM_EXCL", 1);
   const size_t reserve = (size_t)(a->lds_reserve_kb > 0 ? a->lds_reserve_kb : 96) * 1024;
-  if (excl && pl.shm < reserve) pl.shm = reserve;
+  if (pl.shm < reserve) pl.shm = reserve;
   if (pl.shm > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)pl.shm) != hipSuccess) {
@@ -347,18 +342,17 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.poll = stepwise ? 0 : 1;
   p.allow_fast = env_int("ASR_LSTM_FAST", 1);
   p.dbg = env_int("ASR_LSTM_DBG", 0);
-  // measured optimum on MI355X (tools/sweep_poll.sh, tools/sweep_r2c.sh): forward 8-16 naps
-  // (~0.4 us; flat in that range), BPTT 4
+  // naps (64 clocks each) before a step's first poll, measured optimum on MI355X (sweeps of
+  // rounds 1-3): forward 12-16 (~0.4 us; flat in that range), BPTT 4 / 2
   // (the progressive forward step polls at once: a partly stale poll still delivers work)
   const bool prog_f = !bwd && pl.prec == 1 && (a->H == 256 || a->H == 512) && fwd_progressive(a->H);
-  p.prepoll = bwd ? env_int("ASR_LSTM_PREPOLL_B", pl.form_c ? 2 : 4)
-                  : env_int("ASR_LSTM_PREPOLL_F", prog_f ? 0 : (pl.P <= 16 ? 12 : 16));
-  p.repoll = bwd ? env_int("ASR_LSTM_REPOLL_B", 1) : env_int("ASR_LSTM_REPOLL_F", 1);
+  p.prepoll = bwd ? (pl.form_c ? 2 : 4) : (prog_f ? 0 : (pl.P <= 16 ? 12 : 16));
+  p.repoll = 1;
   p.xstride = fwd_xstride();
   // ASR_LSTM_SPIN_MS: bound of a persistent kernel's spins in milliseconds (default 600)
   p.spin = (long long)env_int("ASR_LSTM_SPIN_MS", 600) * 100000LL;
   p.trace = nullptr;
-  p.trace_s0 = env_int("ASR_LSTM_TRACE_STEP", 500);
+  p.trace_s0 = p.T > 32 ? p.T / 2 : 1;            // the 16 traced steps: mid-sequence
   if (p.dbg & 128) {
     if (!g_trace) ASR_CHECK_HIP(hipMalloc(&g_trace, kTraceBytes));
     ASR_CHECK_HIP(hipMemsetAsync(g_trace, 0, kTraceBytes, stream));
@@ -444,7 +438,7 @@ extern "C" int asr_lstm_profile(const void* workspace, asr_stream_t stream_, lon
 
 // Debug: the hand-off timeline of the last launch made with ASR_LSTM_DBG & 128 (forward
 // kernel_x only): out[((block * 4 + wave) * 16 + step) * 2 + {0: data arrived, 1: published}]
-// in ticks of the 100 MHz clock, steps ASR_LSTM_TRACE_STEP .. + 15, block = blockIdx.
+// in ticks of the 100 MHz clock, 16 steps from the middle of the sequence, block = blockIdx.
 extern "C" int asr_lstm_trace(long long* out, size_t n_words, asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ASR_CHECK_ARG(out && g_trace && n_words * sizeof(long long) <= kTraceBytes, "lstm_trace: no trace");

@@ -234,7 +234,7 @@ def _fe_job(job):
 def predict_latency(dev):
     """predict.py's unit of work (predict.py:73-93): ONE 10 s utterance through front-end,
     5 x BiLSTM(256) forward (brsmv1 defaults) and greedy decode, in milliseconds per
-    utterance, with the single-utterance recurrent kernel and with the 16-row batch kernel."""
+    utterance (the single-utterance recurrent kernel, fwd_body_n1)."""
     import torch
     from asr_study_amd import ops
     from asr_study_amd.core import models
@@ -244,23 +244,19 @@ def predict_latency(dev):
     feat = audio.MFCC(device=dev)
     sig = np.random.RandomState(5).randn(SAMPLES).astype(np.float32)
     out = {'utterance_seconds': 10.0, 'topology': 'brsmv1 5xBiLSTM(256), MFCC-39'}
-    for name, env in (('n1_kernel_ms', '1'), ('batch_tile_kernel_ms', '0')):
-        os.environ['ASR_LSTM_N1'] = env
-
-        def once():
-            slab, frames = feat.batch([sig])
-            logits = model.forward(slab, training=False, need_grad=False, n_valid=1)
-            return ops.ctc_greedy(logits, frames, 1)
-        for _ in range(3):
-            once()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 10
-        for _ in range(reps):
-            once()
-        torch.cuda.synchronize()
-        out[name] = round((time.perf_counter() - t0) / reps * 1e3, 3)
-    os.environ.pop('ASR_LSTM_N1', None)
+    def once():
+        slab, frames = feat.batch([sig])
+        logits = model.forward(slab, training=False, need_grad=False, n_valid=1)
+        return ops.ctc_greedy(logits, frames, 1)
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        once()
+    torch.cuda.synchronize()
+    out['n1_kernel_ms'] = round((time.perf_counter() - t0) / reps * 1e3, 3)
     for ws in ('lstm_fwd',):
         ops.lstm_status(ops.WS.get(ws, 0, dev))
     out['real_time_factor'] = round(10.0 / (out['n1_kernel_ms'] * 1e-3), 1)

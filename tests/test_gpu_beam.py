@@ -100,26 +100,6 @@ def test_device_beam_full_length_width_400_and_timing():
         assert (d[:4] == d[4:8]).all()
 
 
-def test_shuffle_variant_of_the_shift_gives_the_same_beams():
-    """ASR_BEAM_SHFL=1 replaces the DPP wave_shr:1 shift by ds_bpermute shuffles."""
-    code = (
-        "import numpy as np, torch\n"
-        "from asr_study_amd import ops\n"
-        "rs = np.random.RandomState(2)\n"
-        "x = rs.randn(40, 16, 28).astype(np.float32)\n"
-        "sl = torch.tensor([40] * 16, dtype=torch.int32).cuda()\n"
-        "for W in (100, 400, 600):\n"
-        "    d, l, s = ops.ctc_beam_search(torch.from_numpy(x).cuda(), sl, 16, W)\n"
-        "    h, hs = ops.ctc_beam_search_host(x, [40] * 16, 16, W)\n"
-        "    d, l = d.cpu().numpy(), l.cpu().numpy()\n"
-        "    assert [d[n, :l[n]].tolist() for n in range(16)] == h\n"
-        "print('same')\n")
-    env = dict(os.environ, ASR_BEAM_SHFL='1')
-    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
-                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert out.returncode == 0 and 'same' in out.stdout, out.stderr[-2000:]
-
-
 def test_eval_mode_model_decodes_on_the_device(monkeypatch):
     """engine.Model with a beam decoder (load_model(mode='eval') semantics) under
     ASR_BEAM=device: predict and test_on_batch never copy the logits to the host

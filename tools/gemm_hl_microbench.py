@@ -1,5 +1,5 @@
 """GEMM shapes of one BiLSTM layer (cfg3 / cfg2) on packed split-fp16 planes (asr_pack_hl +
-asr_gemm_hl; tile size from ASR_GEMM_HL_TILE) next to the convert-per-tile kernel (asr_gemm)."""
+asr_gemm_hl) next to the convert-per-tile kernel (asr_gemm)."""
 import os
 import sys
 sys.path.insert(0, os.getcwd())

@@ -5,7 +5,7 @@ profiler (ASR_LSTM_DBG=32), shader clocks per phase and wave of workgroup 0.
     python tools/rec_bench.py cfg3 [--fwd] [--bwd] VAR=VALUE[,VAR=VALUE...] ...
 
 Each positional VAR=VALUE group is one variant (environment switches read per launch by
-csrc/lstm.hip: ASR_LSTM_BWD_2D, ASR_LSTM_PREPOLL_B, ASR_LSTM_FAST ...); 'base' = no switch."""
+csrc/lstm.hip: ASR_LSTM_BWD_2D, ASR_LSTM_PROG, ASR_LSTM_FAST ...); 'base' = no switch."""
 import os
 import sys
 
