@@ -546,6 +546,8 @@ extern "C" int asr_ctc_loss_grad(const float* logits, const int* labels,
                                  asr_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ASR_CHECK_ARG(logits && labels && label_len && seq_len && loss, "ctc: null pointer");
+  // the gradient kernel re-reads the logits of neighbouring frames while other waves write grad
+  ASR_CHECK_ARG(grad != logits, "ctc: grad must not alias logits");
   ASR_CHECK_ARG(T > 0 && N > 0 && n_pad >= N && C >= 2 && l_max >= 1,
                 "ctc: bad shape T=%d N=%d n_pad=%d C=%d l_max=%d", T, N, n_pad, C, l_max);
   const int ppl = pick_ppl(l_max);

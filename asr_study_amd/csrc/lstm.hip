@@ -346,7 +346,9 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   // rounds 1-3): forward 12-16 (~0.4 us; flat in that range), BPTT 4 / 2
   // (the progressive forward step polls at once: a partly stale poll still delivers work)
   const bool prog_f = !bwd && pl.prec == 1 && (a->H == 256 || a->H == 512) && fwd_progressive(a->H);
-  p.prepoll = bwd ? (pl.form_c ? 2 : 4) : (prog_f ? 0 : (pl.P <= 16 ? 12 : 16));
+  // (ASR_LSTM_PROG = n > 1: progressive with n naps before the first poll -- measurement switch)
+  const int prog_naps = env_int("ASR_LSTM_PROG", 0) > 1 ? env_int("ASR_LSTM_PROG", 0) : 0;
+  p.prepoll = bwd ? (pl.form_c ? 2 : 4) : (prog_f ? prog_naps : (pl.P <= 16 ? 12 : 16));
   p.repoll = 1;
   p.xstride = fwd_xstride();
   // ASR_LSTM_SPIN_MS: bound of a persistent kernel's spins in milliseconds (default 600)

@@ -365,44 +365,63 @@ template <> struct FwdMfma<4> {
   }
 };
 
-// PROGRESSIVE step (fwd_body_x<.., SLAB>; the default at H = 256): the 32-deep slabs of a wave's K
-// slice are polled SEPARATELY.  A slab whose two producer workgroups have published is
-// multiplied at once, the others are polled again -- their loads only: a finished slab's offset
-// is sent out of the descriptor's range, which costs no memory traffic and keeps every load
-// unconditional (rule (3) of DESIGN.md 5).  No nap before the first poll: a poll that comes
-// back partly stale has still delivered work, and a wave that missed one slab re-reads 2 KB,
-// not its whole slice, so the four waves reach the step's barrier closer together (measured at
-// H = 256: 1.53 -> 1.40 us per step, the barrier wait 494 -> 175 clocks; at H = 512 the extra
-// VALU of the per-slab bookkeeping -- ~100 instructions on a one-wave-per-SIMD critical path --
-// costs more than the polling gains: 1.73 -> 2.05, so H = 512 keeps the single gather).
-// One slab = four gate tiles x (uh bl, uh bh, then + ul bh): twelve MFMAs on eight
-// accumulators, each reused eight MFMAs later.  The slab's contribution is r_j = am_j +
-// ac_j / 2048; the slabs' r are added in the FIXED order (r0 + r1) + (r2 + r3) whatever order
-// they arrived in: the result is deterministic (and differs from the chained form of the
-// single-gather kernel by the summation order only, < 4e-7).
+// PROGRESSIVE step (fwd_body_x<.., SLAB>): the 32-deep slabs of a wave's K slice are polled
+// SEPARATELY.  A slab whose two producer workgroups have published is multiplied as soon as the
+// slabs before it are done, the others are polled again -- their loads only: a finished slab's
+// offset is sent out of the descriptor's range, which costs no memory traffic and keeps every
+// load unconditional (rule (3) of DESIGN.md 5).  No nap before the first poll: a poll that
+// comes back partly stale has still delivered work, and a wave that missed one slab re-reads
+// 2 KB, not its whole slice, so the four waves reach the step's barrier closer together.
+// The slabs are multiplied IN ORDER into the same accumulator chains as the single-gather form
+// (per slab and gate tile: ac += uh bl, am += uh bh, ac += ul bh), so the result is bit-identical
+// to it whatever the arrival order.  One slab = twelve MFMAs on eight accumulators, an
+// accumulator is reused four MFMAs (64 cycles of pipe) later at the earliest.
+template <bool FIRST>
 __device__ __forceinline__ void fwd_slab_mfma(f32x4 (&am)[4], f32x4 (&ac)[4], const f32x4& uh0,
                                               const f32x4& uh1, const f32x4& uh2, const f32x4& uh3,
                                               const f32x4& ul0, const f32x4& ul1, const f32x4& ul2,
                                               const f32x4& ul3, const h8& bh, const h8& bl) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_mfma_f32_16x16x32_f16 %4, %8, %17, 0\n\t"        // ac_j  = uh_j bl
-      "v_mfma_f32_16x16x32_f16 %5, %9, %17, 0\n\t"
-      "v_mfma_f32_16x16x32_f16 %6, %10, %17, 0\n\t"
-      "v_mfma_f32_16x16x32_f16 %7, %11, %17, 0\n\t"
-      "v_mfma_f32_16x16x32_f16 %0, %8, %16, 0\n\t"        // am_j  = uh_j bh
-      "v_mfma_f32_16x16x32_f16 %1, %9, %16, 0\n\t"
-      "v_mfma_f32_16x16x32_f16 %2, %10, %16, 0\n\t"
-      "v_mfma_f32_16x16x32_f16 %3, %11, %16, 0\n\t"
-      "v_mfma_f32_16x16x32_f16 %4, %12, %16, %4\n\t"      // ac_j += ul_j bh
-      "v_mfma_f32_16x16x32_f16 %5, %13, %16, %5\n\t"
-      "v_mfma_f32_16x16x32_f16 %6, %14, %16, %6\n\t"
-      "v_mfma_f32_16x16x32_f16 %7, %15, %16, %7\n\t"
-      "s_nop 11"
-      : "=&v"(am[0]), "=&v"(am[1]), "=&v"(am[2]), "=&v"(am[3]), "=&v"(ac[0]), "=&v"(ac[1]),
-        "=&v"(ac[2]), "=&v"(ac[3])
-      : "a"(uh0), "a"(uh1), "a"(uh2), "a"(uh3), "a"(ul0), "a"(ul1), "a"(ul2), "a"(ul3), "v"(bh),
-        "v"(bl));
+  if constexpr (FIRST) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %4, %8, %17, 0\n\t"        // ac_j  = uh_j bl
+        "v_mfma_f32_16x16x32_f16 %5, %9, %17, 0\n\t"
+        "v_mfma_f32_16x16x32_f16 %6, %10, %17, 0\n\t"
+        "v_mfma_f32_16x16x32_f16 %7, %11, %17, 0\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %8, %16, 0\n\t"        // am_j  = uh_j bh
+        "v_mfma_f32_16x16x32_f16 %1, %9, %16, 0\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %10, %16, 0\n\t"
+        "v_mfma_f32_16x16x32_f16 %3, %11, %16, 0\n\t"
+        "v_mfma_f32_16x16x32_f16 %4, %12, %16, %4\n\t"      // ac_j += ul_j bh
+        "v_mfma_f32_16x16x32_f16 %5, %13, %16, %5\n\t"
+        "v_mfma_f32_16x16x32_f16 %6, %14, %16, %6\n\t"
+        "v_mfma_f32_16x16x32_f16 %7, %15, %16, %7\n\t"
+        "s_nop 11"
+        : "=&v"(am[0]), "=&v"(am[1]), "=&v"(am[2]), "=&v"(am[3]), "=&v"(ac[0]), "=&v"(ac[1]),
+          "=&v"(ac[2]), "=&v"(ac[3])
+        : "a"(uh0), "a"(uh1), "a"(uh2), "a"(uh3), "a"(ul0), "a"(ul1), "a"(ul2), "a"(ul3), "v"(bh),
+          "v"(bl));
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %4, %8, %17, %4\n\t"       // ac_j += uh_j bl
+        "v_mfma_f32_16x16x32_f16 %5, %9, %17, %5\n\t"
+        "v_mfma_f32_16x16x32_f16 %6, %10, %17, %6\n\t"
+        "v_mfma_f32_16x16x32_f16 %7, %11, %17, %7\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %8, %16, %0\n\t"       // am_j += uh_j bh
+        "v_mfma_f32_16x16x32_f16 %1, %9, %16, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %10, %16, %2\n\t"
+        "v_mfma_f32_16x16x32_f16 %3, %11, %16, %3\n\t"
+        "v_mfma_f32_16x16x32_f16 %4, %12, %16, %4\n\t"      // ac_j += ul_j bh
+        "v_mfma_f32_16x16x32_f16 %5, %13, %16, %5\n\t"
+        "v_mfma_f32_16x16x32_f16 %6, %14, %16, %6\n\t"
+        "v_mfma_f32_16x16x32_f16 %7, %15, %16, %7\n\t"
+        "s_nop 11"
+        : "+v"(am[0]), "+v"(am[1]), "+v"(am[2]), "+v"(am[3]), "+v"(ac[0]), "+v"(ac[1]), "+v"(ac[2]),
+          "+v"(ac[3])
+        : "a"(uh0), "a"(uh1), "a"(uh2), "a"(uh3), "a"(ul0), "a"(ul1), "a"(ul2), "a"(ul3), "v"(bh),
+          "v"(bl));
+  }
 }
 
 template <int NKW, bool FAST, bool EXACT, bool SLAB = false>
@@ -626,7 +645,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     prof.stamp(0);
     const unsigned flip = 0u - ((unsigned)((s - 1) >> 1) & 1u);
     const __amdgpu_buffer_rsrc_t rsrc = slot(0, s - 1);
-    f32x4 r[NKW][4];
+    f32x4 am[4], ac[4];
     unsigned pend = (1u << NKW) - 1u;              // wave-uniform: slabs not yet multiplied
     long long t0 = 0;
     int round = 0;
@@ -640,13 +659,17 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
         v[0][2 * kk + 1] = __builtin_amdgcn_raw_buffer_load_b128(
             rsrc, o, (unsigned)(8 * kk + 1) * gstep, FAST ? kNt : kSc1);
       }
+      bool blocked = false;                        // a slab before this one is still missing
 #pragma unroll
       for (int kk = 0; kk < NKW; ++kk) {
-        if (!((pend >> kk) & 1u)) continue;
+        if (!((pend >> kk) & 1u) || blocked) continue;
         const u32x4 q0 = v[0][2 * kk], q1 = v[0][2 * kk + 1];
         const unsigned x = (((q0[0] ^ flip) | (q0[1] ^ flip)) | ((q0[2] ^ flip) | (q0[3] ^ flip))) |
                            (((q1[0] ^ flip) | (q1[1] ^ flip)) | ((q1[2] ^ flip) | (q1[3] ^ flip)));
-        if (__builtin_amdgcn_ballot_w64((x & 1u) != 0u) != 0ull && p.poll && !dead) continue;
+        if (__builtin_amdgcn_ballot_w64((x & 1u) != 0u) != 0ull && p.poll && !dead) {
+          blocked = true;
+          continue;
+        }
         u32x4 hi, lo;
         hi[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x07060302u);
         hi[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x07060302u);
@@ -656,14 +679,14 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
         lo[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x05040100u);
         lo[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x05040100u);
         lo[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x05040100u);
-        f32x4 am[4], ac[4];
-        fwd_slab_mfma(am, ac, ufh[0][kk], ufh[1][kk], ufh[2][kk], ufh[3][kk], ufl[0][kk],
-                      ufl[1][kk], ufl[2][kk], ufl[3][kk], __builtin_bit_cast(h8, hi),
-                      __builtin_bit_cast(h8, lo));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) r[kk][j][e] = __builtin_fmaf(ac[j][e], 1.f / kLoScale, am[j][e]);
+        if (kk == 0)
+          fwd_slab_mfma<true>(am, ac, ufh[0][kk], ufh[1][kk], ufh[2][kk], ufh[3][kk], ufl[0][kk],
+                              ufl[1][kk], ufl[2][kk], ufl[3][kk], __builtin_bit_cast(h8, hi),
+                              __builtin_bit_cast(h8, lo));
+        else
+          fwd_slab_mfma<false>(am, ac, ufh[0][kk], ufh[1][kk], ufh[2][kk], ufh[3][kk], ufl[0][kk],
+                               ufl[1][kk], ufl[2][kk], ufl[3][kk], __builtin_bit_cast(h8, hi),
+                               __builtin_bit_cast(h8, lo));
         pend &= ~(1u << kk);
       }
       if (pend != 0u) {
@@ -685,8 +708,8 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 t;
-      if constexpr (NKW == 4) t = (r[0][j] + r[1][j]) + (r[2][j] + r[3][j]);
-      else t = r[0][j] + r[1][j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = __builtin_fmaf(ac[j][e], 1.f / kLoScale, am[j][e]);
       mine[j * 64 + lane] = t;
     }
     prof.stamp(2);

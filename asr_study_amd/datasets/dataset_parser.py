@@ -45,10 +45,18 @@ class DatasetParser(object):
                     slab, frames = input_parser.batch(sigs)
                     # utterance-major on the device (one strided copy kernel), ONE D2H copy per
                     # chunk, then contiguous (T_j * F) host slices
-                    host = slab.transpose(0, 1).contiguous().cpu().numpy()
+                    # (only the chunk's real utterances: the n_pad - len(sigs) padding rows of
+                    # the slab never reach the host)
+                    host = slab[:, :len(sigs)].transpose(0, 1).contiguous().cpu().numpy()
                     frames = frames.cpu().numpy()
                     nf = host.shape[2]
-                    feats += [host[j, :frames[j]].reshape(-1) for j in range(len(sigs))]
+                    if len(set(int(f) for f in frames[:len(sigs)])) == 1:
+                        # equal lengths: views into the chunk cost nothing extra
+                        feats += [host[j, :frames[j]].reshape(-1) for j in range(len(sigs))]
+                    else:
+                        # ragged corpus: compact copies, so that a chunk's (n, T_max, F) buffer
+                        # is not kept alive by views until the file is written
+                        feats += [host[j, :frames[j]].reshape(-1).copy() for j in range(len(sigs))]
                 else:
                     feats += [s.astype(np.float32).reshape(-1) for s in sigs]
             store[key] = dict(inputs=feats, num_feats=nf,

@@ -375,7 +375,9 @@ int asr_lstm_profile(const void* workspace, asr_stream_t stream, long long* out2
 /* label_len/seq_len (N) int32, all on the device.  loss[n] = -log p(l|x);   */
 /* grad = grad_scale * d loss_n / d logits, 0 for t >= seq_len[n] and for    */
 /* padding rows n >= N.  An infeasible target yields loss = +inf, grad = 0   */
-/* (the host raises the TF error before launching).                          */
+/* (the host raises the TF error before launching).  grad may be NULL (loss  */
+/* only) and must NOT alias logits (the gradient kernel re-reads the logits  */
+/* of neighbouring frames while other waves write grad): ASR_ERR_INVALID.    */
 /* ------------------------------------------------------------------------ */
 size_t asr_ctc_workspace_bytes(int T, int N, int n_pad, int C, int l_max);
 int asr_ctc_loss_grad(const float* logits, const int* labels,
