@@ -14,4 +14,4 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BU
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/step_$i -o g -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/step_$i.log 2>&1 </dev/null
 done
-python tools/pmc_parse.py $out $out/summary.md lstm_ gemm_hlx pack_hl ctc_ adam norm_partial fe_ | grep -v "^  " | head -30
+python tools/pmc_parse.py $out $out/summary.md lstm_ gemm_hlx pack_hl ctc_ adam norm_partial fe_ gemm_splitk | grep -v "^  " | head -40
