@@ -68,6 +68,39 @@ def test_train_eval_cli_roundtrip(tmp_path, capsys):
         assert int(f['predictions'].attrs['num_labels']) == 28
 
 
+def test_deep_speech2_through_the_command_lines(tmp_path, capsys):
+    """The conv front-end model through the reference's own command lines: make_dataset
+    (log-mel on the GPU -> HDF5) -> train.py --model deep_speech2 (2 epochs, checkpoints with
+    convolution2d_k groups) -> eval.py (beam search on ceil(len / 2) frames) -> predict.py."""
+    sys.path.insert(0, ROOT)
+    import train
+    import eval as eval_cli
+    import predict as predict_cli
+    from asr_study_amd import cli
+    from asr_study_amd.datasets import h5lite
+    fname = str(tmp_path / ('mel.h5' if h5lite.available() else 'mel.npz'))
+    cli.make_dataset_main(['--parser', 'dummy', '--parser_params', 'num_speakers', '4',
+                           'num_utterances_per_speaker', '6', 'max_duration', '1.2',
+                           'min_duration', '0.6', 'max_label_length', '6', 'split',
+                           '[0.5, 0.25]', 'seed', '5', '--input_parser', 'logfbank',
+                           '--input_parser_params', 'num_filt', '16', '--output_file', fname])
+    out = str(tmp_path / 'ds2')
+    train.main(['--dataset', fname, '--model', 'deep_speech2', '--model_params', 'num_features',
+                '16', 'num_hiddens', '16', 'num_layers', '2', 'conv_filters', '4', '--num_epochs',
+                '2', '--batch_size', '4', '--save', out, '--seed', '1', '--lr', '0.01'])
+    assert os.path.exists(os.path.join(out, 'best.h5'))
+    with h5lite.File(os.path.join(out, 'best.h5'), 'r') as f:
+        names = f['model_weights'].attrs.get_strings('layer_names')
+    assert names[:2] == ['convolution2d_1', 'convolution2d_2'] and 'bidirectional_2' in names
+    m = eval_cli.main(['--model', os.path.join(out, 'best.h5'), '--dataset', fname,
+                       '--beam_width', '20'])
+    assert len(m) == 4 and np.isfinite(m[1]) and m[3] >= 0
+    res = predict_cli.main(['--model', os.path.join(out, 'best.h5'), '--dataset', fname,
+                            '--beam_width', '10'])
+    assert len(res) > 0 and all(isinstance(r['best'], str) for r in res)
+    capsys.readouterr()
+
+
 def test_cfg5_beam_search_ler_matches_oracle(tmp_path):
     """Beam width 100 (README) and 400 (code default): identical top-1 strings and
     LER to the oracle decoder run on the same logits."""
