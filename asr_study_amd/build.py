@@ -48,7 +48,11 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libasr_hip.so.  Safe to call from
     several processes at once (one rank per GPU): an exclusive file lock serialises
     them, the first one builds, the others find the library current."""
+    force = force or os.environ.get('ASR_BUILD_FORCE') == '1'
     if not force and not _stale():
+        print('asr_study_amd.build: libasr_hip.so is current (source hash %s...): nothing to compile; '
+              'ASR_BUILD_FORCE=1 recompiles all %d sources' % (_source_hash()[:12], len(SOURCES)),
+              file=sys.stderr)
         return LIB
     import fcntl
     with open(LIB + '.lock', 'w') as lock:
@@ -82,6 +86,8 @@ def _compile(verbose):
     cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs + ['-lpthread', '-ldl']
     subprocess.check_call(cmd)
     os.replace(tmp, LIB)                     # atomic: a loader never sees a partial file
+    print('asr_study_amd.build: compiled %d sources for %s with %s -> %s'
+          % (len(SOURCES), ARCH, hipcc, LIB), file=sys.stderr)
     with open(STAMP, 'w') as f:
         f.write(_source_hash() + '\n')
 
