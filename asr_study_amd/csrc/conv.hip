@@ -35,6 +35,19 @@ struct Geo {
   int qmin, S;                    // phase layout of the x planes: slots s - qmin in [0, S)
   int padb, pada;                 // zero frames before / behind the dz planes
   long long M;                    // output rows T_out * n_pad
+  // Frequency blocks: the band of a time tap is kf / F_in dense, so the output frequencies are
+  // cut into nblk equal blocks; block b (outputs [fo0, fo0 + nfo)) only reads the input
+  // frequencies [fi0, fi0 + nfi) its filters reach -- a GEMM on a column range of the same
+  // planes with a shorter reduction (second layer of the front-end: 2 blocks, 30 / 29 of 40
+  // input frequencies: 25 % fewer MFMAs).  nblk = 1: the whole band.
+  int nblk;
+  int b_fo0[4], b_nfo[4], b_fi0[4], b_nfi[4];
+  // The weight gradient cuts the band by ROWS instead (tile-aligned blocks of input
+  // frequencies, each with the output frequencies that reach it): its result is the band
+  // itself, so what counts there is the number of 256 x 256 tiles covering the nonzeros
+  // (second layer: 5 row blocks x 2 tiles instead of 5 x 3).  nwblk = 1: the whole band.
+  int nwblk;
+  int w_fo0[8], w_nfo[8], w_fi0[8], w_nfi[8];
 };
 
 __host__ __device__ inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -60,8 +73,70 @@ bool make_geo(const asr_conv2d_args* a, Geo* g) {
   g->padb = a->kt - 1 - g->pt; g->pada = g->pt;
   if (g->padb < 0) g->padb = 0;
   g->M = (long long)g->T_out * a->n_pad;
+  // blocks need whole (hi, lo) groups / slabs at every cut: C_in % 32 == 0 (reduction offsets
+  // and lengths of the forward and weight-gradient GEMMs), nfo * C_out % 32 == 0 (those of the
+  // dgrad), and stay at least 256 output columns wide (the 256 x 256 tile)
+  g->nblk = 1;
+  for (int nb = 4; nb >= 2; --nb) {
+    if (g->F_out % nb || a->C_in % 32) continue;
+    const int nfo = g->F_out / nb;
+    if ((nfo * a->C_out) % 32 || nfo * a->C_out < 256) continue;
+    const int reach = a->sf * (nfo - 1) + a->kf;            // input frequencies a block touches
+    if (reach >= a->F_in) continue;                          // nothing to save
+    g->nblk = nb;
+    break;
+  }
+  for (int b = 0; b < g->nblk; ++b) {
+    const int nfo = g->F_out / g->nblk, fo0 = b * nfo;
+    int lo = a->sf * fo0 - g->pf, hi = a->sf * (fo0 + nfo - 1) - g->pf + a->kf;
+    if (lo < 0) lo = 0;
+    if (hi > a->F_in) hi = a->F_in;
+    g->b_fo0[b] = fo0; g->b_nfo[b] = nfo; g->b_fi0[b] = lo; g->b_nfi[b] = hi - lo;
+  }
+  if (g->nblk == 1) { g->b_fi0[0] = 0; g->b_nfi[0] = a->F_in; }
+  // row blocks of the weight gradient: fpb input frequencies = one 256-row tile
+  g->nwblk = 1;
+  g->w_fo0[0] = 0; g->w_nfo[0] = g->F_out; g->w_fi0[0] = 0; g->w_nfi[0] = a->F_in;
+  if (a->C_in % 32 == 0 && a->C_out % 32 == 0 && 256 % a->C_in == 0) {
+    int fpb = 256 / a->C_in;
+    while ((a->F_in + fpb - 1) / fpb > 8) fpb *= 2;
+    const int nb = (a->F_in + fpb - 1) / fpb;
+    int tiles = 0, fo0[8], nfo[8];
+    for (int b = 0; b < nb; ++b) {
+      const int fi0 = b * fpb, fi1 = (fi0 + fpb < a->F_in ? fi0 + fpb : a->F_in) - 1;
+      // fo reaches fi when 0 <= fi - sf fo + pf < kf
+      int lo = -floordiv(-(fi0 + g->pf - (a->kf - 1)), a->sf), hi = floordiv(fi1 + g->pf, a->sf);
+      if (lo < 0) lo = 0;
+      if (hi > g->F_out - 1) hi = g->F_out - 1;
+      if (hi < lo) { hi = lo; }
+      fo0[b] = lo; nfo[b] = hi - lo + 1;
+      tiles += (((fi1 - fi0 + 1) * a->C_in + 255) / 256) * ((nfo[b] * a->C_out + 255) / 256);
+    }
+    if (nb > 1 && tiles < ((g->Ki + 255) / 256) * ((g->Ko + 255) / 256)) {
+      g->nwblk = nb;
+      for (int b = 0; b < nb; ++b) {
+        g->w_fi0[b] = b * fpb;
+        g->w_nfi[b] = (b * fpb + fpb < a->F_in ? fpb : a->F_in - b * fpb);
+        g->w_fo0[b] = fo0[b]; g->w_nfo[b] = nfo[b];
+      }
+    }
+  }
   return true;
 }
+
+// Block b as a convolution geometry of its own for the band kernels: F_in' = nfi, F_out' = nfo and
+// the frequency padding that makes band'[fi'][fo'] = W[fi' - sf fo' + pf'] the block of the full
+// band (pf' = pf + fi0 - sf fo0).  Time / phase fields and n_pad are the layer's.
+Geo rect_geo(const Geo& g, int fi0, int nfi, int fo0, int nfo) {
+  Geo q = g;
+  q.F_in = nfi; q.F_out = nfo;
+  q.pf = g.pf + fi0 - g.sf * fo0;
+  q.Ki = q.F_in * g.C_in; q.Ko = q.F_out * g.C_out;
+  q.Ki_p = (q.Ki + 31) / 32 * 32; q.Ko_p = (q.Ko + 31) / 32 * 32;
+  return q;
+}
+Geo block_geo(const Geo& g, int b) { return rect_geo(g, g.b_fi0[b], g.b_nfi[b], g.b_fo0[b], g.b_nfo[b]); }
+Geo wblock_geo(const Geo& g, int b) { return rect_geo(g, g.w_fi0[b], g.w_nfi[b], g.w_fo0[b], g.w_nfo[b]); }
 
 // plane row of tap dt's first operand row (output frame 0, sample 0) in the phase layout
 inline long long tap_row(const Geo& g, int dt) {
@@ -101,7 +176,13 @@ Ws make_ws(const Geo& g) {
   w.banddg_pl = take((size_t)g.Ki * g.kt * g.Ko_p * 4);
   w.bias_band = take((size_t)g.Ko * 4);
   w.dband = take((size_t)g.kt * g.Ki * g.Ko * 4);
-  w.gemm_bytes = asr_align_up((size_t)wgrad_splits(g) * g.kt * g.Ki * g.Ko * sizeof(float), 256);
+  w.gemm_bytes = 0;                       // split-K partials of the largest block's launch
+  for (int b = 0; b < g.nwblk; ++b) {
+    const Geo gb = wblock_geo(g, b);
+    const size_t need = (size_t)wgrad_splits(gb) * g.kt * gb.Ki * gb.Ko * sizeof(float);
+    if (need > w.gemm_bytes) w.gemm_bytes = need;
+  }
+  w.gemm_bytes = asr_align_up(w.gemm_bytes, 256);
   w.gemm = take(w.gemm_bytes);
   w.colsum_bytes = asr_colsum_workspace_bytes((int)g.M, g.Ko);
   w.colsum = take(w.colsum_bytes);
@@ -235,9 +316,12 @@ conv_act_kernel(const float* __restrict__ z, float* __restrict__ y, size_t n4, f
 
 // dW[dt][df][ci][co] = sum_fo dband[dt][(sf fo + df - pf, ci)][(fo, co)] (float64 accumulation,
 // fixed order); db[co] = sum_fo colsum[(fo, co)].  One thread per filter element.
+// (g: the geometry of ONE frequency block -- block_geo; accumulate: add to dW (blocks 1..);
+// db / colsum cover all n_fo_total output frequencies and are folded by the first call)
 __global__ void __launch_bounds__(256)
 conv_band_reduce_kernel(Geo g, const float* __restrict__ dband, const float* __restrict__ colsum,
-                        float* __restrict__ dW, float* __restrict__ db) {
+                        float* __restrict__ dW, float* __restrict__ db, int accumulate,
+                        int n_fo_total) {
   const size_t total = (size_t)g.kt * g.kf * g.C_in * g.C_out;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < total) {
@@ -252,11 +336,11 @@ conv_band_reduce_kernel(Geo g, const float* __restrict__ dband, const float* __r
       acc += (double)dband[((size_t)dt * g.Ki + (size_t)fi * g.C_in + ci) * g.Ko +
                            (size_t)fo * g.C_out + co];
     }
-    dW[idx] = (float)acc;
+    dW[idx] = (accumulate ? dW[idx] : 0.f) + (float)acc;
   }
   if (db && idx < (size_t)g.C_out) {
     double acc = 0.0;
-    for (int fo = 0; fo < g.F_out; ++fo) acc += (double)colsum[(size_t)fo * g.C_out + idx];
+    for (int fo = 0; fo < n_fo_total; ++fo) acc += (double)colsum[(size_t)fo * g.C_out + idx];
     db[idx] = (float)acc;
   }
 }
@@ -356,20 +440,27 @@ extern "C" int asr_conv2d_fwd(const asr_conv2d_args* a, void* workspace, size_t 
   if (!ws_ok(w, workspace, ws_bytes)) return ASR_ERR_WORKSPACE;
   char* ws = reinterpret_cast<char*>(workspace);
   float* scal = reinterpret_cast<float*>(ws + w.scal);
-  int rc = build_band(g, a, w, ws, true, false, stream);
-  if (rc) return rc;
+  int rc;
   if (!a->reuse_x) { rc = pack_x(g, a, w, ws, stream); if (rc) return rc; }
-  asr_gemm_hl_args h = {};
-  h.M = (int)g.M; h.N = g.Ko; h.K = g.kt * g.Ki_p;
-  h.a_hl = ws + w.xpl; h.lda = g.Ki_p;
-  h.b_hl = ws + w.bandf_pl; h.ldb = g.kt * g.Ki_p;
-  h.a_scale = scal + 8; h.b_scale = scal + 10;
-  h.C = a->z; h.ldc = g.Ko; h.alpha = 1.f; h.beta = 0.f;
-  h.bias = reinterpret_cast<float*>(ws + w.bias_band);
-  h.a_seg_k = g.Ki_p;
-  for (int dt = 0; dt < g.kt; ++dt) h.a_seg_row[dt] = tap_row(g, dt);
-  rc = asr_gemm_hl(&h, nullptr, 0, stream);
-  if (rc) return rc;
+  for (int b = 0; b < g.nblk; ++b) {
+    // block b: output columns [fo0 C_out, +Ko_b) of z from input columns [fi0 C_in, +Ki_b) of the
+    // x planes (the whole band when nblk == 1; then Ki_b may be padded up to Ki_p: zero columns)
+    const Geo gb = block_geo(g, b);
+    rc = build_band(gb, a, w, ws, true, false, stream);
+    if (rc) return rc;
+    const int kseg = g.nblk == 1 ? g.Ki_p : gb.Ki;
+    asr_gemm_hl_args h = {};
+    h.M = (int)g.M; h.N = gb.Ko; h.K = g.kt * kseg;
+    h.a_hl = ws + w.xpl + (size_t)(g.b_fi0[b] * g.C_in / 16) * 64; h.lda = g.Ki_p;
+    h.b_hl = ws + w.bandf_pl; h.ldb = g.kt * gb.Ki_p;
+    h.a_scale = scal + 8; h.b_scale = scal + 10;
+    h.C = a->z + (size_t)g.b_fo0[b] * g.C_out; h.ldc = g.Ko; h.alpha = 1.f; h.beta = 0.f;
+    h.bias = reinterpret_cast<float*>(ws + w.bias_band);
+    h.a_seg_k = kseg;
+    for (int dt = 0; dt < g.kt; ++dt) h.a_seg_row[dt] = tap_row(g, dt);
+    rc = asr_gemm_hl(&h, nullptr, 0, stream);
+    if (rc) return rc;
+  }
   if (a->clip > 0.f) {
     const size_t n4 = (size_t)g.M * g.Ko / 4;
     hipLaunchKernelGGL(conv_act_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, a->z, a->y, n4,
@@ -394,21 +485,31 @@ extern "C" int asr_conv2d_dgrad(const asr_conv2d_args* a, void* workspace, size_
   if (!ws_ok(w, workspace, ws_bytes)) return ASR_ERR_WORKSPACE;
   char* ws = reinterpret_cast<char*>(workspace);
   float* scal = reinterpret_cast<float*>(ws + w.scal);
-  int rc = build_band(g, a, w, ws, false, true, stream);
-  if (rc) return rc;
+  int rc;
   if (!a->reuse_dz) { rc = pack_dz(g, a, w, ws, stream); if (rc) return rc; }
   // dx[(t, n)] = sum_dt dz[(t - dt + pt, n)] band[dt]^T: tap dt reads the dz planes
-  // (kt - 1 - dt) frames below their first (zero-padded) frame
-  asr_gemm_hl_args h = {};
-  h.M = (int)g.M; h.N = g.Ki; h.K = g.kt * g.Ko_p;
-  h.a_hl = ws + w.dzpl; h.lda = g.Ko_p;
-  h.b_hl = ws + w.banddg_pl; h.ldb = g.kt * g.Ko_p;
-  h.a_scale = scal + 9; h.b_scale = scal + 11;
-  h.C = a->dx; h.ldc = g.Ki; h.alpha = 1.f; h.beta = 0.f;
-  h.a_seg_k = g.Ko_p;
-  for (int dt = 0; dt < g.kt; ++dt)
-    h.a_seg_row[dt] = (long long)(g.padb - (g.kt - 1 - g.pt) + (g.kt - 1 - dt)) * g.n_pad;
-  return asr_gemm_hl(&h, nullptr, 0, stream);
+  // (kt - 1 - dt) frames below their first (zero-padded) frame.  With frequency blocks the
+  // blocks' input ranges overlap: dx is cleared and every block adds its share.
+  if (g.nblk > 1) ASR_CHECK_HIP(hipMemsetAsync(a->dx, 0, (size_t)g.M * g.Ki * 4, stream));
+  for (int b = 0; b < g.nblk; ++b) {
+    const Geo gb = block_geo(g, b);
+    rc = build_band(gb, a, w, ws, false, true, stream);
+    if (rc) return rc;
+    const int kseg = g.nblk == 1 ? g.Ko_p : gb.Ko;
+    asr_gemm_hl_args h = {};
+    h.M = (int)g.M; h.N = gb.Ki; h.K = g.kt * kseg;
+    h.a_hl = ws + w.dzpl + (size_t)(g.b_fo0[b] * g.C_out / 16) * 64; h.lda = g.Ko_p;
+    h.b_hl = ws + w.banddg_pl; h.ldb = g.kt * gb.Ko_p;
+    h.a_scale = scal + 9; h.b_scale = scal + 11;
+    h.C = a->dx + (size_t)g.b_fi0[b] * g.C_in; h.ldc = g.Ki; h.alpha = 1.f;
+    h.beta = g.nblk > 1 ? 1.f : 0.f;
+    h.a_seg_k = kseg;
+    for (int dt = 0; dt < g.kt; ++dt)
+      h.a_seg_row[dt] = (long long)(g.padb - (g.kt - 1 - g.pt) + (g.kt - 1 - dt)) * g.n_pad;
+    rc = asr_gemm_hl(&h, nullptr, 0, stream);
+    if (rc) return rc;
+  }
+  return ASR_OK;
 }
 
 extern "C" int asr_conv2d_wgrad(const asr_conv2d_args* a, void* workspace, size_t ws_bytes,
@@ -425,22 +526,6 @@ extern "C" int asr_conv2d_wgrad(const asr_conv2d_args* a, void* workspace, size_
   if (!a->reuse_x) { rc = pack_x(g, a, w, ws, stream); if (rc) return rc; }
   if (!a->reuse_dz) { rc = pack_dz(g, a, w, ws, stream); if (rc) return rc; }
   float* dband = reinterpret_cast<float*>(ws + w.dband);
-  // d band[dt] (Ki x Ko) = X_dt^T dZ: both operands reduce over their plane ROWS (k_major); the
-  // kt taps share dZ and differ in the row shift of the x planes only: ONE batched launch
-  {
-    asr_gemm_hl_args h = {};
-    h.M = g.Ki; h.N = g.Ko; h.K = (int)g.M;
-    h.a_hl = ws + w.xpl; h.lda = g.Ki_p;
-    h.b_hl = ws + w.dzpl + (size_t)g.padb * g.n_pad * g.Ko_p * 4; h.ldb = g.Ko_p;
-    h.a_scale = scal + 8; h.b_scale = scal + 9;
-    h.C = dband; h.ldc = g.Ko; h.alpha = 1.f; h.beta = 0.f;
-    h.split_k = wgrad_splits(g);
-    h.k_major = 1;
-    h.batch = g.kt;
-    for (int dt = 0; dt < g.kt; ++dt) h.a_batch_row[dt] = tap_row(g, dt);
-    rc = asr_gemm_hl(&h, ws + w.gemm, w.gemm_bytes, stream);
-    if (rc) return rc;
-  }
   float* cs = nullptr;
   if (a->db) {
     // column sums of dz (fp32 copy written by the pack), folded over fo by the reduce kernel
@@ -450,8 +535,31 @@ extern "C" int asr_conv2d_wgrad(const asr_conv2d_args* a, void* workspace, size_
     if (rc) return rc;
   }
   const size_t items = (size_t)g.kt * g.kf * g.C_in * g.C_out;
-  hipLaunchKernelGGL(conv_band_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
-                     stream, g, dband, cs, a->dW, a->db);
-  ASR_CHECK_LAUNCH();
+  for (int b = 0; b < g.nwblk; ++b) {
+    // d band_b[dt] (Ki_b x Ko_b) = X_dt[:, block's input columns]^T dZ[:, block's output columns]:
+    // both operands reduce over their plane ROWS (k_major); the kt taps share dZ and differ in
+    // the row shift of the x planes only: ONE batched launch per block
+    const Geo gb = wblock_geo(g, b);
+    asr_gemm_hl_args h = {};
+    h.M = gb.Ki; h.N = gb.Ko; h.K = (int)g.M;
+    h.a_hl = ws + w.xpl + (size_t)(g.w_fi0[b] * g.C_in / 16) * 64; h.lda = g.Ki_p;
+    h.b_hl = ws + w.dzpl + (size_t)g.padb * g.n_pad * g.Ko_p * 4 +
+             (size_t)(g.w_fo0[b] * g.C_out / 16) * 64;
+    h.ldb = g.Ko_p;
+    h.a_scale = scal + 8; h.b_scale = scal + 9;
+    h.C = dband; h.ldc = gb.Ko; h.alpha = 1.f; h.beta = 0.f;
+    h.split_k = wgrad_splits(gb);
+    h.k_major = 1;
+    h.batch = g.kt;
+    for (int dt = 0; dt < g.kt; ++dt) h.a_batch_row[dt] = tap_row(g, dt);
+    rc = asr_gemm_hl(&h, ws + w.gemm, w.gemm_bytes, stream);
+    if (rc) return rc;
+    // fold the band gradient back onto the filter taps (block 0 writes, the others add; the
+    // bias gradient -- column sums over ALL output frequencies -- with block 0)
+    hipLaunchKernelGGL(conv_band_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
+                       stream, gb, dband, cs, a->dW, b == 0 ? a->db : (float*)nullptr, b > 0 ? 1 : 0,
+                       g.F_out);
+    ASR_CHECK_LAUNCH();
+  }
   return ASR_OK;
 }

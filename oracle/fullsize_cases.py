@@ -40,6 +40,12 @@ CASES = {
     # float64 oracle on four 16-utterance slices and adds their gradients (each scaled 1/64)
     'cfg3': dict(F=80, H=512, L=5, C=28, N=64, feat=('logfbank', {'num_filt': 80}),
                  ragged=False, masks=False, slices=4),
+    # BASELINE.json configs[2] AS WRITTEN: the same stack behind its 2-conv front-end
+    # (models.deep_speech2: 32 x (11 x 41) / (2, 2), 32 x (11 x 21) / (1, 2), clipped ReLU 20; no
+    # reference counterpart, README.md:118), a 16-utterance slice; the stack sees T' = 500 frames
+    'cfg3_conv_n16': dict(F=80, H=512, L=5, C=28, N=16, feat=('logfbank', {'num_filt': 80}),
+                          ragged=False, masks=False,
+                          conv=[(32, 11, 41, 2, 2, 20.0), (32, 11, 21, 1, 2, 20.0)]),
 }
 LOGIT_FRAMES = 50          # frames (spread over T) whose logits a fixture keeps
 GRAD_SAMPLES = 1000        # sampled entries per gradient tensor
@@ -86,7 +92,7 @@ def build(name):
     lab_len = rs.randint(2, 50, size=N)
     labels = [rs.randint(0, 25, size=lab_len[n]).tolist() for n in range(N)]
     params = OL.init_model(seed=0, num_features=F, num_hiddens=H, num_layers=L,
-                           num_classes=C, dtype=np.float32)
+                           num_classes=C, dtype=np.float32, conv=cfg.get('conv'))
     masks = None
     if cfg['masks']:
         rm = np.random.RandomState(4242)
@@ -100,6 +106,14 @@ def build(name):
             masks.append(m)
             n_in = 2 * H
     return dict(x=x, lens=lens, labels=labels, params=params, masks=masks, cfg=cfg, T=T)
+
+
+def out_frames(cfg, T):
+    """Frames (or lengths) on the logits' time axis: ceil(T / st) per conv layer."""
+    T = np.asarray(T)
+    for c in cfg.get('conv') or []:
+        T = -(-T // c[3])
+    return T
 
 
 def feature_probe(x):

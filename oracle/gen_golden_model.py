@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Generate tests/golden/model_<case>.npz: the float64 oracle run ONCE at the benchmarked
-sizes (T = 999; cfg2 = 5 x BiLSTM(256), N = 32; cfg3 slice = 5 x BiLSTM(512), N = 16), kept
+sizes (T = 999; cfg2 = 5 x BiLSTM(256), N = 32; cfg3 slice = 5 x BiLSTM(512), N = 16; the
+same slice behind the 2-conv front-end of configs[2], T' = 500), kept
 as compact fixtures so that the -m gpu suite can compare the HIP path element-wise at full
 size without minutes of NumPy on the GPU box (tests/test_gpu_fullsize_parity.py).
 
@@ -38,7 +39,8 @@ from oracle import lstm as OL            # noqa: E402
 
 def to64(tree):
     if isinstance(tree, dict):
-        return {k: to64(v) for k, v in tree.items()}
+        # (a conv layer's 'stride' / 'clip' are settings, not arrays)
+        return {k: (v if k in ('stride', 'clip') else to64(v)) for k, v in tree.items()}
     if isinstance(tree, (list, tuple)):
         return type(tree)(to64(v) for v in tree)
     return np.asarray(tree, np.float64)
@@ -84,6 +86,8 @@ def run(name):
         out['logits'] = np.concatenate(out['logits'], axis=1)
     logits = out['logits']
     fix = {}
+    lens_out = FC.out_frames(cfg, case['lens'])     # (a conv front-end shortens the time axis)
+    T = int(logits.shape[0])
     fr = FC.logit_frames(T)
     fix['logit_frames'] = fr
     fix['logits'] = logits[fr].astype(np.float32)
@@ -91,7 +95,7 @@ def run(name):
     srt = np.sort(logits, axis=-1)
     fix['argmax'] = np.argmax(logits, axis=-1).astype(np.uint8)
     fix['margin'] = (srt[..., -1] - srt[..., -2]).astype(np.float32)
-    hyp = OD.greedy_decode(logits, case['lens'])
+    hyp = OD.greedy_decode(logits, lens_out)
     hl = max([len(h) for h in hyp] + [1])
     dec = np.full((N, hl), -1, np.int16)
     for n, h in enumerate(hyp):

@@ -110,3 +110,116 @@ def wgrad(g, xp, dy, z, clip):
                                         fo * g.C_out:(fo + 1) * g.C_out]
     db = dz.reshape(g.M, g.F_out, g.C_out).sum(axis=(0, 1))
     return dW, db
+
+
+# ---- frequency blocks (make_geo's nblk / nwblk rules, rect_geo) -------------------------------
+
+def col_blocks(g):
+    """Column blocks of the forward / dgrad GEMMs: [(fi0, nfi, fo0, nfo)]."""
+    nblk = 1
+    for nb in (4, 3, 2):
+        if g.F_out % nb or g.C_in % 32:
+            continue
+        nfo = g.F_out // nb
+        if (nfo * g.C_out) % 32 or nfo * g.C_out < 256:
+            continue
+        if g.sf * (nfo - 1) + g.kf >= g.F_in:
+            continue
+        nblk = nb
+        break
+    if nblk == 1:
+        return [(0, g.F_in, 0, g.F_out)]
+    out = []
+    nfo = g.F_out // nblk
+    for b in range(nblk):
+        fo0 = b * nfo
+        lo = max(g.sf * fo0 - g.pf, 0)
+        hi = min(g.sf * (fo0 + nfo - 1) - g.pf + g.kf, g.F_in)
+        out.append((lo, hi - lo, fo0, nfo))
+    return out
+
+
+def row_blocks(g):
+    """Row blocks of the weight-gradient GEMMs (tile-aligned input-frequency ranges)."""
+    whole = [(0, g.F_in, 0, g.F_out)]
+    if g.C_in % 32 or g.C_out % 32 or 256 % g.C_in:
+        return whole
+    fpb = 256 // g.C_in
+    while -(-g.F_in // fpb) > 8:
+        fpb *= 2
+    nb = -(-g.F_in // fpb)
+    out, tiles = [], 0
+    for b in range(nb):
+        fi0 = b * fpb
+        fi1 = min(fi0 + fpb, g.F_in) - 1
+        lo = max(-((-(fi0 + g.pf - (g.kf - 1))) // g.sf), 0)
+        hi = min((fi1 + g.pf) // g.sf, g.F_out - 1)
+        hi = max(hi, lo)
+        out.append((fi0, fi1 - fi0 + 1, lo, hi - lo + 1))
+        tiles += -(-((fi1 - fi0 + 1) * g.C_in) // 256) * -(-((hi - lo + 1) * g.C_out) // 256)
+    if nb > 1 and tiles < -(-g.Ki // 256) * -(-g.Ko // 256):
+        return out
+    return whole
+
+
+def rect_geo(g, fi0, nfi, fo0, nfo):
+    import copy
+    q = copy.copy(g)
+    q.F_in, q.F_out = nfi, nfo
+    q.pf = g.pf + fi0 - g.sf * fo0
+    q.Ki, q.Ko = nfi * g.C_in, nfo * g.C_out
+    q.Ki_p, q.Ko_p = -(-q.Ki // 32) * 32, -(-q.Ko // 32) * 32
+    return q
+
+
+def forward_blocks(g, x, W, b, clip):
+    """asr_conv2d_fwd with column blocks: block GEMMs on column ranges of the same x planes."""
+    xp = pack_x(g, x)
+    z = np.full((g.M, g.Ko), np.nan)
+    blocks = col_blocks(g)
+    for fi0, nfi, fo0, nfo in blocks:
+        gb = rect_geo(g, fi0, nfi, fo0, nfo)
+        bf, _ = band(gb, W)
+        kseg = g.Ki_p if len(blocks) == 1 else gb.Ki
+        A = xp[:, fi0 * g.C_in:]
+        zb = seg_gemm(A, kseg, [g.tap_row(dt) for dt in range(g.kt)],
+                      np.concatenate([bf[dt * gb.Ki_p:dt * gb.Ki_p + kseg] for dt in range(g.kt)]).T
+                      if kseg != gb.Ki_p else bf.T, g.M)
+        z[:, fo0 * g.C_out:fo0 * g.C_out + gb.Ko] = zb + np.tile(b, nfo)[None]
+    z = z.reshape(g.T_out, g.n_pad, g.Ko)
+    return (np.clip(z, 0, clip) if clip > 0 else z), z, xp
+
+
+def dgrad_blocks(g, dy, z, W, clip):
+    assert g.st == 1
+    dzp, _ = pack_dz(g, dy, z, clip)
+    rows = [(g.padb - (g.kt - 1 - g.pt) + (g.kt - 1 - dt)) * g.n_pad for dt in range(g.kt)]
+    dx = np.zeros((g.M, g.Ki))
+    blocks = col_blocks(g)
+    for fi0, nfi, fo0, nfo in blocks:
+        gb = rect_geo(g, fi0, nfi, fo0, nfo)
+        _, bd = band(gb, W)
+        kseg = g.Ko_p if len(blocks) == 1 else gb.Ko
+        B = np.concatenate([bd[:, dt * gb.Ko_p:dt * gb.Ko_p + kseg] for dt in range(g.kt)], axis=1)
+        dx[:, fi0 * g.C_in:fi0 * g.C_in + gb.Ki] += seg_gemm(dzp[:, fo0 * g.C_out:], kseg, rows, B, g.M)
+    return dx.reshape(g.T_in, g.n_pad, g.Ki)
+
+
+def wgrad_blocks(g, xp, dy, z, clip):
+    dzp, dz = pack_dz(g, dy, z, clip)
+    dzr = dzp[g.padb * g.n_pad:g.padb * g.n_pad + g.M]
+    dW = np.zeros((g.kt, g.kf, g.C_in, g.C_out))
+    for fi0, nfi, fo0, nfo in row_blocks(g):
+        gb = rect_geo(g, fi0, nfi, fo0, nfo)
+        for dt in range(g.kt):
+            r = g.tap_row(dt)
+            dband = xp[r:r + g.M, fi0 * g.C_in:fi0 * g.C_in + gb.Ki].T @ \
+                dzr[:, fo0 * g.C_out:fo0 * g.C_out + gb.Ko]
+            for df in range(g.kf):                  # conv_band_reduce_kernel on the block geometry
+                for fo in range(gb.F_out):
+                    fi = gb.sf * fo + df - gb.pf
+                    if 0 <= fi < gb.F_in:
+                        dW[dt, df] += dband[fi * g.C_in:(fi + 1) * g.C_in,
+                                            fo * g.C_out:(fo + 1) * g.C_out]
+    db = dz.reshape(g.M, g.F_out, g.C_out).sum(axis=(0, 1))
+    return dW, db

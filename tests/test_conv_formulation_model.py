@@ -34,3 +34,31 @@ def test_gemm_formulation_equals_the_convolution(T, F, Ci, Co, kt, kf, st, sf):
     np.testing.assert_allclose(gb, db, atol=1e-11)
     if st == 1:
         np.testing.assert_allclose(CM.dgrad(g, dy, z, W, clip), dx, atol=1e-11)
+
+
+@pytest.mark.parametrize('T,F,Ci,Co,kt,kf,st,sf,ncol,nrow', [
+    (7, 24, 32, 48, 3, 9, 1, 2, 2, 1),       # two column blocks (C_out % 32 != 0: no row blocks)
+    (6, 32, 32, 32, 3, 5, 2, 1, 4, 4),       # four column blocks, four row blocks
+    (5, 40, 32, 32, 3, 21, 1, 2, 2, 5),      # the second front-end layer's frequency geometry
+    (9, 8, 4, 4, 5, 5, 1, 2, 1, 1),          # nothing to cut: one block = the whole band
+])
+def test_frequency_blocks_cover_the_band(T, F, Ci, Co, kt, kf, st, sf, ncol, nrow):
+    """make_geo's column blocks (forward, dgrad) and row blocks (weight gradient): GEMMs on column
+    ranges of the same planes against block bands add up to the whole convolution."""
+    rs = np.random.RandomState(T + 10 * F)
+    n_pad, clip = 16, 1.0
+    x = rs.randn(T, n_pad, F * Ci)
+    W = rs.randn(kt, kf, Ci, Co) * 0.1
+    b = rs.randn(Co) * 0.1
+    g = CM.Geo(T, n_pad, F, Ci, Co, kt, kf, st, sf)
+    assert (len(CM.col_blocks(g)), len(CM.row_blocks(g))) == (ncol, nrow)
+    y, z, xp = CM.forward_blocks(g, x, W, b, clip)
+    want, cache = OC.conv2d_forward(x, W, b, (st, sf), clip)
+    np.testing.assert_allclose(y, want, atol=1e-11)
+    dy = rs.randn(*y.shape)
+    dx, dW, db = OC.conv2d_backward(dy, cache)
+    gW, gb = CM.wgrad_blocks(g, xp, dy, z, clip)
+    np.testing.assert_allclose(gW, dW, atol=1e-10)
+    np.testing.assert_allclose(gb, db, atol=1e-10)
+    if st == 1:
+        np.testing.assert_allclose(CM.dgrad_blocks(g, dy, z, W, clip), dx, atol=1e-10)

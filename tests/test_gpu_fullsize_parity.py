@@ -72,8 +72,16 @@ def _check(name):
     assert np.abs(probe - fix['feat_probe']).max() < 1e-5
     assert np.array_equal(case['lens'], fix['lens'])
     dev = torch.device('cuda:0')
-    model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
-                          dropout=0.0, weight_decay=0.0, seed=1, device=dev)
+    if cfg.get('conv'):         # configs[2] as written: the stack behind its 2-conv front-end
+        model = models.deep_speech2(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
+                                    conv_filters=cfg['conv'][0][0],
+                                    conv_kernels=[c[1:3] for c in cfg['conv']],
+                                    conv_strides=[c[3:5] for c in cfg['conv']],
+                                    max_value=cfg['conv'][0][5], dropout=0.0, weight_decay=0.0,
+                                    seed=1, device=dev)
+    else:
+        model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
+                              dropout=0.0, weight_decay=0.0, seed=1, device=dev)
     model.set_weights([a for _, a in OL.flatten(case['params'])])
     n_pad = ops.pad16(N)
     slab = torch.zeros((T, n_pad, F), dtype=torch.float32, device=dev)
@@ -84,6 +92,8 @@ def _check(name):
     for ws in ('lstm_fwd', 'lstm_bwd'):
         ops.lstm_status(ops.WS.get(ws, 0, dev))
     lg = logits[:, :N].cpu().numpy()
+    T = lg.shape[0]                                    # the logits' time axis (T' behind a conv)
+    lens_out = FC.out_frames(cfg, case['lens'])
     fr = fix['logit_frames']
     assert report(name + ' logits@50 frames', lg[fr], fix['logits']) < 1e-4
     # hidden / cell states of the first and last BiLSTM layer
@@ -113,16 +123,16 @@ def _check(name):
           % (name, worst, len(names)))
     # decoder decisions
     am = np.argmax(lg, axis=-1)
-    valid = np.arange(T)[:, None] < np.asarray(case['lens'])[None, :]
+    valid = np.arange(T)[:, None] < np.asarray(lens_out)[None, :]
     decided = (fix['margin'] > 2e-4) & valid
     assert np.array_equal(am[decided], fix['argmax'][decided])
     flips = int(np.sum((am != fix['argmax']) & valid))
     print('[parity] %-28s argmax exact on %d decided frames; %d of %d close calls flipped'
           % (name, int(decided.sum()), flips, int((valid & ~decided).sum())))
-    hyp = ctc_utils.decode((logits, case['lens']), is_greedy=True)
+    hyp = ctc_utils.decode((logits, lens_out), is_greedy=True)
     for n in range(N):
         seq, prev = [], -1
-        for t in range(int(case['lens'][n])):
+        for t in range(int(lens_out[n])):
             k = int(am[t, n])
             if k != prev and k != C - 1:
                 seq.append(k)

@@ -22,13 +22,31 @@ def test_fixture_matches_its_recipe(name):
     idx, probe = FC.feature_probe(case['x'])
     assert np.abs(probe - fix['feat_probe']).max() < 1e-5
     assert np.array_equal(case['lens'], fix['lens'])
+    nu = FC.STATE_UTTS
+    x = case['x'][:, :nu].astype(np.float64)
+    conv = case['params'].get('conv')
+    if conv:
+        # the stack's input is the conv front-end's output: recompute its first and last frames
+        # from crops of the features that keep the 'same' padding and the stride phase of the
+        # whole slab (T odd: a crop [918, 999) of odd length starts on an even frame)
+        from oracle import conv as OCV
+
+        def front(a):
+            for cp in conv:
+                a, _ = OCV.conv2d_forward(a, cp['W'].astype(np.float64), cp['b'].astype(np.float64),
+                                          cp['stride'], cp['clip'])
+            return a
+        assert T % 2 == 1
+        head, tail = front(x[:81]), front(x[918:])
+        T = int(FC.out_frames(cfg, T))
+        xs_full = np.zeros((T, nu, head.shape[2]))
+        xs_full[:2], xs_full[-2:] = head[:2], tail[-2:]
+        x = xs_full
     assert fix['logits'].shape == (len(FC.logit_frames(T)), N, C)
     assert fix['ctc'].shape == (N,) and np.all(fix['ctc'] > 0)
     assert fix['argmax'].shape == (T, N) and fix['margin'].shape == (T, N)
-    assert len(fix['grad_names']) == 6 * L + 2
+    assert len(fix['grad_names']) == 6 * L + 2 + 2 * len(conv or [])
     # layer 1, forward direction, steps t = 0 and 1; backward direction, t = T-1 and T-2
-    nu = FC.STATE_UTTS
-    x = case['x'][:, :nu].astype(np.float64)
     for d, rev, frames, rows in (('fwd', False, [0, 1], [0, 1]), ('bwd', True, [T - 1, T - 2], [4, 3])):
         p = {k: np.asarray(v, np.float64) for k, v in case['params']['layers'][0][d].items()}
         BW = BU = None
