@@ -138,13 +138,15 @@ class Model(object):
         self._overlap_mode = _os.environ.get('ASR_OVERLAP', 'auto')
         self.overlap = self._overlap_mode != '0'
         self._side = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
-        # the GEMMs either side of a recurrence are pipelined against its last quarter
+        # the GEMMs either side of a recurrence are pipelined against its last steps
         # (frames whose both directions are already final), on a third stream
         # 'auto': only when a layer's recurrence leaves at least half of the CUs to the GEMMs
         # it is pipelined against (cfg2: 64 of 256 workgroups; not cfg3's 256 of 256)
         self._pipeline_mode = _os.environ.get('ASR_PIPELINE', 'auto')
         # the recurrence is cut after split/16 of its steps (frames [T-S, S) are final then)
-        self._pipe_split16 = min(15, max(9, int(_os.environ.get('ASR_PIPE_SPLIT', '12'))))
+        self._pipe_split16 = min(15, max(9, int(_os.environ.get('ASR_PIPE_SPLIT', '13'))))
+        # (ASR_PIPE_HALVES=0: the pipelined GEMMs wait for whole frames -- comparison switch)
+        self._pipe_halves = _os.environ.get('ASR_PIPE_HALVES', '1') != '0'
         self.pipeline = self.overlap and self._pipeline_mode == '1'
         self._pipe = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         # big GEMMs on operands packed once into split-fp16 planes (ops.pack_hl / gemm_hl);
@@ -623,6 +625,13 @@ class Model(object):
                     self._gate_gemm_hl(s, si, rec['pa'], zx, rows)
                 elif inner_done is None:
                     self._gate_gemm(a, s, zx, BW, 0, rows, n_pad)
+                elif self._pipe_halves:
+                    # frames [T-S, S) were projected while the previous layer ran, and of the
+                    # others the half of the reduction that was final by then (below): what is
+                    # left on the critical path is the other half of those frames
+                    main.wait_event(inner_done)
+                    self._gate_gemm_half(a, s, zx, BW, 0, (T - S) * n_pad, n_pad, 1, False)
+                    self._gate_gemm_half(a, s, zx, BW, S * n_pad, rows, n_pad, 0, False)
                 else:       # frames [T-S, S) were projected while the previous layer ran
                     self._gate_gemm(a, s, zx, BW, 0, (T - S) * n_pad, n_pad)
                     self._gate_gemm(a, s, zx, BW, S * n_pad, rows, n_pad)
@@ -642,9 +651,9 @@ class Model(object):
                                         zone_c=var.get('zone_c'), zone_h=var.get('zone_h'))
                 elif pipe and nxt is not None and nxt.kind == 'bilstm' and not var \
                         and nxt.mi is None and nxt.ln is None:
-                    # after S = 3T/4 steps the frames [T-S, S) of y are final in BOTH
+                    # after S = 13T/16 steps the frames [T-S, S) of y are final in BOTH
                     # directions: the next layer's input projection of those frames runs
-                    # on the pipe stream while this recurrence finishes its last quarter
+                    # on the pipe stream while this recurrence finishes its last steps
                     ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
                                      mode=self.lstm_mode, steps=(0, S))
                     ev = torch.cuda.Event()
@@ -652,8 +661,16 @@ class Model(object):
                     zx_n = self._buf('zx%d_%d' % (nb % 2, nxt.Hp), (T, n_pad, 2, 4 * nxt.Hp))
                     with torch.cuda.stream(self._pipe):
                         self._pipe.wait_event(ev)
-                        self._gate_gemm(y, nxt, zx_n, stage_masks(si + 1)[0], (T - S) * n_pad,
-                                        S * n_pad, n_pad)
+                        BWn = stage_masks(si + 1)[0]
+                        self._gate_gemm(y, nxt, zx_n, BWn, (T - S) * n_pad, S * n_pad, n_pad)
+                        if self._pipe_halves:
+                            # x = [y_f, y_b]: after S steps y_f is final on the frames [0, T-S)
+                            # too and y_b on [S, T) -- their halves of the reduction
+                            # (+ bias) go ahead as well
+                            self._gate_gemm_half(y, nxt, zx_n, BWn, 0, (T - S) * n_pad, n_pad,
+                                                 0, True)
+                            self._gate_gemm_half(y, nxt, zx_n, BWn, S * n_pad, rows, n_pad,
+                                                 1, True)
                         done = torch.cuda.Event()
                         done.record(self._pipe)
                     pre[si + 1] = done
@@ -759,6 +776,34 @@ class Model(object):
                           8 * Hp, 8 * Hp, x=a, x_off=r0 * s.f_in_pad,
                           bias=None if bias is None else bias[d * 4 * Hp:(d + 1) * 4 * Hp],
                           mask_w=BW[d], zx=zx, z_off=r0 * 8 * Hp + d * 4 * Hp)
+
+    def _gate_gemm_half(self, a, s, zx, BW, r0, r1, n_pad, half, first):
+        """One half of the reduction of the projection over slab rows [r0, r1): the input is
+        [y_f, y_b] of the BiLSTM stage below, half 0 = its forward direction's columns, 1 = the
+        backward direction's.  first: zx = partial + b, else zx += partial."""
+        m, Hp, kh = r1 - r0, s.Hp, s.f_in_pad // 2
+        if m <= 0:
+            return
+        bias = self._view(s.ob, 8 * Hp) if first else None
+        for d in (range(2) if BW is not None else (None,)):
+            n, c0 = (8 * Hp, 0) if d is None else (4 * Hp, d * 4 * Hp)
+            ops.gemm(a, self.params, zx, m, n, kh, lda=s.f_in_pad, ldb=8 * Hp, ldc=8 * Hp,
+                     a_off=r0 * s.f_in_pad + half * kh, b_off=s.oW + half * kh * 8 * Hp + c0,
+                     c_off=r0 * 8 * Hp + c0, beta=0.0 if first else 1.0,
+                     bias=None if bias is None else bias[c0:c0 + n],
+                     a_scale=None if d is None else BW[d], a_scale_period=n_pad,
+                     a_scale_off=half * kh, a_scale_ld=s.f_in_pad)
+
+    def _dx_gemm_dir(self, dz, s, dx, BW, r0, r1, n_pad, zmx, d, beta):
+        """Direction d's term of _dx_gemm over slab rows [r0, r1): dx = beta dx + B_W[d] (.)
+        (dz_d @ W_d^T)."""
+        m, Hp = r1 - r0, s.Hp
+        if m <= 0:
+            return
+        ops.gate_gemm('dgrad', m, n_pad, s.f_in_pad, 4 * Hp, self.params, s.oW + d * 4 * Hp,
+                      8 * Hp, 8 * Hp, mask_w=None if BW is None else BW[d], dz=dz,
+                      z_off=r0 * 8 * Hp + d * 4 * Hp, dz_absmax=zmx, dx=dx,
+                      dx_off=r0 * s.f_in_pad, dx_beta=beta)
 
     def _dx_gemm(self, dz, s, dx, BW, r0, r1, n_pad, zmx):
         """dx[r0:r1] = sum_d B_W[d] (.) (dz_d[r0:r1] @ W_d^T) over slab rows [r0, r1)."""
@@ -927,7 +972,7 @@ class Model(object):
                 dx = None
                 if pipe_b:
                     # after S BPTT steps the gate gradients of frames [T-S, S) are final
-                    # in both directions: their dX GEMMs overlap the last quarter
+                    # in both directions: their dX GEMMs overlap the last steps
                     dx = self._buf('da_s%d' % si, (T, n_pad, s.f_in_pad))
                     ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp,
                                      mask_u=BU, mode=self.lstm_mode, dz_absmax=zmx, steps=(0, S),
@@ -938,6 +983,12 @@ class Model(object):
                     with torch.cuda.stream(self._pipe):
                         self._pipe.wait_event(ev)
                         self._dx_gemm(dz, s, dx, BW, (T - S) * n_pad, S * n_pad, n_pad, zmx)
+                        if self._pipe_halves:
+                            # the forward direction's BPTT (frames T-1 .. 0) has also finished
+                            # [S, T), the backward direction's [0, T-S): their terms of dx
+                            self._dx_gemm_dir(dz, s, dx, BW, S * n_pad, rows, n_pad, zmx, 0, 0.0)
+                            self._dx_gemm_dir(dz, s, dx, BW, 0, (T - S) * n_pad, n_pad, zmx, 1,
+                                              0.0)
                         dx_inner = torch.cuda.Event()
                         dx_inner.record(self._pipe)
                     rec['ws_b'] = ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad,
@@ -1040,7 +1091,12 @@ class Model(object):
                     gu(wsn)
                     gw(wsn)
 
-                if pipe_b:
+                if pipe_b and self._pipe_halves:
+                    main.wait_event(dx_inner)
+                    self._dx_gemm_dir(dz, s, dx, BW, S * n_pad, rows, n_pad, zmx, 1, 1.0)
+                    self._dx_gemm_dir(dz, s, dx, BW, 0, (T - S) * n_pad, n_pad, zmx, 0, 1.0)
+                    da = dx
+                elif pipe_b:
                     self._dx_gemm(dz, s, dx, BW, 0, (T - S) * n_pad, n_pad, zmx)
                     self._dx_gemm(dz, s, dx, BW, S * n_pad, rows, n_pad, zmx)
                     main.wait_event(dx_inner)

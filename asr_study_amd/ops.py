@@ -67,7 +67,7 @@ def _resolve_split(split_k, M, N, K, tile=128):
 def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None,
          alpha=1.0, beta=0.0, bias=None, a_scale=None, a_scale_period=0, c_scale=None,
          c_scale_period=0, split_k=0, a_off=0, b_off=0, c_off=0, ws_name='gemm',
-         precision=-1, a_absmax=None, b_absmax=None):
+         precision=-1, a_absmax=None, b_absmax=None, a_scale_off=0, a_scale_ld=None):
     """C[M,N] = alpha * opA(A) @ opB(B) + beta*C (+bias), see include/asr_hip.h.
 
     A/B/Cm are float32 CUDA tensors used as raw storage; *_off are element
@@ -84,9 +84,10 @@ def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ld
     a.ldc = int(ldc if ldc is not None else N)
     a.alpha, a.beta = float(alpha), float(beta)
     a.bias = bias.data_ptr() if bias is not None else None
-    a.a_scale = a_scale.data_ptr() if a_scale is not None else None
+    a.a_scale = a_scale.data_ptr() + 4 * int(a_scale_off) if a_scale is not None else None
     a.a_scale_period = int(a_scale_period)
-    a.a_scale_ld = int(a_scale.shape[-1]) if a_scale is not None else 0
+    a.a_scale_ld = int(a_scale_ld if a_scale_ld is not None else a_scale.shape[-1]) \
+        if a_scale is not None else 0
     a.c_scale = c_scale.data_ptr() if c_scale is not None else None
     a.c_scale_period = int(c_scale_period)
     a.c_scale_ld = int(c_scale.shape[-1]) if c_scale is not None else 0
