@@ -144,8 +144,12 @@ inline long long tap_row(const Geo& g, int dt) {
   return ((long long)r * g.S + (q - g.qmin)) * g.n_pad;
 }
 
+// threads of the dz pack that share a column group: each keeps the column sums of its rows
+// (bias gradient) in registers -> a (kPartRows, Ko_p) slab of partial sums, no fp32 copy of dz
+constexpr int kPartRows = 2048;
+
 struct Ws {                       // byte offsets into the caller's workspace
-  size_t scal, xpl, dzpl, dzf, band_f, band_dg, bandf_pl, banddg_pl, bias_band, dband, gemm, colsum, end;
+  size_t scal, xpl, dzpl, colpart, band_f, band_dg, bandf_pl, banddg_pl, bias_band, dband, gemm, colsum, end;
   size_t gemm_bytes, colsum_bytes;
 };
 
@@ -169,7 +173,7 @@ Ws make_ws(const Geo& g) {
   w.scal = take(64 * sizeof(float));
   w.xpl = take((size_t)g.st * g.S * g.n_pad * g.Ki_p * 4);
   w.dzpl = take((size_t)(g.padb + g.T_out + g.pada) * g.n_pad * g.Ko_p * 4);
-  w.dzf = take((size_t)g.M * g.Ko * 4);
+  w.colpart = take((size_t)kPartRows * g.Ko_p * 4);
   w.band_f = take((size_t)g.kt * g.Ki_p * g.Ko * 4);
   w.band_dg = take((size_t)g.Ki * g.kt * g.Ko_p * 4);
   w.bandf_pl = take((size_t)g.Ko * g.kt * g.Ki_p * 4);
@@ -184,7 +188,7 @@ Ws make_ws(const Geo& g) {
   }
   w.gemm_bytes = asr_align_up(w.gemm_bytes, 256);
   w.gemm = take(w.gemm_bytes);
-  w.colsum_bytes = asr_colsum_workspace_bytes((int)g.M, g.Ko);
+  w.colsum_bytes = asr_colsum_workspace_bytes(kPartRows, g.Ko);
   w.colsum = take(w.colsum_bytes);
   w.end = o;
   return w;
@@ -232,22 +236,31 @@ conv_band_kernel(Geo g, const float* __restrict__ W, const float* __restrict__ b
 //   MODE 0: x planes in the phase layout (row = (phase r, slot s, sample n) <- frame
 //           st (s + qmin) + r, zeros outside the slab);
 //   MODE 1: dz planes, dz = dy (.) act'(z), rows (padb + t', n) with zero frames before and
-//           behind; also writes dz as fp32 (bias gradient).
+//           behind.  Thread (slot, group) walks the rows slot, slot + kPartRows, ... of its
+//           column group and leaves the column sums of what it packed in colpart[slot]
+//           (the bias gradient = their sum, folded over fo; fixed order: deterministic).
 template <int MODE>
 __global__ void __launch_bounds__(256)
 conv_pack_kernel(Geo g, const float* __restrict__ src, const float* __restrict__ zpre,
                  float clip, const float* __restrict__ absmax, float* __restrict__ scale_out,
-                 _Float16* __restrict__ planes, float* __restrict__ dzf) {
+                 _Float16* __restrict__ planes, float* __restrict__ colpart) {
   const int K = MODE == 0 ? g.Ki : g.Ko, K_p = MODE == 0 ? g.Ki_p : g.Ko_p;
   const int groups = K_p / 16;
   const long long frames = MODE == 0 ? (long long)g.st * g.S : (long long)g.padb + g.T_out + g.pada;
-  const size_t total = (size_t)frames * g.n_pad * groups;
+  const size_t rows = (size_t)frames * g.n_pad;
   const float s = pow2_scale_of(absmax);
   if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    const int grp = (int)(idx % groups);
-    const size_t row = idx / groups;
+  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // MODE 0: one (row, group) item per step of a grid-stride loop; MODE 1: the group is the
+  // thread's for good (the launch has exactly groups * kPartRows threads)
+  const size_t total = MODE == 0 ? rows * groups : rows;
+  const size_t step = MODE == 0 ? (size_t)gridDim.x * blockDim.x : (size_t)kPartRows;
+  float csum[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) csum[e] = 0.f;
+  for (size_t idx = MODE == 0 ? gtid : gtid / groups; idx < total; idx += step) {
+    const int grp = (int)((MODE == 0 ? idx : gtid) % groups);
+    const size_t row = MODE == 0 ? idx / groups : idx;
     const int n = (int)(row % g.n_pad);
     const long long fr = (long long)(row / g.n_pad);
     long long t;                                   // source frame, or out of range
@@ -270,19 +283,19 @@ conv_pack_kernel(Geo g, const float* __restrict__ src, const float* __restrict__
         if (c0 + 4 * q < K) {                      // K % 4 == 0: whole quads
           const float4 a = *reinterpret_cast<const float4*>(src + base + 4 * q);
           v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
-          if (MODE == 1) {
-            if (clip > 0.f) {
-              const float4 zz = *reinterpret_cast<const float4*>(zpre + base + 4 * q);
-              if (!(zz.x > 0.f && zz.x < clip)) v[4 * q] = 0.f;
-              if (!(zz.y > 0.f && zz.y < clip)) v[4 * q + 1] = 0.f;
-              if (!(zz.z > 0.f && zz.z < clip)) v[4 * q + 2] = 0.f;
-              if (!(zz.w > 0.f && zz.w < clip)) v[4 * q + 3] = 0.f;
-            }
-            *reinterpret_cast<float4*>(dzf + base + 4 * q) =
-                make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+          if (MODE == 1 && clip > 0.f) {
+            const float4 zz = *reinterpret_cast<const float4*>(zpre + base + 4 * q);
+            if (!(zz.x > 0.f && zz.x < clip)) v[4 * q] = 0.f;
+            if (!(zz.y > 0.f && zz.y < clip)) v[4 * q + 1] = 0.f;
+            if (!(zz.z > 0.f && zz.z < clip)) v[4 * q + 2] = 0.f;
+            if (!(zz.w > 0.f && zz.w < clip)) v[4 * q + 3] = 0.f;
           }
         }
       }
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) csum[e] += v[e];
     }
     hx8 hi0, hi1, lo0, lo1;
 #pragma unroll
@@ -297,6 +310,12 @@ conv_pack_kernel(Geo g, const float* __restrict__ src, const float* __restrict__
     *reinterpret_cast<hx8*>(dst + 8) = hi1;
     *reinterpret_cast<hx8*>(dst + 16) = lo0;
     *reinterpret_cast<hx8*>(dst + 24) = lo1;
+  }
+  if (MODE == 1 && gtid < (size_t)kPartRows * groups) {
+    float4* out = reinterpret_cast<float4*>(colpart + (gtid / groups) * K_p + (gtid % groups) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      out[q] = make_float4(csum[4 * q], csum[4 * q + 1], csum[4 * q + 2], csum[4 * q + 3]);
   }
 }
 
@@ -406,10 +425,11 @@ int pack_dz(const Geo& g, const asr_conv2d_args* a, const Ws& w, char* ws, hipSt
   float* scal = reinterpret_cast<float*>(ws + w.scal);
   const int rc = asr_absmax(a->dy, (int64_t)g.M * g.Ko, scal + 1, stream);   // |dz| <= |dy|
   if (rc) return rc;
-  const size_t items = (size_t)(g.padb + g.T_out + g.pada) * g.n_pad * (g.Ko_p / 16);
-  hipLaunchKernelGGL(conv_pack_kernel<1>, dim3(grid_for(items)), dim3(256), 0, stream, g, a->dy,
+  const unsigned blocks = (unsigned)((size_t)kPartRows * (g.Ko_p / 16) / 256);   // exact
+  hipLaunchKernelGGL(conv_pack_kernel<1>, dim3(blocks), dim3(256), 0, stream, g, a->dy,
                      a->z, a->clip, scal + 1, scal + 9,
-                     reinterpret_cast<_Float16*>(ws + w.dzpl), reinterpret_cast<float*>(ws + w.dzf));
+                     reinterpret_cast<_Float16*>(ws + w.dzpl),
+                     reinterpret_cast<float*>(ws + w.colpart));
   ASR_CHECK_LAUNCH();
   return ASR_OK;
 }
@@ -528,9 +548,9 @@ extern "C" int asr_conv2d_wgrad(const asr_conv2d_args* a, void* workspace, size_
   float* dband = reinterpret_cast<float*>(ws + w.dband);
   float* cs = nullptr;
   if (a->db) {
-    // column sums of dz (fp32 copy written by the pack), folded over fo by the reduce kernel
+    // column sums of dz: the pack left kPartRows partial rows; folded over fo by the reduce kernel
     cs = reinterpret_cast<float*>(ws + w.band_f);          // (free during wgrad: Ko floats)
-    rc = asr_colsum(reinterpret_cast<float*>(ws + w.dzf), (int)g.M, g.Ko, g.Ko, cs, 0.f,
+    rc = asr_colsum(reinterpret_cast<float*>(ws + w.colpart), kPartRows, g.Ko, g.Ko_p, cs, 0.f,
                     ws + w.colsum, w.colsum_bytes, stream);
     if (rc) return rc;
   }

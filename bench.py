@@ -790,8 +790,10 @@ def main():
                 'traffic': pmc.get('conv'),
                 'note': 'achieved = 3 x the ALGORITHMIC convolution flops (2 M Ko kt kf Ci per '
                         'pass; split-fp16) / time of the whole entry point.  The banded form '
-                        'multiplies ~2x those flops on the matrix pipes (the band is kf / F_in '
-                        'dense), so the pipes are about twice as busy as `frac` says'}
+                        'multiplies more than those flops on the matrix pipes: the band of a '
+                        'time tap is kf / F_in dense (layer 1: 41 of 80 -> ~2x), cut by the '
+                        'frequency blocks where the channel count allows (layer 2: 21 of 30 '
+                        'per block -> ~1.4x), so the pipes are busier than `frac` says'}
         if world == 1 and not args.no_extras:
             if args.config == 'cfg3':
                 line['cfg3_conv'] = _sub_bench('cfg3_conv', {}, args.steps, args.warmup, args.dropout)

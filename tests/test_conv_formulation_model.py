@@ -41,6 +41,7 @@ def test_gemm_formulation_equals_the_convolution(T, F, Ci, Co, kt, kf, st, sf):
     (6, 32, 32, 32, 3, 5, 2, 1, 4, 4),       # four column blocks, four row blocks
     (5, 40, 32, 32, 3, 21, 1, 2, 2, 5),      # the second front-end layer's frequency geometry
     (9, 8, 4, 4, 5, 5, 1, 2, 1, 1),          # nothing to cut: one block = the whole band
+    (6, 41, 32, 32, 3, 5, 1, 2, 1, 6),       # ragged last row block (one input frequency)
 ])
 def test_frequency_blocks_cover_the_band(T, F, Ci, Co, kt, kf, st, sf, ncol, nrow):
     """make_geo's column blocks (forward, dgrad) and row blocks (weight gradient): GEMMs on column

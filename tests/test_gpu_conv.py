@@ -75,6 +75,7 @@ CASES = [
     (20, 5, 24, 32, 48, 5, 9, 1, 2, 3.0),      # two frequency blocks (C_in % 32 == 0, 288 columns each)
     (11, 17, 32, 32, 32, 3, 5, 2, 1, 0.0),     # four column blocks, four row blocks (dW), stride (2, 1)
     (12, 16, 40, 32, 32, 3, 21, 1, 2, 5.0),    # the second front-end layer's frequency geometry: 2 / 5 blocks
+    (6, 16, 41, 32, 32, 3, 5, 1, 2, 0.0),      # six row blocks, the last one a single input frequency
 ]
 
 
