@@ -33,9 +33,50 @@ constexpr int FRAMES_PER_WAVE = 4;
 constexpr int WAVES = 4;
 constexpr int FRAMES_PER_BLOCK = FRAMES_PER_WAVE * WAVES;
 constexpr double kF64Eps = 2.220446049250313e-16;   // np.finfo(float).eps
+constexpr int kMelLd = 128;             // filters per row of the transposed mel table
+constexpr int kMelPasses = kMelLd / 64;
+// workspace tail: twiddles (385 double2) + the transposed compact mel table (<= 257 rows)
+constexpr size_t kTwBytes = 6400;                                // 385 double2 -> multiple of 256
+constexpr size_t kMelTBytes = (size_t)NBINS * kMelLd * sizeof(double);
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
   return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// Tables of one call: the FFT twiddles, and the mel matrix in the arrangement the frame
+// kernel walks: mel_t[i][jf] = mel[jf][lo_jf + i] for i < hi_jf - lo_jf, else 0 (rows up to the
+// widest filter; columns up to kMelLd).  One workgroup.
+__global__ void __launch_bounds__(256)
+fe_prepare_kernel(int num_filt, const double* __restrict__ mel, const int* __restrict__ mel_range,
+                  double2* __restrict__ tw_tab, double* __restrict__ mel_t) {
+  __shared__ int s_w[256];
+  const int tid = threadIdx.x;
+  for (int m = tid; m <= 384; m += 256) {
+    double s, c;
+    sincospi(-(double)m / 256.0, &s, &c);         // angle = -2 pi m / 512
+    tw_tab[m] = make_double2(c, s);
+  }
+  int wmax = 0;
+  for (int jf = tid; jf < num_filt; jf += 256) {
+    const int wd = mel_range[2 * jf + 1] - mel_range[2 * jf];
+    wmax = wd > wmax ? wd : wmax;
+  }
+  s_w[tid] = wmax;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) s_w[tid] = s_w[tid] > s_w[tid + st] ? s_w[tid] : s_w[tid + st];
+    __syncthreads();
+  }
+  wmax = s_w[0] < NBINS ? s_w[0] : NBINS;
+  for (int e = tid; e < wmax * kMelLd; e += 256) {
+    const int i = e / kMelLd, jf = e % kMelLd;
+    double v = 0.0;
+    if (jf < num_filt) {
+      const int lo = mel_range[2 * jf], hi = mel_range[2 * jf + 1];
+      if (lo + i < hi && lo + i < NBINS) v = mel[(size_t)jf * NBINS + lo + i];
+    }
+    mel_t[e] = v;
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -43,7 +84,8 @@ fe_frames_kernel(asr_frontend_cfg cfg, const float* __restrict__ audio,
                  const int* __restrict__ offsets, const int* __restrict__ lengths,
                  const double* __restrict__ window, const double* __restrict__ mel,
                  const int* __restrict__ mel_range, const double* __restrict__ dct,
-                 double* __restrict__ base, int max_frames, int fb) {
+                 double* __restrict__ base, int max_frames, int fb,
+                 const double2* __restrict__ tw_tab, const double* __restrict__ mel_t) {
   __shared__ double2 tw[384 + 1];                // e^{-2 pi i m / 512}, m = 0..384
   __shared__ double2 buf[WAVES][2][256];         // ping-pong complex buffers
   __shared__ double pspec[WAVES][NBINS + 3];
@@ -61,31 +103,54 @@ fe_frames_kernel(asr_frontend_cfg cfg, const float* __restrict__ audio,
   const int f_block = blockIdx.x * FRAMES_PER_BLOCK;
   if (f_block >= nframes) return;                 // uniform per block
 
-  for (int m = tid; m <= 384; m += 256) {
-    double s, c;
-    sincospi(-(double)m / 256.0, &s, &c);         // angle = -2 pi m / 512
-    tw[m] = make_double2(c, s);
+  for (int m = tid; m <= 384; m += 256) tw[m] = tw_tab[m];    // (fe_prepare_kernel)
+  // this lane's mel filters (lane, lane + 64): first bin, width, and the width the wave
+  // walks (its widest filter): the same for every frame
+  int mlo[kMelPasses], mwave[kMelPasses];
+#pragma unroll
+  for (int ps = 0; ps < kMelPasses; ++ps) {
+    const int jf = lane + 64 * ps;
+    const bool has = jf < cfg.num_filt;
+    mlo[ps] = has ? mel_range[2 * jf] : 0;
+    const int width = has ? mel_range[2 * jf + 1] - mlo[ps] : 0;
+    mwave[ps] = __builtin_amdgcn_readfirstlane((int)asr_wave_max((float)width));
   }
   __syncthreads();
 
   double* real_in = reinterpret_cast<double*>(&buf[w][0][0]);   // 512 reals == 256 complex
+  // The samples of a frame (and their predecessors, for the pre-emphasis) are fetched into
+  // registers one frame AHEAD: the loads of frame fi + 1 fly under the FFT of frame fi.  (Loaded
+  // where they were used, a frame waited for 8 dependent round trips to HBM / L2: 11 us per
+  // frame and wave, most of the kernel.)
+  float xs[NFFT / 64], xq[NFFT / 64];
+  auto fetch = [&](int f) {
+    const int s0 = f * cfg.frame_step;
+    const bool live = f < nframes;
+#pragma unroll
+    for (int q = 0; q < NFFT / 64; ++q) {
+      const int i = lane + 64 * q, idx = s0 + i;
+      const bool in = live && i < cfg.frame_len && idx < len;
+      xs[q] = in ? audio[off + idx] : 0.f;
+      xq[q] = (in && idx > 0) ? audio[off + idx - 1] : 0.f;
+    }
+  };
+  fetch(f_block + w * FRAMES_PER_WAVE);
   for (int fi = 0; fi < FRAMES_PER_WAVE; ++fi) {
     const int f = f_block + w * FRAMES_PER_WAVE + fi;
     const bool live = f < nframes;
-    // ---- load + pre-emphasis + window (zero padded to 512)
+    // ---- pre-emphasis + window (zero padded to 512)
     const int s0 = f * cfg.frame_step;
-    for (int i = lane; i < NFFT; i += 64) {
+#pragma unroll
+    for (int q = 0; q < NFFT / 64; ++q) {
+      const int i = lane + 64 * q, idx = s0 + i;
       double v = 0.0;
-      if (live && i < cfg.frame_len) {
-        const int idx = s0 + i;
-        if (idx < len) {
-          const double x = (double)audio[off + idx];
-          const double xp = idx > 0 ? (double)audio[off + idx - 1] : 0.0;
-          v = (idx > 0 ? x - cfg.pre_emph * xp : x) * window[i];
-        }
+      if (live && i < cfg.frame_len && idx < len) {
+        const double x = (double)xs[q], xp = (double)xq[q];
+        v = (idx > 0 ? x - cfg.pre_emph * xp : x) * window[i];
       }
       real_in[i] = v;
     }
+    if (fi + 1 < FRAMES_PER_WAVE) fetch(f + 1);
     __syncthreads();
     // ---- 256-point complex FFT, radix-4 Stockham, Ns = 1, 4, 16, 64
     int cur = 0;
@@ -136,13 +201,27 @@ fe_frames_kernel(asr_frontend_cfg cfg, const float* __restrict__ audio,
     if (esum == 0.0) esum = kF64Eps;
     __syncthreads();
     // ---- mel filterbank (triangles are sparse: only [lo, hi) bins) + log
-    for (int jf = lane; jf < cfg.num_filt; jf += 64) {
-      const int lo = mel_range[2 * jf], hi = mel_range[2 * jf + 1];
-      const double* mrow = mel + (size_t)jf * NBINS;
+    // filter jf = sum over its bins lo .. hi-1, in that order; the weights come from the
+    // transposed compact table mel_t[i][jf] = mel[jf][lo + i] (0 from the filter's width on:
+    // adding x * 0 changes nothing), so that the loop is uniform over the wave, its loads
+    // coalesced and independent of each other (the per-lane `for k in [lo, hi)` over the dense
+    // rows was a chain of dependent L1 round trips: the slowest part of the kernel)
+#pragma unroll
+    for (int ps = 0; ps < kMelPasses; ++ps) {
+      const int jf = lane + 64 * ps;
+      if (64 * ps >= cfg.num_filt) break;
       double acc = 0.0;
-      for (int k = lo; k < hi; ++k) acc += pspec[w][k] * mrow[k];
-      if (acc == 0.0) acc = kF64Eps;
-      lmel[w][jf] = log(acc);
+      const double* wt = mel_t + jf;
+#pragma unroll 4
+      for (int i = 0; i < mwave[ps]; ++i) {
+        int k = mlo[ps] + i;
+        k = k < NBINS ? k : NBINS - 1;
+        acc += pspec[w][k] * wt[(size_t)i * kMelLd];
+      }
+      if (jf < cfg.num_filt) {
+        if (acc == 0.0) acc = kF64Eps;
+        lmel[w][jf] = log(acc);
+      }
     }
     __syncthreads();
     // ---- write base features
@@ -324,7 +403,7 @@ extern "C" int asr_frontend_num_feats(const asr_frontend_cfg* cfg) {
 extern "C" size_t asr_frontend_workspace_bytes(const asr_frontend_cfg* cfg, int n_utt,
                                                int max_frames) {
   return asr_align_up((size_t)n_utt * max_frames * asr_frontend_num_feats(cfg) *
-                          sizeof(double), 256);
+                          sizeof(double), 256) + kTwBytes + kMelTBytes;
 }
 
 extern "C" int asr_frontend_features(const asr_frontend_cfg* cfg, const float* audio,
@@ -360,9 +439,15 @@ extern "C" int asr_frontend_features(const asr_frontend_cfg* cfg, const float* a
     return ASR_ERR_WORKSPACE;
   }
   double* full = reinterpret_cast<double*>(workspace);
+  char* tail = reinterpret_cast<char*>(workspace) + (need - kTwBytes - kMelTBytes);
+  double2* tw_tab = reinterpret_cast<double2*>(tail);
+  double* mel_t = reinterpret_cast<double*>(tail + kTwBytes);
+  hipLaunchKernelGGL(fe_prepare_kernel, dim3(1), dim3(256), 0, stream, cfg->num_filt, mel,
+                     mel_range, tw_tab, mel_t);
+  ASR_CHECK_LAUNCH();
   dim3 grid((max_frames + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK, n_utt);
   hipLaunchKernelGGL(fe_frames_kernel, grid, dim3(256), 0, stream, *cfg, audio, offsets,
-                     lengths, window, mel, mel_range, dct, full, max_frames, ffull);
+                     lengths, window, mel, mel_range, dct, full, max_frames, ffull, tw_tab, mel_t);
   ASR_CHECK_LAUNCH();
   hipLaunchKernelGGL(fe_finalize_kernel, dim3(n_utt), dim3(kFinalizeThreads), 0, stream, *cfg, lengths,
                      full, max_frames, fb, ffull, out, t_out, n_pad, f_out, out_frames);
