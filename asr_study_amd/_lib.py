@@ -57,7 +57,8 @@ class GemmHlArgs(C.Structure):
                 ('c_scale', void_p), ('c_scale_period', C.c_int), ('c_scale_ld', C.c_int),
                 ('split_k', C.c_int), ('tile', C.c_int), ('k_major', C.c_int),
                 ('a_seg_k', C.c_int), ('a_seg_row', C.c_longlong * 16),
-                ('batch', C.c_int), ('a_batch_row', C.c_longlong * 16)]
+                ('batch', C.c_int), ('a_batch_row', C.c_longlong * 16),
+                ('clamp_hi', C.c_float)]
 
 
 class Conv2dArgs(C.Structure):
@@ -66,7 +67,7 @@ class Conv2dArgs(C.Structure):
                 ('sf', C.c_int), ('clip', C.c_float),
                 ('x', void_p), ('W', void_p), ('bias', void_p), ('z', void_p), ('y', void_p),
                 ('dy', void_p), ('dx', void_p), ('dW', void_p), ('db', void_p),
-                ('reuse_x', C.c_int), ('reuse_dz', C.c_int)]
+                ('reuse_x', C.c_int), ('reuse_dz', C.c_int), ('x_absmax', void_p)]
 
 
 class LstmArgs(C.Structure):

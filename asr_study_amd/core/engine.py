@@ -574,12 +574,13 @@ class Model(object):
                 pass
             elif s.kind == 'conv':
                 op = self._conv_op(si, s, T, n_pad)
-                z = self._buf('convz%d' % si, (op.T_out, n_pad, s.F_out * s.C_out))
-                y = self._buf('convy%d' % si, (op.T_out, n_pad, s.F_out * s.C_out)) \
-                    if s.clip > 0 else z
+                # clipped ReLU: applied in the GEMM epilogue, only y exists (its mask
+                # 0 < z < clip reads the same from y); linear: y is z
+                y = self._buf('convy%d' % si, (op.T_out, n_pad, s.F_out * s.C_out))
                 nw = s.kt * s.kf * s.C_in * s.C_out
-                op.fwd(a.contiguous(), self._view(s.oW, nw), self._view(s.ob, s.C_out), z, y)
-                rec.update(op=op, z=z)
+                op.fwd(a.contiguous(), self._view(s.oW, nw), self._view(s.ob, s.C_out),
+                       None if s.clip > 0 else y, y, x_absmax=self._clip_bound(si))
+                rec.update(op=op, z=y)
                 a = y
             elif s.kind == 'noise':
                 if training and s.value > 0:
@@ -619,8 +620,10 @@ class Model(object):
                 if self._stage_packed(s):
                     # |y| < 1 behind a BiLSTM stage; anything else is measured
                     prev = self.stages[si - 1] if si > 0 else None
+                    bound = self._clip_bound(si)
                     amax = self._const_one() if (prev is not None and prev.kind == 'bilstm') \
-                        else ops.absmax(a, self._buf('aamax%d' % si, (1,)))
+                        else (bound if bound is not None
+                              else ops.absmax(a, self._buf('aamax%d' % si, (1,))))
                     rec['pa'] = self._pack_input(si, s, a, BW, rows, n_pad, amax)
                     self._gate_gemm_hl(s, si, rec['pa'], zx, rows)
                 elif inner_done is None:
@@ -685,6 +688,21 @@ class Model(object):
             rec['out'] = a
             self._acts.append(rec)
         return a
+
+    def _clip_bound(self, si):
+        """1-element device tensor >= max|input of stage si| when that input is a clipped-ReLU
+        convolution's output (0 <= y <= clip), seen through reshapes; else None (measure)."""
+        j = si - 1
+        while j >= 0 and self.stages[j].kind == 'reshape':
+            j -= 1
+        if j < 0 or self.stages[j].kind != 'conv' or not self.stages[j].clip > 0:
+            return None
+        key = ('clipbound', float(self.stages[j].clip))
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.full((1,), float(self.stages[j].clip),
+                                              dtype=torch.float32, device=self.device)
+        return t
 
     def _conv_op(self, si, s, T, n_pad):
         """The ops.Conv2d of stage si for this slab shape (owns the layer's workspace: the

@@ -411,11 +411,15 @@ int build_band(const Geo& g, const asr_conv2d_args* a, const Ws& w, char* ws, bo
 
 int pack_x(const Geo& g, const asr_conv2d_args* a, const Ws& w, char* ws, hipStream_t stream) {
   float* scal = reinterpret_cast<float*>(ws + w.scal);
-  const int rc = asr_absmax(a->x, (int64_t)g.T_in * g.n_pad * g.Ki, scal + 0, stream);
-  if (rc) return rc;
+  const float* amax = a->x_absmax;          // the caller's bound (e.g. the clip of the layer
+  if (!amax) {                               // below), else a pass over x
+    const int rc = asr_absmax(a->x, (int64_t)g.T_in * g.n_pad * g.Ki, scal + 0, stream);
+    if (rc) return rc;
+    amax = scal + 0;
+  }
   const size_t items = (size_t)g.st * g.S * g.n_pad * (g.Ki_p / 16);
   hipLaunchKernelGGL(conv_pack_kernel<0>, dim3(grid_for(items)), dim3(256), 0, stream, g, a->x,
-                     (const float*)nullptr, 0.f, scal + 0, scal + 8,
+                     (const float*)nullptr, 0.f, amax, scal + 8,
                      reinterpret_cast<_Float16*>(ws + w.xpl), (float*)nullptr);
   ASR_CHECK_LAUNCH();
   return ASR_OK;
@@ -455,7 +459,11 @@ extern "C" int asr_conv2d_fwd(const asr_conv2d_args* a, void* workspace, size_t 
   hipStream_t stream = (hipStream_t)stream_;
   Geo g;
   ASR_CHECK_ARG(make_geo(a, &g), "conv2d: bad geometry (n_pad %% 16, kt <= 16, F*C %% 4 == 0)");
-  ASR_CHECK_ARG(a->x && a->W && a->z && (a->y || a->clip <= 0.f), "conv2d fwd: null pointer");
+  ASR_CHECK_ARG(a->x && a->W && (a->z || (a->y && a->clip > 0.f)) && (a->y || a->clip <= 0.f),
+                "conv2d fwd: null pointer");
+  // z == NULL (or y): the clipped ReLU leaves the GEMM epilogue, only y is written
+  const bool fused = a->clip > 0.f && (a->z == nullptr || a->z == a->y);
+  float* zout = fused ? a->y : a->z;
   const Ws w = make_ws(g);
   if (!ws_ok(w, workspace, ws_bytes)) return ASR_ERR_WORKSPACE;
   char* ws = reinterpret_cast<char*>(workspace);
@@ -474,14 +482,16 @@ extern "C" int asr_conv2d_fwd(const asr_conv2d_args* a, void* workspace, size_t 
     h.a_hl = ws + w.xpl + (size_t)(g.b_fi0[b] * g.C_in / 16) * 64; h.lda = g.Ki_p;
     h.b_hl = ws + w.bandf_pl; h.ldb = g.kt * gb.Ki_p;
     h.a_scale = scal + 8; h.b_scale = scal + 10;
-    h.C = a->z + (size_t)g.b_fo0[b] * g.C_out; h.ldc = g.Ko; h.alpha = 1.f; h.beta = 0.f;
+    h.C = zout + (size_t)g.b_fo0[b] * g.C_out; h.ldc = g.Ko; h.alpha = 1.f; h.beta = 0.f;
     h.bias = reinterpret_cast<float*>(ws + w.bias_band);
+    h.clamp_hi = fused ? a->clip : 0.f;
     h.a_seg_k = kseg;
     for (int dt = 0; dt < g.kt; ++dt) h.a_seg_row[dt] = tap_row(g, dt);
     rc = asr_gemm_hl(&h, nullptr, 0, stream);
     if (rc) return rc;
   }
-  if (a->clip > 0.f) {
+  if (fused) {
+  } else if (a->clip > 0.f) {
     const size_t n4 = (size_t)g.M * g.Ko / 4;
     hipLaunchKernelGGL(conv_act_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, a->z, a->y, n4,
                        a->clip);

@@ -133,6 +133,7 @@ struct Epilogue {
   const float* bias;
   const float* c_scale; int c_period, c_ld;
   float* partial;      // split-K: raw accumulators go here ([split][M][N])
+  float clamp_hi;      // > 0 (segmented gemm_hlx only): C = min(max(., 0), clamp_hi)
 };
 
 template <int BK>
@@ -1369,6 +1370,21 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
 #pragma unroll
         for (int e = 0; e < 4; ++e) bias[j][e] = ep.bias[col_w + 16 * j + e];
     }
+    if constexpr (SEG) {
+      if (ep.clamp_hi > 0.f) {          // the convolution's clipped ReLU, fused
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) {
+            float* dst = ep.C + (size_t)(row_w + 16 * i) * ep.ldc + col_w + 16 * j;
+            f32x4 v = am[i][j] * sc + bias[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), ep.clamp_hi);
+            *reinterpret_cast<f32x4*>(dst) = v;
+          }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -1431,6 +1447,9 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
         float v = am[i][j][e] * unscale * ep.alpha + (ep.bias ? ep.bias[col] : 0.f);
         if (use_msk) v *= ep.c_scale[(size_t)mod_period(row, ep.c_period) * ep.c_ld + col];
         if (use_old) v += ep.beta * *dst;
+        if constexpr (SEG) {
+          if (ep.clamp_hi > 0.f) v = fminf(fmaxf(v, 0.f), ep.clamp_hi);
+        }
         *dst = v;
       }
     }
@@ -1574,7 +1593,7 @@ extern "C" int asr_gemm(const asr_gemm_args* a, void* workspace, size_t ws_bytes
   Epilogue ep;
   ep.C = a->C; ep.ldc = a->ldc; ep.alpha = a->alpha; ep.beta = a->beta; ep.bias = a->bias;
   ep.c_scale = a->c_scale; ep.c_period = a->c_scale_period > 0 ? a->c_scale_period : 1;
-  ep.c_ld = a->c_scale_ld; ep.partial = nullptr;
+  ep.c_ld = a->c_scale_ld; ep.partial = nullptr; ep.clamp_hi = 0.f;
   if (splits > 1) {
     const size_t need = (size_t)splits * a->M * a->N * sizeof(float);
     if (!workspace || ws_bytes < need) {
@@ -1752,7 +1771,7 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
   Epilogue ep;
   ep.C = a->C; ep.ldc = a->ldc; ep.alpha = a->alpha; ep.beta = a->beta; ep.bias = a->bias;
   ep.c_scale = a->c_scale; ep.c_period = a->c_scale_period > 0 ? a->c_scale_period : 1;
-  ep.c_ld = a->c_scale_ld; ep.partial = nullptr;
+  ep.c_ld = a->c_scale_ld; ep.partial = nullptr; ep.clamp_hi = 0.f;
   if (splits > 1) {
     const size_t need = (size_t)splits * (a->batch > 1 ? a->batch : 1) * a->M * a->N * sizeof(float);
     if (!workspace || ws_bytes < need) {
@@ -1760,6 +1779,11 @@ extern "C" int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws
       return ASR_ERR_WORKSPACE;
     }
     ep.partial = reinterpret_cast<float*>(workspace);
+  }
+  if (a->clamp_hi > 0.f) {
+    ASR_CHECK_ARG(a->a_seg_k > 0 && a->beta == 0.f && !a->c_scale && splits == 1,
+                  "gemm_hl: clamp_hi needs the segmented form, beta = 0, no mask, no split");
+    ep.clamp_hi = a->clamp_hi;
   }
   HlSeg seg;
   seg.magic = 0u;

@@ -668,15 +668,19 @@ class Conv2d(object):
 
     def _call(self, fn, name, **ptrs):
         a = self.args
-        for k in ('x', 'W', 'bias', 'z', 'y', 'dy', 'dx', 'dW', 'db'):
+        for k in ('x', 'W', 'bias', 'z', 'y', 'dy', 'dx', 'dW', 'db', 'x_absmax'):
             t = ptrs.get(k)
             setattr(a, k, t.data_ptr() if t is not None else None)
         a.reuse_x, a.reuse_dz = int(ptrs.get('reuse_x', 0)), int(ptrs.get('reuse_dz', 0))
         L.check(fn(C.byref(a), _ptr(self.ws), self.ws_bytes, _stream()), name)
 
-    def fwd(self, x, W, bias, z, y):
-        _check_f32(x, W, bias, z, y)
-        self._call(L.load().asr_conv2d_fwd, 'asr_conv2d_fwd', x=x, W=W, bias=bias, z=z, y=y)
+    def fwd(self, x, W, bias, z, y, x_absmax=None):
+        """z=None (clip > 0): the clipped ReLU is applied in the GEMM epilogue and only y is
+        written -- pass y as `z` to dgrad / wgrad then (the mask 0 < z < clip reads the same
+        from y).  x_absmax: 1-element device tensor >= max|x| (skips the measuring pass)."""
+        _check_f32(x, W, bias, z, y, x_absmax)
+        self._call(L.load().asr_conv2d_fwd, 'asr_conv2d_fwd', x=x, W=W, bias=bias, z=z, y=y,
+                   x_absmax=x_absmax)
         return y
 
     def dgrad(self, dy, z, W, dx, reuse_dz=False):
@@ -685,10 +689,10 @@ class Conv2d(object):
                    reuse_dz=reuse_dz)
         return dx
 
-    def wgrad(self, x, dy, z, dW, db, reuse_x=False, reuse_dz=False):
-        _check_f32(x, dy, z, dW, db)
+    def wgrad(self, x, dy, z, dW, db, reuse_x=False, reuse_dz=False, x_absmax=None):
+        _check_f32(x, dy, z, dW, db, x_absmax)
         self._call(L.load().asr_conv2d_wgrad, 'asr_conv2d_wgrad', x=x, dy=dy, z=z, dW=dW, db=db,
-                   reuse_x=reuse_x, reuse_dz=reuse_dz)
+                   reuse_x=reuse_x, reuse_dz=reuse_dz, x_absmax=x_absmax)
 
 
 # --------------------------------------------------------------------------- random streams

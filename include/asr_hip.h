@@ -207,6 +207,9 @@ typedef struct asr_gemm_hl_args {
   /* workspace is split_k * batch * M * N floats.                                              */
   int batch;
   long long a_batch_row[16];
+  /* > 0 (segmented form only; beta = 0, no mask): C = min(max(alpha A B^T + bias, 0), clamp_hi) */
+  /* -- the clipped ReLU of asr_conv2d_fwd applied where the tile is still in registers.         */
+  float clamp_hi;
 } asr_gemm_hl_args;
 size_t asr_gemm_hl_workspace_bytes(const asr_gemm_hl_args* a);
 int asr_gemm_hl(const asr_gemm_hl_args* a, void* workspace, size_t ws_bytes,
@@ -247,13 +250,19 @@ typedef struct asr_conv2d_args {
   const float* x;                /* fwd, wgrad                                      */
   const float* W;                /* (kt, kf, C_in, C_out)                           */
   const float* bias;             /* (C_out)                                         */
-  float* z;                      /* (T_out, n_pad, F_out*C_out): fwd out, bwd in    */
+  float* z;                      /* (T_out, n_pad, F_out*C_out): fwd out, bwd in.   */
+                                 /* fwd with clip > 0: NULL (or == y) fuses the     */
+                                 /* clipped ReLU into the GEMM epilogue -- only y   */
+                                 /* is written; bwd then takes y here (the mask     */
+                                 /* 0 < z < clip reads the same from y)             */
   float* y;                      /* fwd out (may be NULL when clip <= 0: y = z)     */
   const float* dy;               /* dgrad / wgrad in, shape of z                    */
   float* dx;                     /* dgrad out, shape of x                           */
   float* dW;                     /* wgrad out, shape of W                           */
   float* db;                     /* wgrad out (C_out)                               */
   int reuse_x, reuse_dz;
+  const float* x_absmax;         /* device float >= max|x| (the previous layer's    */
+                                 /* clip), or NULL: measured with asr_absmax        */
 } asr_conv2d_args;
 /* T_out = ceil(T_in / st), F_out = ceil(F_in / sf). */
 int asr_conv2d_out_shape(const asr_conv2d_args* a, int* T_out, int* F_out);

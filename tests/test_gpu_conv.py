@@ -121,6 +121,26 @@ def test_conv2d_fwd_dgrad_wgrad_vs_oracle(T, N, F, Ci, Co, kt, kf, st, sf, clip)
     gW2, gb2 = torch.zeros_like(gW), torch.zeros_like(gb)
     op2.wgrad(xd, dyd, z, gW2, gb2)
     assert torch.equal(gW2, gW) and torch.equal(gb2, gb)
+    if clip > 0:
+        # clipped ReLU fused into the GEMM epilogue (z = None): the same y, bit for bit, and the
+        # same gradients with y standing in for z (0 < z < clip reads the same from y); a bound
+        # on |x| instead of the measured maximum changes the planes' scale only
+        op3 = ops.Conv2d(T, n_pad, F, Ci, Co, kt, kf, st, sf, clip, dev())
+        y3 = torch.full(want_y.shape, 7.0, device=dev())
+        op3.fwd(xd, Wd, bd, None, y3)
+        assert torch.equal(y3, y)
+        gW3, gb3 = torch.zeros_like(gW), torch.zeros_like(gb)
+        if st == 1:
+            gx3 = torch.full(x.shape, 3.0, device=dev())
+            op3.dgrad(dyd, y3, Wd, gx3)
+            assert torch.equal(gx3, gx)
+        op3.wgrad(xd, dyd, y3, gW3, gb3, reuse_x=True, reuse_dz=st == 1)
+        assert torch.equal(gW3, gW) and torch.equal(gb3, gb)
+        bound = torch.full((1,), float(2.0 * np.abs(x).max() + 1.0), device=dev())
+        y4 = torch.full(want_y.shape, 7.0, device=dev())
+        ops.Conv2d(T, n_pad, F, Ci, Co, kt, kf, st, sf, clip, dev()).fwd(xd, Wd, bd, None, y4,
+                                                                          x_absmax=bound)
+        assert report('conv y under a bound on |x|', y4.cpu().numpy(), want_y) < tol
 
 
 def _ds2(F=16, C=7, H=16, L=2, seed=1, **kw):
