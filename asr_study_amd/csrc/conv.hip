@@ -155,12 +155,14 @@ struct Ws {                       // byte offsets into the caller's workspace
 
 int wgrad_splits(const Geo& g) {
   // kt K-major GEMMs (one per time tap, (Ki x Ko) outputs) in one batched launch: split the
-  // long row reduction only until about one workgroup per CU exists -- more splits add
-  // partial-sum traffic (a 64-way split per tap wrote and re-read 210 MB of partials per tap:
-  // 2.7 ms per step of reduce kernels)
+  // long row reduction until the launch fills the chip ONCE -- a workgroup of the 256 x 256
+  // kernel has a CU to itself (256 slots), the 128 x 128 kernel runs two per CU; a launch of
+  // 330 workgroups was two rounds, the second 29 % full.  More splits also add partial-sum
+  // traffic (a 64-way split per tap wrote and re-read 210 MB of partials per tap).
   const int tl = (g.Ki >= 256 && g.Ko >= 256) ? 256 : 128;
+  const int slots = tl == 256 ? 256 : 512;
   const int tiles = ((g.Ki + tl - 1) / tl) * ((g.Ko + tl - 1) / tl) * g.kt;   // all taps: one launch
-  long long s = (320 + tiles - 1) / tiles;
+  long long s = slots / tiles;
   if (s > 64) s = 64;
   if (s > g.M / 256) s = g.M / 256;
   return s < 1 ? 1 : (int)s;
