@@ -19,6 +19,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/summarize_prof.py $out/prof bench $out/kernel_stats.md "$cfg bench, round 4" > /dev/null 2> $out/summ.err
 cp $out/prof/bench_kernel_stats.csv $out/kernel_stats.csv
-python tools/summarize_pmc.py $out $out/hbm_traffic.md $cfg --json $out/pmc_traffic.json --source "profiles/${tag}_bench_${cfg}_hbm_traffic.md" > /dev/null 2>> $out/summ.err
+python tools/summarize_pmc.py $out $out/hbm_traffic.md $cfg --json $out/pmc_traffic.json --source "profiles/r4z_bench_${cfg}_hbm_traffic.md" > /dev/null 2>> $out/summ.err
 if [ "$cfg" = "cfg3" ]; then bash tools/pmc_step.sh ${tag}_pmc > $out/pmc_step.log 2>&1; fi
 head -12 $out/kernel_stats.md; tail -3 $out/summ.err

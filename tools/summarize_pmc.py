@@ -64,6 +64,14 @@ def families(rd, wr, layers):
             t += fetch_mult * sum(r) / max(len(r), 1) + sum(w) / max(len(w), 1)
         return t * 1e3
     steps = max([len(v) for k, v in list(rd.items()) + list(wr.items()) if k.startswith('adam_kernel')] + [1])
+
+    def per_step_sum(pred, fetch_mult):
+        # kernels launched several times per step (the conv front-end's packs, band builds and
+        # folds): every launch counts
+        t = 0.0
+        for k in names_of(pred):
+            t += fetch_mult * sum(rd.get(k, [])) + sum(wr.get(k, []))
+        return t * 1e3 / steps
     out = {'_steps_profiled': steps}
     for key, pred in (('fwd', lambda k: k.startswith('lstm_fwd_kernel')),
                       ('bwd', lambda k: k.startswith('lstm_bwd_kernel')),
@@ -80,7 +88,7 @@ def families(rd, wr, layers):
                             ('optimizer', lambda k: k.startswith('adam_kernel') or
                              k.startswith('norm_partial'), 2)):
         if names_of(pred):
-            out[key] = round(per_launch_sum(pred, mult), 1)
+            out[key] = round((per_step_sum if key == 'conv' else per_launch_sum)(pred, mult), 1)
     t, n = total(lambda k: k.startswith('gemm_hlx_kernel'))
     if n:
         out['gemm'] = round(t / n, 1)               # per LAUNCH (average over both forms)
