@@ -64,6 +64,18 @@ def _resolve_split(split_k, M, N, K, tile=128):
     return int(split_k)
 
 
+def _resolve_split_hl(split_k, M, N, K, tile=0, batch=1):
+    """'auto' for asr_gemm_hl: split K until the launch fills the chip ONCE -- a workgroup of the
+    256 x 256 kernel has a CU to itself (256 slots), the 128 x 128 kernel runs two per CU.  (A
+    launch a little over one round costs two: 312 workgroups of a 640 x 2048 weight gradient.)"""
+    if split_k != 'auto':
+        return int(split_k)
+    big = int(tile) != 128 and int(M) >= 256 and int(N) >= 256
+    tl, slots = (256, 256) if big else (128, 512)
+    tiles = ((int(M) + tl - 1) // tl) * ((int(N) + tl - 1) // tl) * max(1, int(batch))
+    return max(1, min(64, slots // tiles, int(K) // 256))
+
+
 def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None,
          alpha=1.0, beta=0.0, bias=None, a_scale=None, a_scale_period=0, c_scale=None,
          c_scale_period=0, split_k=0, a_off=0, b_off=0, c_off=0, ws_name='gemm',
@@ -630,7 +642,8 @@ def gemm_hl(A, B, Cm, M, N, K, a_row=0, a_k=0, b_row=0, b_k=0, c_off=0, ldc=None
     g.c_scale = c_scale.data_ptr() if c_scale is not None else None
     g.c_scale_period = int(c_scale_period)
     g.c_scale_ld = int(c_scale.shape[-1]) if c_scale is not None else 0
-    g.split_k = _resolve_split(split_k, M, N, K)
+    g.split_k = _resolve_split_hl(split_k, M, N, K, tile,
+                                  len(batch_rows) if batch_rows is not None else 1)
     g.tile = int(tile)
     g.k_major = 1 if k_major else 0
     if batch_rows is not None:      # k_major batch sharing B: C_b = A_b^T B, rows b*M.. of Cm
