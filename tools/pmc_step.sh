@@ -1,9 +1,10 @@
 #!/bin/bash
 # PMC passes (one counter group per run) over the cfg3 training step: wave-time split, MFMA
 # pipe use, LDS and L2 figures of every kernel of the step.
-# Usage (repo root, on the GPU box): bash tools/pmc_step.sh <tag>
+# Usage (repo root, on the GPU box): bash tools/pmc_step.sh <tag> [config]
 export TMPDIR=/tmp
 tag=${1:-pmc_step}
+cfg=${2:-cfg3}
 out=gpurun_out/$tag
 mkdir -p $out
 i=0
@@ -12,6 +13,6 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BU
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/step_$i -o g -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/step_$i.log 2>&1 </dev/null
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/step_$i -o g -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/step_$i.log 2>&1 </dev/null
 done
-python tools/pmc_parse.py $out $out/summary.md lstm_ gemm_hlx pack_hl ctc_ adam norm_partial fe_ gemm_splitk | grep -v "^  " | head -40
+python tools/pmc_parse.py $out $out/summary.md lstm_ gemm_hlx pack_hl ctc_ adam norm_partial fe_ gemm_splitk conv_ | grep -v "^  " | head -40
