@@ -616,7 +616,7 @@ class Model(object):
                     rec['zx'] = zx
                 nb += 1
                 main = torch.cuda.current_stream(self.device)
-                inner_done = pre.pop(si, None)
+                inner_done, halves = pre.pop(si, (None, False))
                 if self._stage_packed(s):
                     # |y| < 1 behind a BiLSTM stage; anything else is measured
                     prev = self.stages[si - 1] if si > 0 else None
@@ -628,7 +628,7 @@ class Model(object):
                     self._gate_gemm_hl(s, si, rec['pa'], zx, rows)
                 elif inner_done is None:
                     self._gate_gemm(a, s, zx, BW, 0, rows, n_pad)
-                elif self._pipe_halves:
+                elif halves:
                     # frames [T-S, S) were projected while the previous layer ran, and of the
                     # others the half of the reduction that was final by then (below): what is
                     # left on the critical path is the other half of those frames
@@ -666,7 +666,9 @@ class Model(object):
                         self._pipe.wait_event(ev)
                         BWn = stage_masks(si + 1)[0]
                         self._gate_gemm(y, nxt, zx_n, BWn, (T - S) * n_pad, S * n_pad, n_pad)
-                        if self._pipe_halves:
+                        # (the next stage's input must be exactly [y_f, y_b] of this one)
+                        halves = self._pipe_halves and nxt.f_in_pad == 2 * Hp
+                        if halves:
                             # x = [y_f, y_b]: after S steps y_f is final on the frames [0, T-S)
                             # too and y_b on [S, T) -- their halves of the reduction
                             # (+ bias) go ahead as well
@@ -676,7 +678,7 @@ class Model(object):
                                                  1, True)
                         done = torch.cuda.Event()
                         done.record(self._pipe)
-                    pre[si + 1] = done
+                    pre[si + 1] = (done, halves)
                     rec['ws'] = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
                                                  mode=self.lstm_mode, steps=(S, T - S))
                 else:
