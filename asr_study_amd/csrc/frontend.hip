@@ -259,115 +259,112 @@ __device__ __forceinline__ double delta_at(const double* __restrict__ x, int ld,
   return acc / 10.0;
 }
 
-// one 1024-thread workgroup per utterance: 16 row walkers per feature column
+// Workgroup (utterance, block of CX output columns): 1024 / CX row walkers per column.  (One
+// workgroup per utterance walked 62 rows per thread and pass on 64 of the 256 CUs.)  CX = 16
+// for wide outputs (64-byte runs of the slab rows: 80 log-mel columns 141 -> 39 us), 8 for
+// narrow ones (more workgroups: 39 MFCC columns 69 -> 36 us).
 constexpr int kFinalizeThreads = 1024;
 
+template <int CX>
 __global__ void __launch_bounds__(1024)
 fe_finalize_kernel(asr_frontend_cfg cfg, const int* __restrict__ lengths,
                    double* __restrict__ full, int max_frames, int fb, int ffull,
                    float* __restrict__ out, int t_out, int n_pad, int f_out,
                    int* __restrict__ out_frames) {
+  constexpr int TY = kFinalizeThreads / CX;
   const int utt = blockIdx.x;
+  const int c0 = blockIdx.y * CX;
   const int tid = threadIdx.x;
+  const int cx = tid % CX, ty = tid / CX;
   const int len = lengths[utt];
   int T = 1;
   if (len > cfg.frame_len) T = 1 + (len - cfg.frame_len + cfg.frame_step - 1) / cfg.frame_step;
   if (T > max_frames) T = max_frames;
   double* x = full + (size_t)utt * max_frames * ffull;
-  // ---- deltas (global scratch, visible block-wide after the barrier)
+  const int col = c0 + cx;                    // this thread's output column
+  const int cfull = col % ffull;              // ... is column cfull of the (base | d | dd) rows
+  // ---- deltas of the columns this workgroup reads (global scratch, visible block-wide after
+  // the barriers).  A delta-delta column needs its delta column, which another workgroup may
+  // own: this one computes it as well (workgroups that share a column write equal values).
   if (cfg.d) {
-    for (int e = tid; e < T * fb; e += kFinalizeThreads) {
-      const int t = e / fb, c = e % fb;
-      x[(size_t)t * ffull + fb + c] = delta_at(x, ffull, T, t, c);
-    }
+    const bool mine = col < f_out && cfull >= fb;
+    const int dcol = cfull >= 2 * fb ? cfull - fb : cfull;        // the delta column involved
+    if (mine)
+      for (int t = ty; t < T; t += TY) x[(size_t)t * ffull + dcol] = delta_at(x, ffull, T, t, dcol - fb);
     __syncthreads();
-    if (cfg.dd) {
-      for (int e = tid; e < T * fb; e += kFinalizeThreads) {
-        const int t = e / fb, c = e % fb;
-        x[(size_t)t * ffull + 2 * fb + c] = delta_at(x + fb, ffull, T, t, c);
-      }
-      __syncthreads();
-    }
+    if (mine && cfull >= 2 * fb)
+      for (int t = ty; t < T; t += TY)
+        x[(size_t)t * ffull + cfull] = delta_at(x + fb, ffull, T, t, cfull - 2 * fb);
+    __syncthreads();
   }
   const int stride = cfg.stride < 1 ? 1 : cfg.stride;
   const int Ts = (T + stride - 1) / stride;       // frames after feats[::stride]
-  const int nctx = 2 * cfg.num_context + 1;
-  auto get = [&](int ts, int col) -> double {
-    const int cslot = col / ffull, c = col % ffull;
+  auto get = [&](int ts) -> double {
+    const int cslot = col / ffull;
     const int src = ts + cslot - cfg.num_context;
     if (src < 0 || src >= Ts) return 0.0;
-    return x[(size_t)(src * stride) * ffull + c];
+    return x[(size_t)(src * stride) * ffull + cfull];
   };
-  (void)nctx;
-  // ---- column statistics: thread (cx, ty) walks t = ty, ty+TY, ... of column cx
-  constexpr int CX = 64, TY = kFinalizeThreads / 64;
+  // ---- column statistics: thread (cx, ty) walks t = ty, ty+TY, ... of column c0 + cx
   __shared__ double s_sum[TY][CX];
   __shared__ double s_sq[TY][CX];
   __shared__ double s_mx[TY][CX];
   __shared__ double s_mean[CX];
   __shared__ double s_inv[CX];
-  const int cx = tid & 63, ty = tid >> 6;
-  for (int c0 = 0; c0 < f_out; c0 += CX) {
-    const int col = c0 + cx;
-    double sum = 0.0, mn = 1e300, mx = -1e300;
-    if (col < f_out)
-      for (int ts = ty; ts < Ts; ts += TY) {
-        const double v = get(ts, col);
-        sum += v;
-        mn = v < mn ? v : mn;
-        mx = v > mx ? v : mx;
-      }
-    s_sum[ty][cx] = sum;
-    s_sq[ty][cx] = mn;            // (s_sq doubles as scratch for the column minimum ...)
-    s_mx[ty][cx] = mx;
-    __syncthreads();
-    double mean = 0.0;
-    if (col < f_out) {
-      double tot = 0.0, lo = 1e300, hi = -1e300;
-#pragma unroll
-      for (int i = 0; i < TY; ++i) {
-        tot += s_sum[i][cx];
-        lo = s_sq[i][cx] < lo ? s_sq[i][cx] : lo;
-        hi = s_mx[i][cx] > hi ? s_mx[i][cx] : hi;
-      }
-      // a constant column (an empty mel filter: log(eps) in every frame) has exactly its
-      // value as mean -- NumPy's pairwise sum of equal terms is exact there -- so that it
-      // standardises to exactly 0
-      mean = lo == hi ? lo : tot / Ts;
+  double sum = 0.0, mn = 1e300, mx = -1e300;
+  if (col < f_out)
+    for (int ts = ty; ts < Ts; ts += TY) {
+      const double v = get(ts);
+      sum += v;
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
     }
-    __syncthreads();              // (... before s_sq is reused for the squares)
-    double sq = 0.0;
-    if (col < f_out)
-      for (int ts = ty; ts < Ts; ts += TY) {
-        const double dlt = get(ts, col) - mean;
-        sq += dlt * dlt;
-      }
-    s_sq[ty][cx] = sq;
-    __syncthreads();
-    if (ty == 0 && col < f_out) {
-      double tot = 0.0;
-#pragma unroll
-      for (int i = 0; i < TY; ++i) tot += s_sq[i][cx];
-      const double var = tot / Ts;
-      s_mean[cx] = cfg.mean_norm ? mean : 0.0;
-      double sd = sqrt(var);
-      if (!cfg.mean_norm) {
-        // std is still computed about the true mean (np.std), only the shift is skipped
-      }
-      s_inv[cx] = cfg.var_norm ? sd + cfg.eps : 1.0;     // the divisor (audio.py:70-75)
+  s_sum[ty][cx] = sum;
+  s_sq[ty][cx] = mn;            // (s_sq doubles as scratch for the column minimum ...)
+  s_mx[ty][cx] = mx;
+  __syncthreads();
+  double mean = 0.0;
+  if (col < f_out) {
+    double tot = 0.0, lo = 1e300, hi = -1e300;
+    for (int i = 0; i < TY; ++i) {
+      tot += s_sum[i][cx];
+      lo = s_sq[i][cx] < lo ? s_sq[i][cx] : lo;
+      hi = s_mx[i][cx] > hi ? s_mx[i][cx] : hi;
     }
-    __syncthreads();
-    if (col < f_out) {
-      const double mu = s_mean[cx], den = s_inv[cx];
-      for (int ts = ty; ts < t_out; ts += TY) {
-        float v = 0.f;
-        if (ts < Ts) v = (float)((get(ts, col) - mu) / den);
-        out[((size_t)ts * n_pad + utt) * f_out + col] = v;
-      }
-    }
-    __syncthreads();
+    // a constant column (an empty mel filter: log(eps) in every frame) has exactly its
+    // value as mean -- NumPy's pairwise sum of equal terms is exact there -- so that it
+    // standardises to exactly 0
+    mean = lo == hi ? lo : tot / Ts;
   }
-  if (tid == 0 && out_frames) out_frames[utt] = Ts < t_out ? Ts : t_out;
+  __syncthreads();              // (... before s_sq is reused for the squares)
+  double sq = 0.0;
+  if (col < f_out)
+    for (int ts = ty; ts < Ts; ts += TY) {
+      const double dlt = get(ts) - mean;
+      sq += dlt * dlt;
+    }
+  s_sq[ty][cx] = sq;
+  __syncthreads();
+  if (ty == 0 && col < f_out) {
+    double tot = 0.0;
+    for (int i = 0; i < TY; ++i) tot += s_sq[i][cx];
+    const double var = tot / Ts;
+    s_mean[cx] = cfg.mean_norm ? mean : 0.0;
+    // (without mean_norm the std is still taken about the true mean -- np.std -- only the
+    // shift is skipped)
+    const double sd = sqrt(var);
+    s_inv[cx] = cfg.var_norm ? sd + cfg.eps : 1.0;     // the divisor (audio.py:70-75)
+  }
+  __syncthreads();
+  if (col < f_out) {
+    const double mu = s_mean[cx], den = s_inv[cx];
+    for (int ts = ty; ts < t_out; ts += TY) {
+      float v = 0.f;
+      if (ts < Ts) v = (float)((get(ts) - mu) / den);
+      out[((size_t)ts * n_pad + utt) * f_out + col] = v;
+    }
+  }
+  if (tid == 0 && blockIdx.y == 0 && out_frames) out_frames[utt] = Ts < t_out ? Ts : t_out;
 }
 
 __global__ void fe_zero_pad_rows_kernel(float* __restrict__ out, int t_out, int n_utt,
@@ -449,8 +446,14 @@ extern "C" int asr_frontend_features(const asr_frontend_cfg* cfg, const float* a
   hipLaunchKernelGGL(fe_frames_kernel, grid, dim3(256), 0, stream, *cfg, audio, offsets,
                      lengths, window, mel, mel_range, dct, full, max_frames, ffull, tw_tab, mel_t);
   ASR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(fe_finalize_kernel, dim3(n_utt), dim3(kFinalizeThreads), 0, stream, *cfg, lengths,
-                     full, max_frames, fb, ffull, out, t_out, n_pad, f_out, out_frames);
+  if (f_out >= 64)
+    hipLaunchKernelGGL(fe_finalize_kernel<16>, dim3(n_utt, (f_out + 15) / 16),
+                       dim3(kFinalizeThreads), 0, stream, *cfg, lengths, full, max_frames, fb,
+                       ffull, out, t_out, n_pad, f_out, out_frames);
+  else
+    hipLaunchKernelGGL(fe_finalize_kernel<8>, dim3(n_utt, (f_out + 7) / 8),
+                       dim3(kFinalizeThreads), 0, stream, *cfg, lengths, full, max_frames, fb,
+                       ffull, out, t_out, n_pad, f_out, out_frames);
   ASR_CHECK_LAUNCH();
   if (n_pad > n_utt) {
     hipLaunchKernelGGL(fe_zero_pad_rows_kernel, dim3(256), dim3(256), 0, stream, out, t_out,
