@@ -136,6 +136,10 @@ int main(void) {
          offsetof(asr_pack_args, ldk_c));
   printf("gemmhl %zu %zu %zu %zu\\n", sizeof(asr_gemm_hl_args), offsetof(asr_gemm_hl_args, b_scale),
          offsetof(asr_gemm_hl_args, bias), offsetof(asr_gemm_hl_args, split_k) + 1000 * offsetof(asr_gemm_hl_args, tile));
+  printf("gemmhl2 %zu %zu %zu\\n", offsetof(asr_gemm_hl_args, a_seg_row), offsetof(asr_gemm_hl_args, a_batch_row),
+         offsetof(asr_gemm_hl_args, clamp_hi));
+  printf("conv %zu %zu %zu %zu %zu\\n", sizeof(asr_conv2d_args), offsetof(asr_conv2d_args, clip),
+         offsetof(asr_conv2d_args, y), offsetof(asr_conv2d_args, reuse_dz), offsetof(asr_conv2d_args, x_absmax));
   printf("segment %zu %zu\\n", sizeof(asr_segment), offsetof(asr_segment, l2));
   printf("lstmln %zu %zu %zu\\n", sizeof(asr_lstm_ln_args), offsetof(asr_lstm_ln_args, cellp),
          offsetof(asr_lstm_ln_args, dparams));
@@ -156,6 +160,10 @@ int main(void) {
     P, GH = _lib.PackArgs, _lib.GemmHlArgs
     assert out['pack'] == [C.sizeof(P), P.scale_out.offset, P.ldk_c.offset]
     assert out['gemmhl'] == [C.sizeof(GH), GH.b_scale.offset, GH.bias.offset, GH.split_k.offset + 1000 * GH.tile.offset]
+    assert out['gemmhl2'] == [GH.a_seg_row.offset, GH.a_batch_row.offset, GH.clamp_hi.offset]
+    CV = _lib.Conv2dArgs
+    assert out['conv'] == [C.sizeof(CV), CV.clip.offset, CV.y.offset, CV.reuse_dz.offset,
+                           CV.x_absmax.offset]
     assert out['segment'] == [C.sizeof(S), S.l2.offset]
     LN = _lib.LstmLnArgs
     assert out['lstmln'] == [C.sizeof(LN), LN.cellp.offset, LN.dparams.offset]
@@ -186,3 +194,32 @@ def test_gemm_hl_argument_checks_need_no_gpu(lib):
     g.a_hl = base + 16                          # not at a reduction group
     assert lib.asr_gemm_hl(C.byref(g), None, 0, None) != 0
     assert b'64-byte' in lib.asr_last_error()
+
+
+def test_gemm_hl_clamp_needs_the_segmented_form(lib):
+    """clamp_hi (the conv front-end's clipped ReLU in the GEMM epilogue) exists in the segmented
+    instantiation only: anything else is refused before the device is touched."""
+    import ctypes as C
+    g = L.GemmHlArgs()
+    buf = (C.c_char * 4096)()
+    base = (C.addressof(buf) + 63) & ~63
+    g.M, g.N, g.K = 64, 64, 128
+    g.a_hl, g.b_hl, g.C = base, base, base
+    g.lda, g.ldb, g.ldc = 128, 128, 64
+    g.alpha = 1.0
+    g.clamp_hi = 20.0
+    assert lib.asr_gemm_hl(C.byref(g), None, 0, None) != 0
+    assert b'clamp_hi' in lib.asr_last_error()
+
+
+def test_auto_split_fills_the_chip_once():
+    """ops._resolve_split_hl: a workgroup of the 256 x 256 kernel has a CU to itself (256 slots),
+    the 128 x 128 kernel runs two per CU (512)."""
+    from asr_study_amd.ops import _resolve_split_hl as rs
+    assert rs('auto', 1024, 4096, 63936) == 4            # dW of a cfg3 layer: 64 tiles
+    assert rs('auto', 512, 2048, 63936) == 16            # dU of one direction: 16 tiles
+    assert rs('auto', 640, 2048, 32000) == 10            # 24 tiles: 240 workgroups, not 312
+    assert rs('auto', 80, 4096, 63936) == 16             # M < 256: the 128 x 128 kernel, 512 slots
+    assert rs('auto', 1280, 640, 32000, batch=11) == 1   # more tiles than slots
+    assert rs('auto', 256, 256, 512) == 2                # never shorter than 256 reduction indices
+    assert rs(7, 1024, 4096, 63936) == 7
