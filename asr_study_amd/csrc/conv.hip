@@ -42,17 +42,20 @@ struct Geo {
   int qmin, S;                    // phase layout of the x planes: slots s - qmin in [0, S)
   int padb, pada;                 // zero frames before / behind the dz planes
   long long M;                    // output rows T_out * n_pad
-  // Frequency blocks: the band of a time tap is kf / F_in dense, so the output frequencies are
-  // cut into nblk equal blocks; block b (outputs [fo0, fo0 + nfo)) only reads the input
-  // frequencies [fi0, fi0 + nfi) its filters reach -- a GEMM on a column range of the same
-  // planes with a shorter reduction (second layer of the front-end: 2 blocks, 30 / 29 of 40
-  // input frequencies: 25 % fewer MFMAs).  nblk = 1: the whole band.
+  // Frequency blocks: the band of a time tap is kf / F_in dense.  The FORWARD GEMM cuts its
+  // output columns into 256-wide blocks of output frequencies (whole tiles); block b (outputs
+  // [fo0, fo0 + nfo)) only reads the input frequencies [fi0, fi0 + nfi) its filters reach -- a
+  // GEMM on a column range of the same planes with a shorter reduction (second layer of the
+  // front-end: 3 blocks reading 26 / 33 / 17 of 40 input frequencies).  A block alone is half a
+  // round of the chip (125 workgroups at 64 x 10 s): the blocks' launches go out on separate
+  // streams (fork_join below).  nblk = 1: the whole band.
   int nblk;
   int b_fo0[4], b_nfo[4], b_fi0[4], b_nfi[4];
-  // The weight gradient cuts the band by ROWS instead (tile-aligned blocks of input
-  // frequencies, each with the output frequencies that reach it): its result is the band
-  // itself, so what counts there is the number of 256 x 256 tiles covering the nonzeros
-  // (second layer: 5 row blocks x 2 tiles instead of 5 x 3).  nwblk = 1: the whole band.
+  // The input gradient and the weight gradient cut the band by ROWS instead (tile-aligned
+  // blocks of input frequencies, each with the output frequencies that reach it): dx blocks do
+  // not overlap (nothing is accumulated between blocks), and the weight gradient's result is
+  // the band itself, so what counts there is the number of 256 x 256 tiles covering its
+  // nonzeros (second layer: 5 row blocks x 2 tiles instead of 5 x 3).  nwblk = 1: whole band.
   int nwblk;
   int w_fo0[8], w_nfo[8], w_fi0[8], w_nfi[8];
 };
@@ -80,28 +83,35 @@ bool make_geo(const asr_conv2d_args* a, Geo* g) {
   g->padb = a->kt - 1 - g->pt; g->pada = g->pt;
   if (g->padb < 0) g->padb = 0;
   g->M = (long long)g->T_out * a->n_pad;
-  // blocks need whole (hi, lo) groups / slabs at every cut: C_in % 32 == 0 (reduction offsets
-  // and lengths of the forward and weight-gradient GEMMs), nfo * C_out % 32 == 0 (those of the
-  // dgrad), and stay at least 256 output columns wide (the 256 x 256 tile)
+  // column blocks (forward): whole 256-column tiles of output frequencies, each with the input
+  // frequencies its filters reach.  Cuts need whole slabs of the reduction: C_in % 32 == 0.
+  // Adopted when they lower (column tiles) x (reduction length) summed over the blocks.
   g->nblk = 1;
-  for (int nb = 4; nb >= 2; --nb) {
-    if (g->F_out % nb || a->C_in % 32) continue;
-    const int nfo = g->F_out / nb;
-    if ((nfo * a->C_out) % 32 || nfo * a->C_out < 256) continue;
-    const int reach = a->sf * (nfo - 1) + a->kf;            // input frequencies a block touches
-    if (reach >= a->F_in) continue;                          // nothing to save
-    g->nblk = nb;
-    break;
+  g->b_fo0[0] = 0; g->b_nfo[0] = g->F_out; g->b_fi0[0] = 0; g->b_nfi[0] = a->F_in;
+  if (a->C_in % 32 == 0 && a->C_out <= 256 && 256 % a->C_out == 0) {
+    int cb = 256 / a->C_out;
+    while ((g->F_out + cb - 1) / cb > 4) cb *= 2;
+    const int nb = (g->F_out + cb - 1) / cb;
+    int cost = 0, fi0[4], nfi[4];
+    for (int b = 0; b < nb; ++b) {
+      const int fo0 = b * cb, nfo = fo0 + cb < g->F_out ? cb : g->F_out - fo0;
+      int lo = a->sf * fo0 - g->pf, hi = a->sf * (fo0 + nfo - 1) - g->pf + a->kf;
+      if (lo < 0) lo = 0;
+      if (hi > a->F_in) hi = a->F_in;
+      if (hi <= lo) hi = lo + 1;
+      fi0[b] = lo; nfi[b] = hi - lo;
+      cost += ((nfo * a->C_out + 255) / 256) * nfi[b];
+    }
+    if (nb > 1 && cost < ((g->Ko + 255) / 256) * a->F_in) {
+      g->nblk = nb;
+      for (int b = 0; b < nb; ++b) {
+        g->b_fo0[b] = b * cb;
+        g->b_nfo[b] = b * cb + cb < g->F_out ? cb : g->F_out - b * cb;
+        g->b_fi0[b] = fi0[b]; g->b_nfi[b] = nfi[b];
+      }
+    }
   }
-  for (int b = 0; b < g->nblk; ++b) {
-    const int nfo = g->F_out / g->nblk, fo0 = b * nfo;
-    int lo = a->sf * fo0 - g->pf, hi = a->sf * (fo0 + nfo - 1) - g->pf + a->kf;
-    if (lo < 0) lo = 0;
-    if (hi > a->F_in) hi = a->F_in;
-    g->b_fo0[b] = fo0; g->b_nfo[b] = nfo; g->b_fi0[b] = lo; g->b_nfi[b] = hi - lo;
-  }
-  if (g->nblk == 1) { g->b_fi0[0] = 0; g->b_nfi[0] = a->F_in; }
-  // row blocks of the weight gradient: fpb input frequencies = one 256-row tile
+  // row blocks (dgrad, weight gradient): fpb input frequencies = one 256-row tile of the band
   g->nwblk = 1;
   g->w_fo0[0] = 0; g->w_nfo[0] = g->F_out; g->w_fi0[0] = 0; g->w_nfi[0] = a->F_in;
   if (a->C_in % 32 == 0 && a->C_out % 32 == 0 && 256 % a->C_in == 0) {
@@ -185,8 +195,9 @@ Ws make_ws(const Geo& g) {
   w.colpart = take((size_t)kPartRows * g.Ko_p * 4);
   w.band_f = take((size_t)g.kt * g.Ki_p * g.Ko * 4);
   w.band_dg = take((size_t)g.Ki * g.kt * g.Ko_p * 4);
-  w.bandf_pl = take((size_t)g.Ko * g.kt * g.Ki_p * 4);
-  w.banddg_pl = take((size_t)g.Ki * g.kt * g.Ko_p * 4);
+  // (the blocks' planes lie one behind the other, each 256-byte aligned)
+  w.bandf_pl = take((size_t)g.Ko * g.kt * g.Ki_p * 4 + 8 * 256);
+  w.banddg_pl = take((size_t)g.Ki * g.kt * g.Ko_p * 4 + 8 * 256);
   w.bias_band = take((size_t)g.Ko * 4);
   w.dband = take((size_t)g.kt * g.Ki * g.Ko * 4);
   w.gemm_bytes = 0;                       // split-K partials of the largest block's launch
@@ -236,7 +247,7 @@ conv_band_kernel(Geo g, const float* __restrict__ W, const float* __restrict__ b
       band_dg[(size_t)k * g.kt * g.Ko_p + (size_t)dt * g.Ko_p + j] = v;
     }
     band_f[idx] = v;
-    if (idx < (size_t)g.Ko) bias_band[idx] = bias ? bias[idx % g.C_out] : 0.f;
+    if (bias_band && idx < (size_t)g.Ko) bias_band[idx] = bias ? bias[idx % g.C_out] : 0.f;
   }
 }
 
@@ -385,38 +396,93 @@ bool ws_ok(const Ws& w, void* workspace, size_t ws_bytes) {
   return false;
 }
 
-// W -> band matrices -> packed planes (both arrangements), bias_band
+// W -> band matrices of one block -> packed planes (either arrangement) at byte offset pl_off of
+// the plane region, bias_band.  first: also max|W| and the planes' scale (the same for every
+// block: later blocks leave the slots alone -- a GEMM of an earlier block may be reading them).
 int build_band(const Geo& g, const asr_conv2d_args* a, const Ws& w, char* ws, bool need_f,
-               bool need_dg, hipStream_t stream) {
+               bool need_dg, size_t pl_off, bool first, hipStream_t stream) {
   float* scal = reinterpret_cast<float*>(ws + w.scal);
   float* band_f = reinterpret_cast<float*>(ws + w.band_f);
   float* band_dg = reinterpret_cast<float*>(ws + w.band_dg);
   ASR_CHECK_HIP(hipMemsetAsync(band_dg, 0, (size_t)g.Ki * g.kt * g.Ko_p * 4, stream));
   hipLaunchKernelGGL(conv_band_kernel, dim3(grid_for((size_t)g.kt * g.Ki_p * g.Ko)), dim3(256), 0,
                      stream, g, a->W, a->bias, band_f, band_dg,
-                     reinterpret_cast<float*>(ws + w.bias_band));
+                     first ? reinterpret_cast<float*>(ws + w.bias_band) : (float*)nullptr);
   ASR_CHECK_LAUNCH();
-  int rc = asr_absmax(a->W, (int64_t)g.kt * g.kf * g.C_in * g.C_out, scal + 2, stream);
-  if (rc) return rc;
+  int rc;
+  if (first) {
+    rc = asr_absmax(a->W, (int64_t)g.kt * g.kf * g.C_in * g.C_out, scal + 2, stream);
+    if (rc) return rc;
+  }
   asr_pack_args p;
   if (need_f) {
     p = asr_pack_args{};
     p.src = band_f; p.rows = g.kt * g.Ki_p; p.cols = g.Ko; p.ld = g.Ko;
-    p.absmax = scal + 2; p.scale_out = scal + 10;
-    p.c_hl = ws + w.bandf_pl; p.ldk_c = g.kt * g.Ki_p;
+    p.absmax = scal + 2; p.scale_out = first ? scal + 10 : nullptr;
+    p.c_hl = ws + w.bandf_pl + pl_off; p.ldk_c = g.kt * g.Ki_p;
     rc = asr_pack_hl(&p, stream);
     if (rc) return rc;
   }
   if (need_dg) {
     p = asr_pack_args{};
     p.src = band_dg; p.rows = g.Ki; p.cols = g.kt * g.Ko_p; p.ld = g.kt * g.Ko_p;
-    p.absmax = scal + 2; p.scale_out = scal + 11;
-    p.r_hl = ws + w.banddg_pl; p.ldk_r = g.kt * g.Ko_p;
+    p.absmax = scal + 2; p.scale_out = first ? scal + 11 : nullptr;
+    p.r_hl = ws + w.banddg_pl + pl_off; p.ldk_r = g.kt * g.Ko_p;
     rc = asr_pack_hl(&p, stream);
     if (rc) return rc;
   }
   return ASR_OK;
 }
+
+// The block GEMMs of one pass are independent and each fills only part of the chip (125
+// workgroups of the 256 x 256 kernel per block at 64 x 10 s): they are issued on up to three
+// streams -- the caller's and two of the library's own -- between a fork event (everything
+// enqueued so far: packs, band builds) and joins (the caller's stream waits for the others).
+constexpr int kSideStreams = 2;
+hipStream_t side_stream(int i) {
+  static hipStream_t streams[16][kSideStreams] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!streams[dev][i] &&
+      hipStreamCreateWithFlags(&streams[dev][i], hipStreamNonBlocking) != hipSuccess)
+    streams[dev][i] = nullptr;
+  return streams[dev][i];
+}
+
+struct ForkJoin {
+  hipStream_t main;
+  hipStream_t lanes[1 + kSideStreams];
+  bool used[1 + kSideStreams];
+  int n;
+  // after everything enqueued on `stream` so far; n_jobs <= 1 (or no side stream): one lane
+  int fork(hipStream_t stream, int n_jobs) {
+    main = stream; n = 1; lanes[0] = stream; used[0] = true;
+    if (n_jobs > 1)
+      for (int i = 0; i < kSideStreams && n < n_jobs; ++i) {
+        hipStream_t s = side_stream(i);
+        if (s) { lanes[n] = s; used[n] = false; ++n; }
+      }
+    if (n == 1) return ASR_OK;
+    hipEvent_t ev;
+    ASR_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ASR_CHECK_HIP(hipEventRecord(ev, main));
+    for (int i = 1; i < n; ++i) ASR_CHECK_HIP(hipStreamWaitEvent(lanes[i], ev, 0));
+    ASR_CHECK_HIP(hipEventDestroy(ev));
+    return ASR_OK;
+  }
+  hipStream_t lane(int job) { const int i = job % n; used[i] = true; return lanes[i]; }
+  int join() {
+    for (int i = 1; i < n; ++i) {
+      if (!used[i]) continue;
+      hipEvent_t ev;
+      ASR_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      ASR_CHECK_HIP(hipEventRecord(ev, lanes[i]));
+      ASR_CHECK_HIP(hipStreamWaitEvent(main, ev, 0));
+      ASR_CHECK_HIP(hipEventDestroy(ev));
+    }
+    return ASR_OK;
+  }
+};
 
 int pack_x(const Geo& g, const asr_conv2d_args* a, const Ws& w, char* ws, hipStream_t stream) {
   float* scal = reinterpret_cast<float*>(ws + w.scal);
@@ -479,26 +545,39 @@ extern "C" int asr_conv2d_fwd(const asr_conv2d_args* a, void* workspace, size_t 
   float* scal = reinterpret_cast<float*>(ws + w.scal);
   int rc;
   if (!a->reuse_x) { rc = pack_x(g, a, w, ws, stream); if (rc) return rc; }
+  // block b: output columns [fo0 C_out, +Ko_b) of z from input columns [fi0 C_in, +Ki_b) of the
+  // x planes (the whole band when nblk == 1; then Ki_b may be padded up to Ki_p: zero columns).
+  // All bands first (the caller's stream), then the block GEMMs side by side.
+  size_t pl_off[4];
+  size_t off = 0;
   for (int b = 0; b < g.nblk; ++b) {
-    // block b: output columns [fo0 C_out, +Ko_b) of z from input columns [fi0 C_in, +Ki_b) of the
-    // x planes (the whole band when nblk == 1; then Ki_b may be padded up to Ki_p: zero columns)
     const Geo gb = block_geo(g, b);
-    rc = build_band(gb, a, w, ws, true, false, stream);
+    pl_off[b] = off;
+    rc = build_band(gb, a, w, ws, true, false, off, b == 0, stream);
     if (rc) return rc;
+    off += asr_align_up((size_t)gb.Ko * g.kt * gb.Ki_p * 4, 256);
+  }
+  ForkJoin fj;
+  rc = fj.fork(stream, g.nblk);
+  if (rc) return rc;
+  for (int b = 0; b < g.nblk; ++b) {
+    const Geo gb = block_geo(g, b);
     const int kseg = g.nblk == 1 ? g.Ki_p : gb.Ki;
     asr_gemm_hl_args h = {};
     h.M = (int)g.M; h.N = gb.Ko; h.K = g.kt * kseg;
     h.a_hl = ws + w.xpl + (size_t)(g.b_fi0[b] * g.C_in / 16) * 64; h.lda = g.Ki_p;
-    h.b_hl = ws + w.bandf_pl; h.ldb = g.kt * gb.Ki_p;
+    h.b_hl = ws + w.bandf_pl + pl_off[b]; h.ldb = g.kt * gb.Ki_p;
     h.a_scale = scal + 8; h.b_scale = scal + 10;
     h.C = zout + (size_t)g.b_fo0[b] * g.C_out; h.ldc = g.Ko; h.alpha = 1.f; h.beta = 0.f;
     h.bias = reinterpret_cast<float*>(ws + w.bias_band);
     h.clamp_hi = fused ? a->clip : 0.f;
     h.a_seg_k = kseg;
     for (int dt = 0; dt < g.kt; ++dt) h.a_seg_row[dt] = tap_row(g, dt);
-    rc = asr_gemm_hl(&h, nullptr, 0, stream);
+    rc = asr_gemm_hl(&h, nullptr, 0, fj.lane(b));
     if (rc) return rc;
   }
+  rc = fj.join();
+  if (rc) return rc;
   if (fused) {
   } else if (a->clip > 0.f) {
     const size_t n4 = (size_t)g.M * g.Ko / 4;
@@ -527,28 +606,37 @@ extern "C" int asr_conv2d_dgrad(const asr_conv2d_args* a, void* workspace, size_
   int rc;
   if (!a->reuse_dz) { rc = pack_dz(g, a, w, ws, stream); if (rc) return rc; }
   // dx[(t, n)] = sum_dt dz[(t - dt + pt, n)] band[dt]^T: tap dt reads the dz planes
-  // (kt - 1 - dt) frames below their first (zero-padded) frame.  With frequency blocks the
-  // blocks' input ranges overlap: dx is cleared and every block adds its share.
-  if (g.nblk > 1) ASR_CHECK_HIP(hipMemsetAsync(a->dx, 0, (size_t)g.M * g.Ki * 4, stream));
-  for (int b = 0; b < g.nblk; ++b) {
-    const Geo gb = block_geo(g, b);
-    rc = build_band(gb, a, w, ws, false, true, stream);
+  // (kt - 1 - dt) frames below their first (zero-padded) frame.  Row blocks: block b writes
+  // the input frequencies [fi0, fi0 + nfi) of dx from the output frequencies that reach them;
+  // all bands first (the caller's stream), then the block GEMMs side by side.
+  size_t pl_off[8];
+  size_t off = 0;
+  for (int b = 0; b < g.nwblk; ++b) {
+    const Geo gb = wblock_geo(g, b);
+    pl_off[b] = off;
+    rc = build_band(gb, a, w, ws, false, true, off, b == 0, stream);
     if (rc) return rc;
-    const int kseg = g.nblk == 1 ? g.Ko_p : gb.Ko;
+    off += asr_align_up((size_t)gb.Ki * g.kt * gb.Ko_p * 4, 256);
+  }
+  ForkJoin fj;
+  rc = fj.fork(stream, g.nwblk);
+  if (rc) return rc;
+  for (int b = 0; b < g.nwblk; ++b) {
+    const Geo gb = wblock_geo(g, b);
+    const int kseg = g.nwblk == 1 ? g.Ko_p : gb.Ko;
     asr_gemm_hl_args h = {};
     h.M = (int)g.M; h.N = gb.Ki; h.K = g.kt * kseg;
-    h.a_hl = ws + w.dzpl + (size_t)(g.b_fo0[b] * g.C_out / 16) * 64; h.lda = g.Ko_p;
-    h.b_hl = ws + w.banddg_pl; h.ldb = g.kt * gb.Ko_p;
+    h.a_hl = ws + w.dzpl + (size_t)(g.w_fo0[b] * g.C_out / 16) * 64; h.lda = g.Ko_p;
+    h.b_hl = ws + w.banddg_pl + pl_off[b]; h.ldb = g.kt * gb.Ko_p;
     h.a_scale = scal + 9; h.b_scale = scal + 11;
-    h.C = a->dx + (size_t)g.b_fi0[b] * g.C_in; h.ldc = g.Ki; h.alpha = 1.f;
-    h.beta = g.nblk > 1 ? 1.f : 0.f;
+    h.C = a->dx + (size_t)g.w_fi0[b] * g.C_in; h.ldc = g.Ki; h.alpha = 1.f; h.beta = 0.f;
     h.a_seg_k = kseg;
     for (int dt = 0; dt < g.kt; ++dt)
       h.a_seg_row[dt] = (long long)(g.padb - (g.kt - 1 - g.pt) + (g.kt - 1 - dt)) * g.n_pad;
-    rc = asr_gemm_hl(&h, nullptr, 0, stream);
+    rc = asr_gemm_hl(&h, nullptr, 0, fj.lane(b));
     if (rc) return rc;
   }
-  return ASR_OK;
+  return fj.join();
 }
 
 extern "C" int asr_conv2d_wgrad(const asr_conv2d_args* a, void* workspace, size_t ws_bytes,

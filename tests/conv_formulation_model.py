@@ -115,32 +115,32 @@ def wgrad(g, xp, dy, z, clip):
 # ---- frequency blocks (make_geo's nblk / nwblk rules, rect_geo) -------------------------------
 
 def col_blocks(g):
-    """Column blocks of the forward / dgrad GEMMs: [(fi0, nfi, fo0, nfo)]."""
-    nblk = 1
-    for nb in (4, 3, 2):
-        if g.F_out % nb or g.C_in % 32:
-            continue
-        nfo = g.F_out // nb
-        if (nfo * g.C_out) % 32 or nfo * g.C_out < 256:
-            continue
-        if g.sf * (nfo - 1) + g.kf >= g.F_in:
-            continue
-        nblk = nb
-        break
-    if nblk == 1:
-        return [(0, g.F_in, 0, g.F_out)]
-    out = []
-    nfo = g.F_out // nblk
-    for b in range(nblk):
-        fo0 = b * nfo
+    """Column blocks of the forward GEMM (256-column tiles of output frequencies):
+    [(fi0, nfi, fo0, nfo)]."""
+    whole = [(0, g.F_in, 0, g.F_out)]
+    if g.C_in % 32 or g.C_out > 256 or 256 % g.C_out:
+        return whole
+    cb = 256 // g.C_out
+    while -(-g.F_out // cb) > 4:
+        cb *= 2
+    nb = -(-g.F_out // cb)
+    out, cost = [], 0
+    for b in range(nb):
+        fo0 = b * cb
+        nfo = min(cb, g.F_out - fo0)
         lo = max(g.sf * fo0 - g.pf, 0)
         hi = min(g.sf * (fo0 + nfo - 1) - g.pf + g.kf, g.F_in)
+        hi = max(hi, lo + 1)
         out.append((lo, hi - lo, fo0, nfo))
-    return out
+        cost += -(-(nfo * g.C_out) // 256) * (hi - lo)
+    if nb > 1 and cost < -(-g.Ko // 256) * g.F_in:
+        return out
+    return whole
 
 
 def row_blocks(g):
-    """Row blocks of the weight-gradient GEMMs (tile-aligned input-frequency ranges)."""
+    """Row blocks of the dgrad and weight-gradient GEMMs (tile-aligned input-frequency
+    ranges)."""
     whole = [(0, g.F_in, 0, g.F_out)]
     if g.C_in % 32 or g.C_out % 32 or 256 % g.C_in:
         return whole
@@ -191,17 +191,19 @@ def forward_blocks(g, x, W, b, clip):
 
 
 def dgrad_blocks(g, dy, z, W, clip):
+    """asr_conv2d_dgrad with row blocks: block GEMMs on column ranges of the dz planes, each
+    writing its own column range of dx."""
     assert g.st == 1
     dzp, _ = pack_dz(g, dy, z, clip)
     rows = [(g.padb - (g.kt - 1 - g.pt) + (g.kt - 1 - dt)) * g.n_pad for dt in range(g.kt)]
-    dx = np.zeros((g.M, g.Ki))
-    blocks = col_blocks(g)
+    dx = np.full((g.M, g.Ki), np.nan)
+    blocks = row_blocks(g)
     for fi0, nfi, fo0, nfo in blocks:
         gb = rect_geo(g, fi0, nfi, fo0, nfo)
         _, bd = band(gb, W)
         kseg = g.Ko_p if len(blocks) == 1 else gb.Ko
         B = np.concatenate([bd[:, dt * gb.Ko_p:dt * gb.Ko_p + kseg] for dt in range(g.kt)], axis=1)
-        dx[:, fi0 * g.C_in:fi0 * g.C_in + gb.Ki] += seg_gemm(dzp[:, fo0 * g.C_out:], kseg, rows, B, g.M)
+        dx[:, fi0 * g.C_in:fi0 * g.C_in + gb.Ki] = seg_gemm(dzp[:, fo0 * g.C_out:], kseg, rows, B, g.M)
     return dx.reshape(g.T_in, g.n_pad, g.Ki)
 
 

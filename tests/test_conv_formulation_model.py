@@ -37,11 +37,12 @@ def test_gemm_formulation_equals_the_convolution(T, F, Ci, Co, kt, kf, st, sf):
 
 
 @pytest.mark.parametrize('T,F,Ci,Co,kt,kf,st,sf,ncol,nrow', [
-    (7, 24, 32, 48, 3, 9, 1, 2, 2, 1),       # two column blocks (C_out % 32 != 0: no row blocks)
+    (7, 24, 32, 48, 3, 9, 1, 2, 1, 1),       # C_out divides neither 256 nor 32: the whole band
+    (7, 24, 32, 64, 3, 9, 1, 2, 3, 3),       # three column blocks of 4 output frequencies
     (6, 32, 32, 32, 3, 5, 2, 1, 4, 4),       # four column blocks, four row blocks
-    (5, 40, 32, 32, 3, 21, 1, 2, 2, 5),      # the second front-end layer's frequency geometry
+    (5, 40, 32, 32, 3, 21, 1, 2, 3, 5),      # the second front-end layer's frequency geometry
     (9, 8, 4, 4, 5, 5, 1, 2, 1, 1),          # nothing to cut: one block = the whole band
-    (6, 41, 32, 32, 3, 5, 1, 2, 1, 6),       # ragged last row block (one input frequency)
+    (6, 41, 32, 32, 3, 5, 1, 2, 3, 6),       # ragged last blocks (5 output / 1 input frequency)
 ])
 def test_frequency_blocks_cover_the_band(T, F, Ci, Co, kt, kf, st, sf, ncol, nrow):
     """make_geo's column blocks (forward, dgrad) and row blocks (weight gradient): GEMMs on column

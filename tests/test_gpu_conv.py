@@ -72,10 +72,11 @@ CASES = [
     (6, 3, 8, 2, 2, 11, 3, 1, 1, 20.0),        # filter longer than the slab
     (40, 7, 20, 1, 8, 11, 11, 2, 2, 0.0),      # linear output
     (31, 33, 16, 8, 8, 11, 9, 1, 2, 2.0),      # three batch tiles, K per tap = 128
-    (20, 5, 24, 32, 48, 5, 9, 1, 2, 3.0),      # two frequency blocks (C_in % 32 == 0, 288 columns each)
-    (11, 17, 32, 32, 32, 3, 5, 2, 1, 0.0),     # four column blocks, four row blocks (dW), stride (2, 1)
-    (12, 16, 40, 32, 32, 3, 21, 1, 2, 5.0),    # the second front-end layer's frequency geometry: 2 / 5 blocks
-    (6, 16, 41, 32, 32, 3, 5, 1, 2, 0.0),      # six row blocks, the last one a single input frequency
+    (20, 5, 24, 32, 48, 5, 9, 1, 2, 3.0),      # C_out = 48 fits no block rule: the whole band, 576 columns
+    (10, 5, 24, 32, 64, 3, 9, 1, 2, 3.0),      # three column blocks (fwd), three row blocks (dgrad, dW)
+    (11, 17, 32, 32, 32, 3, 5, 2, 1, 0.0),     # four column blocks, four row blocks, stride (2, 1)
+    (12, 16, 40, 32, 32, 3, 21, 1, 2, 5.0),    # the second front-end layer's frequency geometry: 3 / 5 blocks
+    (6, 16, 41, 32, 32, 3, 5, 1, 2, 0.0),      # ragged last blocks: 5 output frequencies / 1 input frequency
 ]
 
 
