@@ -20,15 +20,16 @@
 //     back onto the filter taps.
 // The band is ~kf / F_in dense (21 of 40, 41 of 80 here).  Where the channel counts allow whole
 // slabs at the cuts (C_in % 32 == 0: the second layer) the GEMMs run on FREQUENCY BLOCKS -- the
-// forward and input-gradient GEMMs on 2 column blocks of output frequencies with the input
-// frequencies their filters reach (a column range of the same planes, a 25 % shorter reduction,
-// and one round of the chip per launch), the weight gradient on tile-aligned row blocks of the
-// band (10 tiles per tap instead of 15) -- so the matrix pipes execute 1.4 x (blocks) to 2 x
-// (first layer) the algorithmic flops of the convolution, at the rate of the tuned 256 x 256
-// kernel (bench.py reports the ALGORITHMIC rate).  The clipped ReLU is applied in the epilogue
-// of the forward GEMM (only y is written; the backward mask 0 < z < clip reads the same from y);
-// the bias gradient comes from column sums the dz pack keeps in registers.  All kernels besides
-// the GEMMs are HBM-bound element-wise passes over the activation slabs.
+// forward GEMM on 256-column blocks of output frequencies with the input frequencies their
+// filters reach (a column range of the same planes, a shorter reduction), the input-gradient
+// and weight-gradient GEMMs on tile-aligned row blocks of the band -- and the block launches of a
+// pass, each half a round of the chip, go out side by side on three streams (ForkJoin).  The
+// matrix pipes then execute 1.3 x (blocks) to 2 x (first layer) the algorithmic flops of the
+// convolution, at the rate of the tuned 256 x 256 kernel (bench.py reports the ALGORITHMIC
+// rate).  The clipped ReLU is applied in the epilogue of the forward GEMM (only y is written; the
+// backward mask 0 < z < clip reads the same from y); the bias gradient comes from column sums
+// the dz pack keeps in registers.  All kernels besides the GEMMs are HBM-bound element-wise
+// passes over the activation slabs.
 #include "common.h"
 
 namespace {

@@ -792,8 +792,8 @@ def main():
                         'pass; split-fp16) / time of the whole entry point.  The banded form '
                         'multiplies more than those flops on the matrix pipes: the band of a '
                         'time tap is kf / F_in dense (layer 1: 41 of 80 -> ~2x), cut by the '
-                        'frequency blocks where the channel count allows (layer 2: 21 of 30 '
-                        'per block -> ~1.4x), so the pipes are busier than `frac` says'}
+                        'frequency blocks where the channel count allows (layer 2: ~1.3x), '
+                        'so the pipes are busier than `frac` says'}
         if world == 1 and not args.no_extras:
             if args.config == 'cfg3':
                 line['cfg3_conv'] = _sub_bench('cfg3_conv', {}, args.steps, args.warmup, args.dropout)

@@ -264,6 +264,9 @@ typedef struct asr_conv2d_args {
   const float* x_absmax;         /* device float >= max|x| (the previous layer's    */
                                  /* clip), or NULL: measured with asr_absmax        */
 } asr_conv2d_args;
+/* Streams: the block GEMMs of one forward / dgrad call may be issued on two streams of the   */
+/* library's own beside `stream` (forked behind everything enqueued on it, joined before the   */
+/* call returns): to the caller the call is ordered on `stream` like any other.              */
 /* T_out = ceil(T_in / st), F_out = ceil(F_in / sf). */
 int asr_conv2d_out_shape(const asr_conv2d_args* a, int* T_out, int* F_out);
 size_t asr_conv2d_workspace_bytes(const asr_conv2d_args* a);
