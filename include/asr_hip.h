@@ -500,14 +500,15 @@ int asr_lstm_ln_seq_bwd(const asr_lstm_ln_args* a, void* workspace, size_t ws_by
                         asr_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
-/* C1  Gradient all-reduce (RCCL over xGMI) for hosts without torch.           */
+/* C1  Gradient all-reduce (RCCL over xGMI).                                   */
 /* One communicator per process / GPU: rank 0 calls asr_comm_unique_id and     */
 /* ships the ASR_COMM_ID_BYTES to the other ranks by any side channel; every   */
 /* rank then calls asr_comm_init with the HIP device already selected.         */
 /* asr_comm_allreduce_sum sums n floats over the ranks in place, enqueued on    */
-/* the given stream.  librccl is resolved with dlopen at first use.  (The      */
-/* shipped Python host issues the same collective through torch.distributed,   */
-/* backend "nccl" = RCCL, unless ASR_COMM=capi.)                               */
+/* the given stream.  librccl is resolved with dlopen at first use.  This IS    */
+/* the collective path of the shipped Python host (parallel.CapiComm: gradient  */
+/* all-reduce, parameter broadcast, metric sums); torch.distributed only ships  */
+/* the id bytes.                                                                */
 /* ------------------------------------------------------------------------ */
 #define ASR_COMM_ID_BYTES 128
 typedef void* asr_comm_t;
