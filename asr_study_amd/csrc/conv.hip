@@ -23,7 +23,7 @@
 // forward GEMM on 256-column blocks of output frequencies with the input frequencies their
 // filters reach (a column range of the same planes, a shorter reduction), the input-gradient
 // and weight-gradient GEMMs on tile-aligned row blocks of the band -- and the block launches of a
-// pass, each half a round of the chip, go out side by side on three streams (ForkJoin).  The
+// pass, each half a round of the chip, go out side by side on two or three streams (ForkJoin).  The
 // matrix pipes then execute 1.3 x (blocks) to 2 x (first layer) the algorithmic flops of the
 // convolution, at the rate of the tuned 256 x 256 kernel (bench.py reports the ALGORITHMIC
 // rate).  The clipped ReLU is applied in the epilogue of the forward GEMM (only y is written; the
@@ -437,7 +437,7 @@ int build_band(const Geo& g, const asr_conv2d_args* a, const Ws& w, char* ws, bo
 
 // The block GEMMs of one pass are independent and each fills only part of the chip (125
 // workgroups of the 256 x 256 kernel per block at 64 x 10 s): they are issued on up to three
-// streams -- the caller's and two of the library's own -- between a fork event (everything
+// streams (as many as fill the chip), longest first onto the less loaded one, -- the caller's and two of the library's own -- between a fork event (everything
 // enqueued so far: packs, band builds) and joins (the caller's stream waits for the others).
 constexpr int kSideStreams = 2;
 hipStream_t side_stream(int i) {
@@ -454,15 +454,19 @@ struct ForkJoin {
   hipStream_t main;
   hipStream_t lanes[1 + kSideStreams];
   bool used[1 + kSideStreams];
+  double load[1 + kSideStreams];
   int n;
-  // after everything enqueued on `stream` so far; n_jobs <= 1 (or no side stream): one lane
-  int fork(hipStream_t stream, int n_jobs) {
-    main = stream; n = 1; lanes[0] = stream; used[0] = true;
-    if (n_jobs > 1)
-      for (int i = 0; i < kSideStreams && n < n_jobs; ++i) {
-        hipStream_t s = side_stream(i);
-        if (s) { lanes[n] = s; used[n] = false; ++n; }
-      }
+  // after everything enqueued on `stream` so far.  wgs = workgroups of one job: lanes beyond
+  // what fills the 256 CUs only let a small job grab CUs ahead of a long one (measured: the
+  // 128-column forward block started first and the longest block ran last on half the chip)
+  int fork(hipStream_t stream, int n_jobs, long long wgs) {
+    main = stream; n = 1; lanes[0] = stream; used[0] = true; load[0] = 0.0;
+    int want = wgs > 0 ? (int)(256 / wgs) : 1;
+    if (want > n_jobs) want = n_jobs;
+    for (int i = 0; i < kSideStreams && n < want; ++i) {
+      hipStream_t s = side_stream(i);
+      if (s) { lanes[n] = s; used[n] = false; load[n] = 0.0; ++n; }
+    }
     if (n == 1) return ASR_OK;
     hipEvent_t ev;
     ASR_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -471,7 +475,13 @@ struct ForkJoin {
     ASR_CHECK_HIP(hipEventDestroy(ev));
     return ASR_OK;
   }
-  hipStream_t lane(int job) { const int i = job % n; used[i] = true; return lanes[i]; }
+  // the lane with the least work so far (call with the jobs in descending cost order)
+  hipStream_t lane(double cost) {
+    int best = 0;
+    for (int i = 1; i < n; ++i) if (load[i] < load[best]) best = i;
+    load[best] += cost; used[best] = true;
+    return lanes[best];
+  }
   int join() {
     for (int i = 1; i < n; ++i) {
       if (!used[i]) continue;
@@ -484,6 +494,15 @@ struct ForkJoin {
     return ASR_OK;
   }
 };
+
+// block indices in descending order of (column tiles x reduction length)
+void by_cost(int n, const double* cost, int* order) {
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) {
+      const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+    }
+}
 
 int pack_x(const Geo& g, const asr_conv2d_args* a, const Ws& w, char* ws, hipStream_t stream) {
   float* scal = reinterpret_cast<float*>(ws + w.scal);
@@ -558,10 +577,17 @@ extern "C" int asr_conv2d_fwd(const asr_conv2d_args* a, void* workspace, size_t 
     if (rc) return rc;
     off += asr_align_up((size_t)gb.Ko * g.kt * gb.Ki_p * 4, 256);
   }
+  double cost[4];
+  int order[4];
+  for (int b = 0; b < g.nblk; ++b)
+    cost[b] = (double)((g.b_nfo[b] * g.C_out + 255) / 256) * g.b_nfi[b] *
+              (g.b_nfo[b] * g.C_out >= 256 ? 1.0 : 0.5);      // (a 128-wide block: half tiles)
+  by_cost(g.nblk, cost, order);
   ForkJoin fj;
-  rc = fj.fork(stream, g.nblk);
+  rc = fj.fork(stream, g.nblk, ((g.M + 255) / 256) * ((block_geo(g, 0).Ko + 255) / 256));
   if (rc) return rc;
-  for (int b = 0; b < g.nblk; ++b) {
+  for (int ob = 0; ob < g.nblk; ++ob) {
+    const int b = order[ob];
     const Geo gb = block_geo(g, b);
     const int kseg = g.nblk == 1 ? g.Ki_p : gb.Ki;
     asr_gemm_hl_args h = {};
@@ -574,7 +600,7 @@ extern "C" int asr_conv2d_fwd(const asr_conv2d_args* a, void* workspace, size_t 
     h.clamp_hi = fused ? a->clip : 0.f;
     h.a_seg_k = kseg;
     for (int dt = 0; dt < g.kt; ++dt) h.a_seg_row[dt] = tap_row(g, dt);
-    rc = asr_gemm_hl(&h, nullptr, 0, fj.lane(b));
+    rc = asr_gemm_hl(&h, nullptr, 0, fj.lane(cost[b]));
     if (rc) return rc;
   }
   rc = fj.join();
@@ -619,10 +645,16 @@ extern "C" int asr_conv2d_dgrad(const asr_conv2d_args* a, void* workspace, size_
     if (rc) return rc;
     off += asr_align_up((size_t)gb.Ki * g.kt * gb.Ko_p * 4, 256);
   }
+  double cost[8];
+  int order[8];
+  for (int b = 0; b < g.nwblk; ++b)
+    cost[b] = (double)((g.w_nfi[b] * g.C_in + 255) / 256) * g.w_nfo[b];
+  by_cost(g.nwblk, cost, order);
   ForkJoin fj;
-  rc = fj.fork(stream, g.nwblk);
+  rc = fj.fork(stream, g.nwblk, ((g.M + 255) / 256) * ((wblock_geo(g, 0).Ki + 255) / 256));
   if (rc) return rc;
-  for (int b = 0; b < g.nwblk; ++b) {
+  for (int ob = 0; ob < g.nwblk; ++ob) {
+    const int b = order[ob];
     const Geo gb = wblock_geo(g, b);
     const int kseg = g.nwblk == 1 ? g.Ko_p : gb.Ko;
     asr_gemm_hl_args h = {};
@@ -634,7 +666,7 @@ extern "C" int asr_conv2d_dgrad(const asr_conv2d_args* a, void* workspace, size_
     h.a_seg_k = kseg;
     for (int dt = 0; dt < g.kt; ++dt)
       h.a_seg_row[dt] = (long long)(g.padb - (g.kt - 1 - g.pt) + (g.kt - 1 - dt)) * g.n_pad;
-    rc = asr_gemm_hl(&h, nullptr, 0, fj.lane(b));
+    rc = asr_gemm_hl(&h, nullptr, 0, fj.lane(cost[b]));
     if (rc) return rc;
   }
   return fj.join();
