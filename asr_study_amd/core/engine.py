@@ -148,6 +148,13 @@ class Model(object):
         # (ASR_PIPE_HALVES=0: the pipelined GEMMs wait for whole frames -- comparison switch)
         self._pipe_halves = _os.environ.get('ASR_PIPE_HALVES', '1') != '0'
         self.pipeline = self.overlap and self._pipeline_mode == '1'
+        # ASR_BPTT_COMPACT: auto (default) = where a layer's BPTT would fill every CU (cfg3) it is
+        # launched in the COMPACT geometry (asr_lstm_args.compact: H/32 workgroups per chain,
+        # half the CUs, bit-identical gradients, a longer step) whenever the weight-gradient
+        # GEMMs of the layer above are waiting, and those run beside it on the side stream
+        # instead of behind it; 0 = never (the serial schedule of rounds 1-4), 1 = wherever the
+        # compact kernel exists
+        self._compact_mode = _os.environ.get('ASR_BPTT_COMPACT', 'auto')
         self._pipe = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         # big GEMMs on operands packed once into split-fp16 planes (ops.pack_hl / gemm_hl);
         # ASR_GEMM_PACKED=0 keeps the convert-per-tile kernels, ASR_GEMM_PREC=0 (exact fp32) too
@@ -741,6 +748,24 @@ class Model(object):
         widest = max([(st.Hp + 15) // 16 for st in self.stages if st.kind == 'bilstm'] + [0])
         return 2 * (n_pad // 16) * widest >= self._num_cu
 
+    def _bptt_compact(self, s, n_pad):
+        """True if stage s's BPTT may run in the compact geometry with GEMMs on the CUs it
+        leaves free (plain cell, persistent kernels, H = 256 / 512, at most half of the CUs)."""
+        if self._compact_mode == '0' or self.device.type != 'cuda' or self.lstm_mode != 0:
+            return False
+        if s.kind != 'bilstm' or s.mi is not None or s.ln is not None or s.Hp not in (256, 512):
+            return False
+        if s.zoneout_c > 0 or s.zoneout_h > 0:
+            return False
+        if os.environ.get('ASR_LSTM_PREC', '1') == '0':
+            return False
+        if not hasattr(self, '_num_cu'):
+            self._num_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if self._compact_mode == '1':
+            return True
+        return (self._recurrence_fills_chip(n_pad)
+                and 2 * (n_pad // 16) * (s.Hp // 32) <= self._num_cu // 2)
+
     def _pipeline_on(self, n_pad):
         if not self.overlap or self._pipeline_mode == '0':
             return False
@@ -908,6 +933,11 @@ class Model(object):
                 if reduce_now and rng is not None:
                     reduce_async(rng[0], rng[1], self._side)
 
+        # the side stream is in use if the recurrences leave CUs free by themselves (cfg2) or
+        # are made to (compact BPTT geometry, cfg3)
+        compact_any = any(self._bptt_compact(st, n_pad) for st in self.stages)
+        overlap = self.overlap or compact_any
+        self._compact_launches = 0
         skip_grads = {}        # stage index -> gradient to add to that stage's OUTPUT
         for si in range(len(self.stages) - 1, -1, -1):
             s = self.stages[si]
@@ -925,6 +955,7 @@ class Model(object):
             if s.kind in ('noise', 'reshape'):
                 continue
             if s.kind == 'conv':
+                flush_side()        # (weight gradients of the stack above: beside this layer)
                 op, z = rec['op'], rec['z']
                 nw = s.kt * s.kf * s.C_in * s.C_out
                 da = da.contiguous()
@@ -963,7 +994,7 @@ class Model(object):
                 par = self._dz_parity = 1 - getattr(self, '_dz_parity', 0)
                 dz = self._buf('dz%d' % par, (T, n_pad, 2, 4 * Hp))
                 main = torch.cuda.current_stream(self.device)
-                if self.overlap and self._dz_free[par] is not None:
+                if overlap and self._dz_free[par] is not None:
                     main.wait_event(self._dz_free[par])
                 U = self._view(s.oU, 2 * Hp * 4 * Hp)
                 zmx = self._buf('dzmax%d' % par, (1,))
@@ -1028,9 +1059,13 @@ class Model(object):
                 else:
                     if s.mi is None:
                         var['db_part'] = pgrad[0]
+                    # compact geometry only while there is work to run beside it (the top
+                    # layer's BPTT has none: it keeps the whole chip and the shorter step)
+                    cmp_now = bool(pending) and not self.overlap and self._bptt_compact(s, n_pad)
+                    self._compact_launches += int(cmp_now)
                     rec['ws_b'] = ops.lstm_seq_bwd(
                         da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp, mask_u=BU,
-                        mode=self.lstm_mode, dz_absmax=zmx, **var)
+                        mode=self.lstm_mode, dz_absmax=zmx, compact=cmp_now, **var)
                     flush_side()    # previous layer's dW/dU/db now overlap this BPTT
                 y = rec['y']
                 hl = self._stage_packed(s)
@@ -1136,13 +1171,16 @@ class Model(object):
                     dx = self._buf('da_s%d' % si, (T, n_pad, s.f_in_pad))
                     self._dx_gemm(gsrc, s, dx, BW, 0, rows, n_pad, zmx)
                     da = dx
-                if not self.overlap:
+                if not overlap:
                     weight_grads('gemm')
                     if reduce_now and not first:
                         # no side stream (a recurrence fills the chip): this layer's gradients
                         # are final on the main stream; their all-reduce runs beside the layers
                         # below instead of after them all
                         reduce_async(s.p_lo, s.p_hi, main)
+                elif first and not self.overlap:
+                    # (compact schedule: the tail's GEMMs each fill the chip -- one stream)
+                    weight_grads('gemm')
                 elif first:
                     # nothing left to hide behind: share the tail between both streams
                     ready = torch.cuda.Event()
@@ -1158,7 +1196,7 @@ class Model(object):
                     pending.append((weight_grads, ready, par, (s.p_lo, s.p_hi)))
                     da = dx
         flush_side()
-        if self.overlap and self._side is not None:
+        if overlap and self._side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
         return da
 

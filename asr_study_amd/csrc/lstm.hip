@@ -190,12 +190,17 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       // ASR_LSTM_BWD_2D: 1 = the two-dimensional split (bwd_body_c), 0 = bwd_body_x; default:
       // from H = 512 on, where the partial-tile exchange of bwd_body_x is 1 MB per chain-step
       // (measured at H = 256: 1.89 us per step against 1.60)
-      const bool form_c = wide && env_int("ASR_LSTM_BWD_2D", H >= 512 ? 1 : 0) != 0;
+      // asr_lstm_args.compact: the two-block form of bwd_body_c -- H/32 workgroups per chain,
+      // half as many CUs per layer (the caller overlaps GEMMs on the others)
+      // (ASR_LSTM_COMPACT = 1 / 0 forces / forbids it: measurement and test switch)
+      const bool compact = wide && env_int("ASR_LSTM_COMPACT", a->compact != 0 ? 1 : 0) != 0;
+      const bool form_c = compact || (wide && env_int("ASR_LSTM_BWD_2D", H >= 512 ? 1 : 0) != 0);
       if (form_c) {
         pl.form_c = 1;
         pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 264 * 2);
         pl.xchain_words = (size_t)4 * 4 * (H / 64) * (H / 64) * 256;
-        k = ASR_PICK(asr_lstm_pick_bwd_c(H, false));
+        if (compact) pl.P = H / 32;
+        k = ASR_PICK(asr_lstm_pick_bwd_c(H, false, compact));
       } else if (wide) {
         k = ASR_PICK(asr_lstm_pick_bwd_x(H));
       } else {

@@ -696,15 +696,28 @@ __device__ __forceinline__ void mfma_settle(f32x4& am, f32x4& a1, f32x4& a2) {
   asm volatile("s_nop 13" : "+v"(am), "+v"(a1), "+v"(a2));
 }
 
-template <int OT, bool FAST, bool EXACT>
+//
+// NBLK = 2 (the COMPACT form, asr_lstm_args.compact): two output blocks instead of four, i.e. a
+// workgroup owns H/2 outputs (TW = 4 OT / NBLK output tiles per wave, 256 AGPRs of U^T at
+// H = 512) and a chain is H/32 workgroups -- the layer then occupies HALF as many CUs (128 of 256
+// at cfg3) at twice the MFMAs per step and workgroup; the gate-gradient arithmetic is duplicated
+// twice instead of four times, the gather and the published volume of a chain-step are
+// unchanged.  It exists so that the weight-gradient GEMMs of the layer above can run on the other
+// half of the chip beside the BPTT of this one (engine.backward).  Same exchange layout
+// ([output tile][slice a][256 words]), same products; a (sample, unit)'s partial sums are added
+// in the same order, so the gate gradients are bit-identical to NBLK = 4.
+template <int OT, bool FAST, bool EXACT, int NBLK = 4>
 __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw, float* lds) {
   constexpr int PA = 4 * OT;                       // reduction slices (H / 64)
   constexpr int KS = 8;                            // K-steps of 32 columns per slice
-  constexpr int NTILE = 4 * OT;                    // output tiles of a workgroup
+  constexpr int NTILE = 16 * OT / NBLK;            // output tiles of a workgroup
+  constexpr int TW = NTILE / 4;                    // ... of a wave
+  constexpr int NG = 4 / NBLK;                     // units per thread whose bias partials it keeps
+  static_assert(NBLK == 4 || NBLK == 2, "output blocks per chain");
   constexpr int DZS = 264;                         // LDS row stride of the dz tile (halfs)
   constexpr int DZF = 260;                         // EXACT: row stride of the fp32 dz tile (floats)
   constexpr int kBufFloats = EXACT ? 16 * DZF : 16 + (2 * 16 * DZS) / 2;   // fp32 tile | sinv + hi + lo
-  constexpr int kSlotWords = 4 * NTILE * PA * 256;            // one exchange slot of a chain
+  constexpr int kSlotWords = NBLK * NTILE * PA * 256;         // one exchange slot of a chain
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -718,11 +731,11 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   // nl), i.e. k-index g <-> column 16 c4 + 4 g + e of the slice: the dz tile stays plain fp32 in
   // LDS (no per-sample scale, no split), the U^T fragments are one fp32 register per MFMA.
   constexpr int NM = EXACT ? 64 : 1;               // fp32 MFMAs per output tile
-  float uf[OT][NM];
+  float uf[TW][NM];
   if constexpr (EXACT) {
 #pragma unroll
-    for (int i = 0; i < OT; ++i) {
-      const int orow = 64 * OT * b + 16 * (w + 4 * i) + nl;
+    for (int i = 0; i < TW; ++i) {
+      const int orow = 16 * NTILE * b + 16 * (w + 4 * i) + nl;
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const int j = 256 * a + 16 * (m >> 2) + 4 * g + (m & 3);
@@ -731,11 +744,11 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       }
     }
   }
-  f32x4 ufh[OT][KS], ufl[OT][KS];                  // bit patterns of 8 halfs each (AGPRs)
+  f32x4 ufh[TW][KS], ufl[TW][KS];                  // bit patterns of 8 halfs each (AGPRs)
 #pragma unroll
-  for (int i = 0; i < OT; ++i) {
+  for (int i = 0; i < TW; ++i) {
     if constexpr (EXACT) break;
-    const int orow = 64 * OT * b + 16 * (w + 4 * i) + nl;     // output unit of this lane's A row
+    const int orow = 16 * NTILE * b + 16 * (w + 4 * i) + nl;  // output unit of this lane's A row
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       h8 hv, lv;
@@ -765,7 +778,9 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   // (waited for HERE, once: left pending, the first use inside the loop would be a vmcnt(0) in
   // every iteration -- the compiler cannot know on which entry path they have landed)
   asm volatile("" : "+v"(cmask), "+v"(dc));
-  float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias-gradient partials of unit u0 + b
+  float4 gsum[NG];                                 // bias-gradient partials of units u0 + b + NBLK k
+#pragma unroll
+  for (int k = 0; k < NG; ++k) gsum[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   float zmax = 0.f;
   bool dead = false;
   StepProf prof;
@@ -782,7 +797,7 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   const unsigned vo_dy = (unsigned)(((size_t)cn * H2 + dir * H + u0) * 4);
   const unsigned vo_c = (unsigned)((((size_t)cn * 2 + dir) * H + u0) * 4);
   const unsigned vo_g = (unsigned)((((size_t)cn * 2 + dir) * H4 + 4 * u0) * 4);
-  const unsigned vo_z = (n & 3) == b ? vo_g : 0xC0000000u;   // dz rows: owner lanes only
+  const unsigned vo_z = (n & (NBLK - 1)) == b ? vo_g : 0xC0000000u;   // dz rows: owner lanes only
   // Frame bases of the step being LOADED (ld_*) and of the step being STORED (st_dz) as running
   // pointers: one scalar 64-bit add per slab and step.
   const long long fstep = dir == 0 ? -1 : 1;       // frame increment of a BPTT step
@@ -819,10 +834,10 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   };
 
   // gather: the 16-byte group (sample n, units 4 q ..) of the partial tiles of the PA producers
-  // (a', a / OT), 1 KB apart (immediates of one offset register)
+  // (a', block of these units), 1 KB apart (immediates of one offset register); the slot is
+  // indexed by the GLOBAL output tile 4 a + (q >> 2) = block * NTILE + tile of the block
   constexpr int NL = PA;
-  const unsigned goff = (unsigned)(((((a / OT) * NTILE + 4 * (a % OT) + (q >> 2)) * PA) * 256 +
-                                    n * 16 + (q & 3) * 4) * 4);
+  const unsigned goff = (unsigned)((((4 * a + (q >> 2)) * PA) * 256 + n * 16 + (q & 3) * 4) * 4);
   u32x4 v[NL];
   auto rslot = [&](int ss) -> __amdgpu_buffer_rsrc_t {
     return __builtin_amdgcn_make_buffer_rsrc(xch + (size_t)(ss & 3) * kSlotWords, 0,
@@ -962,10 +977,20 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     }
     }
     // (b is uniform: scalar branches, no indexed access)
-    if (b == 0) { gsum.x += z[0][0]; gsum.y += z[0][1]; gsum.z += z[0][2]; gsum.w += z[0][3]; }
-    else if (b == 1) { gsum.x += z[1][0]; gsum.y += z[1][1]; gsum.z += z[1][2]; gsum.w += z[1][3]; }
-    else if (b == 2) { gsum.x += z[2][0]; gsum.y += z[2][1]; gsum.z += z[2][2]; gsum.w += z[2][3]; }
-    else { gsum.x += z[3][0]; gsum.y += z[3][1]; gsum.z += z[3][2]; gsum.w += z[3][3]; }
+    if constexpr (NBLK == 4) {
+      if (b == 0) { gsum[0].x += z[0][0]; gsum[0].y += z[0][1]; gsum[0].z += z[0][2]; gsum[0].w += z[0][3]; }
+      else if (b == 1) { gsum[0].x += z[1][0]; gsum[0].y += z[1][1]; gsum[0].z += z[1][2]; gsum[0].w += z[1][3]; }
+      else if (b == 2) { gsum[0].x += z[2][0]; gsum[0].y += z[2][1]; gsum[0].z += z[2][2]; gsum[0].w += z[2][3]; }
+      else { gsum[0].x += z[3][0]; gsum[0].y += z[3][1]; gsum[0].z += z[3][2]; gsum[0].w += z[3][3]; }
+    } else {
+      if (b == 0) {
+        gsum[0].x += z[0][0]; gsum[0].y += z[0][1]; gsum[0].z += z[0][2]; gsum[0].w += z[0][3];
+        gsum[1].x += z[2][0]; gsum[1].y += z[2][1]; gsum[1].z += z[2][2]; gsum[1].w += z[2][3];
+      } else {
+        gsum[0].x += z[1][0]; gsum[0].y += z[1][1]; gsum[0].z += z[1][2]; gsum[0].w += z[1][3];
+        gsum[1].x += z[3][0]; gsum[1].y += z[3][1]; gsum[1].z += z[3][2]; gsum[1].w += z[3][3];
+      }
+    }
     // off the dependent path (the other waves are still on their way to the barrier), and ahead
     // of the publish and the gather in the CU's in-order memory queue only by a whole MFMA phase:
     // this workgroup's rows of the dz slab, and the slab values of step s + 2 into the set this
@@ -994,13 +1019,14 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
           xch + (size_t)(s & 3) * kSlotWords, 0, kSlotWords * 4, 0x00020000);
       const unsigned soff = (unsigned)((((b * NTILE + w) * PA + a) * 256 + nl * 16 + 4 * g) * 4);
-      f32x4 acc[OT];
+      static_assert(!EXACT || NBLK == 4, "the exact kernel exists in the four-block form");
+      f32x4 acc[TW];
       // (the OT tiles' accumulator chains interleaved: 32 cycles of pipe per MFMA, 40 of latency)
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const float bw = bq[m >> 2][m & 3];
 #pragma unroll
-        for (int i = 0; i < OT; ++i) {
+        for (int i = 0; i < TW; ++i) {
           if (m == 0)
             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc[i]) : "a"(uf[i][0]), "v"(bw));
           else
@@ -1010,7 +1036,7 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       if constexpr (OT == 2) asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
       else asm volatile("s_nop 15" : "+v"(acc[0]));
 #pragma unroll
-      for (int i = 0; i < OT; ++i) {
+      for (int i = 0; i < TW; ++i) {
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = tag_word(acc[i][e], wtag);
@@ -1040,9 +1066,9 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
         // output tile w + 4 i of this block: 4 PA KB further on
         __builtin_amdgcn_raw_buffer_store_b128(o, wr, soff, i * (4 * PA * 1024), FAST ? 0 : kSc1);
       };
-      f32x4 am[OT], a1[OT], a2[OT];
+      f32x4 am[TW], a1[TW], a2[TW];
 #pragma unroll
-      for (int i = 0; i < OT; ++i) {
+      for (int i = 0; i < TW; ++i) {
         mfma3_first(am[i], a1[i], a2[i], ufh[i][0], ufl[i][0], bh[0], bl[0]);
 #pragma unroll
         for (int kk = 1; kk < KS; ++kk) {
@@ -1057,8 +1083,8 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
           }
         }
       }
-      mfma_settle(am[OT - 1], a1[OT - 1], a2[OT - 1]);
-      finish(OT - 1, am[OT - 1], a1[OT - 1], a2[OT - 1]);
+      mfma_settle(am[TW - 1], a1[TW - 1], a2[TW - 1]);
+      finish(TW - 1, am[TW - 1], a1[TW - 1], a2[TW - 1]);
     }
     if (p.trace && lane == 0 && (unsigned)(s - p.trace_s0) < 16u)
       p.trace[(((size_t)blockIdx.x * 4 + w) * 16 + (s - p.trace_s0)) * 2 + 1] = wall_clock64();
@@ -1109,24 +1135,27 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   if (b == 0)
     *reinterpret_cast<f32x4*>(p.dc_state + ((size_t)dir * p.n_pad + cn) * H + u0) = dc;
   if (p.db_part) {
-    // sum over the 16 samples of every thread's float4 (unit u0 + b), fixed order
-    float vs[4] = {gsum.x, gsum.y, gsum.z, gsum.w};
+    // sum over the 16 samples of every thread's float4 (unit u0 + b + NBLK k), fixed order
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                  // over the wave's four samples (lane >> 4)
-      vs[k] += __shfl_xor(vs[k], 16);
-      vs[k] += __shfl_xor(vs[k], 32);
+    for (int kg = 0; kg < NG; ++kg) {
+      float vs[4] = {gsum[kg].x, gsum[kg].y, gsum[kg].z, gsum[kg].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {                // over the wave's four samples (lane >> 4)
+        vs[k] += __shfl_xor(vs[k], 16);
+        vs[k] += __shfl_xor(vs[k], 32);
+      }
+      __syncthreads();
+      if (lane < 16) *reinterpret_cast<float4*>(lds + (w * 16 + lane) * 4) =
+          make_float4(vs[0], vs[1], vs[2], vs[3]);
+      __syncthreads();
+      if (tid < 64) {                              // (unit quad tid >> 2, gate tid & 3)
+        const float tsum = ((lds[tid] + lds[64 + tid]) + lds[128 + tid]) + lds[192 + tid];
+        float* dst = p.db_part + ((size_t)bt * 2 + dir) * H4 + 256 * a + 16 * (tid >> 2) +
+                     4 * (b + NBLK * kg) + (tid & 3);
+        *dst = (p.s_begin > 0 ? *dst : 0.f) + tsum;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (lane < 16) *reinterpret_cast<float4*>(lds + (w * 16 + lane) * 4) =
-        make_float4(vs[0], vs[1], vs[2], vs[3]);
-    __syncthreads();
-    if (tid < 64) {                                // (unit quad tid >> 2, gate tid & 3)
-      const float tsum = ((lds[tid] + lds[64 + tid]) + lds[128 + tid]) + lds[192 + tid];
-      float* dst = p.db_part + ((size_t)bt * 2 + dir) * H4 + 256 * a + 16 * (tid >> 2) + 4 * b +
-                   (tid & 3);
-      *dst = (p.s_begin > 0 ? *dst : 0.f) + tsum;
-    }
-    __syncthreads();
   }
   if (p.dz_absmax && b == 0) {
     zmax = asr_wave_max(zmax);
@@ -1134,7 +1163,7 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   }
 }
 
-template <int OT, bool EXACT>
+template <int OT, bool EXACT, int NBLK = 4>
 __global__ void __launch_bounds__(kThreads)
 lstm_bwd_kernel_c(LstmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1142,8 +1171,8 @@ lstm_bwd_kernel_c(LstmParams p) {
   if (!map_block(p, unit_local, cw)) return;
   const int unit = p.chain_begin + unit_local;
   const bool fast = chain_on_one_xcd(p, unit, cw, reinterpret_cast<int*>(lds));
-  if (fast) bwd_body_c<OT, true, EXACT>(p, unit, cw, lds);
-  else bwd_body_c<OT, false, EXACT>(p, unit, cw, lds);
+  if (fast) bwd_body_c<OT, true, EXACT, NBLK>(p, unit, cw, lds);
+  else bwd_body_c<OT, false, EXACT, NBLK>(p, unit, cw, lds);
 }
 
 
@@ -1161,7 +1190,9 @@ asr_lstm_kern_t asr_lstm_pick_bwd_h(int tpw, bool variants) {
 asr_lstm_kern_t asr_lstm_pick_bwd_x(int H) {
   return H == 256 ? ASR_KERN(lstm_bwd_kernel_x<4>) : ASR_KERN(lstm_bwd_kernel_x<8>);
 }
-asr_lstm_kern_t asr_lstm_pick_bwd_c(int H, bool exact) {
+asr_lstm_kern_t asr_lstm_pick_bwd_c(int H, bool exact, bool compact) {
+  if (compact && !exact)
+    return H == 256 ? ASR_KERN((lstm_bwd_kernel_c<1, false, 2>)) : ASR_KERN((lstm_bwd_kernel_c<2, false, 2>));
   if (H == 256) return exact ? ASR_KERN((lstm_bwd_kernel_c<1, true>)) : ASR_KERN((lstm_bwd_kernel_c<1, false>));
   return exact ? ASR_KERN((lstm_bwd_kernel_c<2, true>)) : ASR_KERN((lstm_bwd_kernel_c<2, false>));
 }

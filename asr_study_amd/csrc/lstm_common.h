@@ -270,4 +270,4 @@ asr_lstm_kern_t asr_lstm_pick_fwd_x(int H, bool exact, bool slab = false);   // 
 asr_lstm_kern_t asr_lstm_pick_fwd_n1(int H);                      // one utterance, H = 256 / 512
 asr_lstm_kern_t asr_lstm_pick_bwd_h(int tpw, bool variants);
 asr_lstm_kern_t asr_lstm_pick_bwd_x(int H);                       // unit split, H = 256 / 512
-asr_lstm_kern_t asr_lstm_pick_bwd_c(int H, bool exact);           // two-dimensional split
+asr_lstm_kern_t asr_lstm_pick_bwd_c(int H, bool exact, bool compact = false);   // two-dimensional split

@@ -225,15 +225,17 @@ def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=
 
 def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check=False,
                  dz_absmax=None, steps=None, mi=None, uh=None, zone_c=None, zone_h=None,
-                 wx=None, dwx=None, dmi=None, db_part=None):
+                 wx=None, dwx=None, dmi=None, db_part=None, compact=False):
     """db_part: optional (n_pad/16, 2, 4H) buffer receiving the per-batch-tile sums of dz over
-    samples and steps (bias-gradient partials; accumulated across the slices of a sequence)."""
+    samples and steps (bias-gradient partials; accumulated across the slices of a sequence).
+    compact: H/32 workgroups per chain (half the CUs per layer, asr_lstm_args.compact)."""
     lib = L.load()
     _check_f32(dy, U, cell, gates, dz, mask_u)
     a = _lstm_args(T, n_pad, H, U, mask_u, cell=cell, gates=gates, dy=dy, dz=dz, mode=mode,
                    dz_absmax=dz_absmax, steps=steps, mi=mi, uh=uh, zone_c=zone_c,
                    zone_h=zone_h, wx=wx, dwx=dwx, dmi=dmi, db_part=db_part)
     a.lds_reserve_kb = LSTM_LDS_KB
+    a.compact = 1 if compact else 0
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 1)
     ws = WS.get('lstm_bwd', nbytes, dy.device)
     L.check(lib.asr_lstm_seq_bwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_bwd')

@@ -351,6 +351,13 @@ typedef struct asr_lstm_args {
   /* to half of the CUs (asr_stream_create_cu_mask): the recurrence is latency-bound, so two */
   /* chains interleave on one CU while the other half of the chip runs GEMMs.                */
   int lds_reserve_kb;
+  /* backward, optional: 1 = the COMPACT launch geometry of the plain cell at H = 256 / 512   */
+  /* in persistent mode: a chain is H/32 workgroups instead of H/16 (each owns twice the      */
+  /* outputs), so a layer occupies half as many CUs (128 of 256 at H = 512, 64 utterances) at */
+  /* a longer step; the caller runs the weight-gradient GEMMs of the layer above on the CUs   */
+  /* left free.  Gate gradients are bit-identical to the default geometry.  Ignored where the */
+  /* compact kernel does not exist (other H, cell variants, stepwise mode, forward).          */
+  int compact;
 } asr_lstm_args;
 size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
 int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,

@@ -448,6 +448,66 @@ def test_bptt_two_dimensional_split_matches_the_one_dimensional_kernel(N, H, mon
                                float(np.abs(got - again).max()))
 
 
+@pytest.mark.parametrize('N,H', [(64, 512), (16, 512), (32, 256), (48, 256)])
+def test_bptt_compact_geometry_is_bit_identical_to_the_default_two_dimensional_split(N, H, monkeypatch):
+    """asr_lstm_args.compact (lstm_bwd_kernel_c<.., NBLK = 2>: two output blocks, H/32 workgroups
+    per chain, half the CUs per layer -- what engine.backward launches beside the weight-gradient
+    GEMMs of the layer above) against the four-block form on the same activations: every
+    (sample, unit)'s products and their summation order are the same, so dz, max|dz| and the
+    bias-gradient partials must agree BIT FOR BIT; sliced == whole, both transports; the plan
+    reports half the workgroups."""
+    from asr_study_amd import ops
+    import ctypes as C
+    from asr_study_amd import _lib as L
+    T = 47
+    rs = np.random.RandomState(5 * H + N)
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.1).astype(np.float32)).to(dev)
+    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
+    y = torch.zeros(T, n_pad, 2 * H, device=dev)
+    cell = torch.zeros(T, n_pad, 2, H, device=dev)
+    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    ops.lstm_status(ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask))
+    monkeypatch.setenv('ASR_LSTM_BWD_2D', '1')
+
+    def run(ranges, compact):
+        dz = torch.full((T, n_pad, 2, 4 * H), 7.0, device=dev)
+        dbp = torch.full((n_pad // 16, 2, 4 * H), 9.0, device=dev)
+        amax = torch.zeros(1, device=dev)
+        for r in ranges:
+            ws = ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=mask,
+                                  dz_absmax=amax, steps=r, db_part=dbp, compact=compact)
+        ops.lstm_status(ws)
+        return dz.cpu().numpy(), dbp.cpu().numpy(), amax.cpu().numpy()
+    want, dbw, amw = run([None], False)
+    got, dbg, amg = run([None], True)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, ('compact != default', len(bad), bad[:4].tolist(),
+                           float(np.abs(got - want).max()))
+    assert np.array_equal(dbg, dbw) and amg[0] == amw[0]
+    sliced, dbs, ams = run([(0, 1), (1, 2), (3, 17), (20, 27)], True)
+    assert np.array_equal(sliced, got) and ams[0] == amg[0]
+    assert np.abs(dbs - dbg).max() <= 2e-6 * max(1.0, np.abs(dbg).max())
+    for transport in ('0', '1'):
+        monkeypatch.setenv('ASR_LSTM_FAST', transport)
+        again, _, _ = run([None], True)
+        assert np.array_equal(again, got), transport
+    # the plan: half the workgroups per chain
+    a = L.LstmArgs()
+    a.T, a.n_pad, a.H = T, n_pad, H
+    blocks, cpl = C.c_int(), C.c_int()
+    out = []
+    for c in (0, 1):
+        a.compact = c
+        L.check(L.load().asr_lstm_plan(C.byref(a), 1, None, None, C.byref(blocks), C.byref(cpl)),
+                'asr_lstm_plan')
+        out.append(blocks.value // max(1, cpl.value))
+    assert out == [H // 16, H // 32], out
+
+
 @pytest.mark.parametrize('N,H', [(32, 256), (64, 512), (16, 512)])
 def test_exact_fp32_kernels_at_the_benchmarked_widths(N, H, monkeypatch):
     """ASR_LSTM_PREC=0 at H = 256 / 512: the structure of the split-fp16 kernels (forward: K split
