@@ -92,5 +92,28 @@ def _compile(verbose):
         f.write(_source_hash() + '\n')
 
 
+def toolchain_probe(workdir=None):
+    """Compile TWO small sources of the library (capi.cpp + random.hip, a few seconds) with THIS
+    machine's hipcc into a scratch directory and link them into libasr_probe.so; returns its
+    path.  The shipped libasr_hip.so is normally reused as built (its source hash matches), so
+    a GPU box never runs hipcc on its own: __graft_entry__.smoke() and one -m gpu test load this
+    probe next to the shipped library and compare their Philox streams bit for bit -- a
+    toolchain / runtime skew on the box shows up as a red test, not as a silently reused
+    binary."""
+    import tempfile
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    workdir = workdir or tempfile.mkdtemp(prefix='asr_probe_')
+    objs = []
+    for src in ('capi.cpp', 'random.hip'):
+        obj = os.path.join(workdir, os.path.splitext(src)[0] + '.o')
+        subprocess.check_call([hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC',
+                               '-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj])
+        objs.append(obj)
+    lib = os.path.join(workdir, 'libasr_probe.so')
+    subprocess.check_call([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + objs +
+                          ['-lpthread', '-ldl'])
+    return lib
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))

@@ -217,6 +217,18 @@ class Model(object):
                                      'got %d (padded %d)' % (s.F_in * s.C_in, f_real, f_pad))
                 if (s.F_out * s.C_out) % 4:
                     raise ValueError('conv stage: F_out * C_out must be a multiple of 4')
+                # limits of asr_conv2d_* (csrc/conv.hip), checked when the model is BUILT rather
+                # than at the first launch / the first backward pass:
+                if not 1 <= s.kt <= 16:
+                    raise ValueError('conv stage: kernel length over time %d not in 1..16 '
+                                     '(asr_conv2d_* keeps one plane shift per time tap)' % s.kt)
+                if s.st < 1 or s.sf < 1:
+                    raise ValueError('conv stage: strides must be >= 1')
+                if s.st > 1 and any(p.kind in ('dense', 'bilstm', 'conv') for p in self.stages):
+                    raise ValueError(
+                        'conv stage with time stride %d behind a trainable stage: asr_conv2d_dgrad '
+                        'exists for time stride 1 only, so a time-strided convolution must be the '
+                        'FIRST trainable stage (its input is data and needs no gradient)' % s.st)
                 nw = s.kt * s.kf * s.C_in * s.C_out
                 s.oW = take(nw)
                 s.ob = take(s.C_out)

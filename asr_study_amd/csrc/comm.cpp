@@ -1,10 +1,12 @@
 // C1  Gradient all-reduce over RCCL behind the C ABI (asr_comm_*).
 //
-// The data-parallel step of the product issues its collective through torch.distributed
-// (backend "nccl" = RCCL); these entry points give a host WITHOUT torch the same collective:
-// one communicator per process / GPU, sum of a float buffer in place, on the caller's
-// stream.  RCCL is resolved at first use with dlopen -- the library links against the HIP
-// runtime only, and inside a torch process the already loaded librccl is reused -- so
+// THE collective path of the product: the data-parallel step (asr_study_amd/parallel.py,
+// CapiComm) reduces gradients, broadcasts parameters (sum of a zeroed staging copy) and sums
+// metrics through these entry points on the communicator's own stream; torch.distributed only
+// ferries the 128-byte unique id between the ranks (and stays available as a fallback behind
+// ASR_COMM=torch).  One communicator per process / GPU, sum of a float buffer in place, on the
+// caller's stream.  RCCL is resolved at first use with dlopen -- the library links against the
+// HIP runtime only, and inside a torch process the already loaded librccl is reused -- so
 // nothing changes for callers that never touch asr_comm_*.
 #include "common.h"
 

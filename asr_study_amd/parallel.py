@@ -11,7 +11,9 @@ with ONE fp32 all-reduce over the model's flat gradient buffer (27.7 MB at cfg2,
 sum IS the gradient of the global batch mean; clip + Adam then run replicated.
 The collective itself is issued through the library's own C ABI (``asr_comm_*``: RCCL
 resolved with dlopen); ``torch.distributed`` only ferries the communicator's 128-byte id
-(and serves the CPU tests over gloo).
+(and serves the CPU tests over gloo).  Fallback: ``ASR_COMM=torch``, or a failed probe of the
+library's RCCL entry points on ANY rank (agreed through the process group before the
+communicator is created), routes the same calls through ``torch.distributed``.
 """
 import os
 
@@ -69,32 +71,57 @@ def allreduce_sum_(flat):
 
 
 def broadcast_parameters(model, src=0):
-    """Every rank starts from rank `src`'s weights: the others zero theirs and the flat buffer
-    is summed (exact: x + 0 + ...) through the gradient communicator."""
+    """Every rank starts from rank `src`'s weights.  A STAGING copy is summed through the
+    gradient communicator (rank `src` contributes its weights, the others zeros: exact, x + 0 +
+    ...) and copied over the parameters only once the collective has been enqueued without an
+    error -- a failing all-reduce leaves every rank's own weights untouched."""
     if world_size() > 1:
-        if dist.get_rank() != src:
-            model.params.zero_()
-        allreduce_sum_(model.params)
+        stage = model.params.clone() if dist.get_rank() == src else torch.zeros_like(model.params)
+        allreduce_sum_(stage)
+        model.params.copy_(stage)
+
+
+_COUNT_LIMB = 4096.0
+
+
+def encode_metrics(vals, count):
+    """float64 metric sums + integer sample count -> the float32 vector that rides the gradient
+    communicator: [hi parts, lo parts, count % 4096, count // 4096]."""
+    vals = torch.as_tensor(vals, dtype=torch.float64)
+    hi = vals.float()
+    c = float(int(count))
+    limbs = torch.tensor([c % _COUNT_LIMB, float(int(c) // int(_COUNT_LIMB))], dtype=torch.float32)
+    return torch.cat([hi, (vals - hi.double()).float(), limbs])
+
+
+def decode_metrics(pair, k):
+    """The summed vector of encode_metrics -> (float64 sums (k,), exact sample count)."""
+    pair = pair.double()
+    return pair[:k] + pair[k:2 * k], float(pair[2 * k] + _COUNT_LIMB * pair[2 * k + 1])
 
 
 def reduce_metrics(sums, count):
     """Sum (metric_sums, sample_count) over ranks -> global batch-weighted means.  On the GPU
-    the sums travel through the gradient communicator as float32 (hi, lo) pairs (48 significant
-    bits), so torch.distributed carries nothing but the communicator's 128-byte id."""
-    t = torch.tensor(list(sums) + [float(count)], dtype=torch.float64)
+    the values travel through the gradient communicator (float32 only): each metric sum as a
+    float32 (hi, lo) pair -- RCCL adds the hi parts across ranks in float32, so the global sum
+    carries float32 accuracy (2^-24 relative per addition), not 48 bits; the SAMPLE COUNT as two
+    integer limbs (count % 4096, count // 4096) whose cross-rank sums stay below 2^24 and are
+    therefore exact for counts up to 2^36 / world.  torch.distributed carries nothing but the
+    communicator's 128-byte id."""
+    vals = torch.tensor(list(sums), dtype=torch.float64)
     if world_size() > 1:
         if torch.cuda.is_available() and dist.get_backend() == 'nccl':
             dev = torch.device('cuda', torch.cuda.current_device())
-            hi = t.float()
-            pair = torch.cat([hi, (t - hi.double()).float()]).to(dev)
+            pair = encode_metrics(vals, count).to(dev)
             comm = grad_comm(dev)
             comm.allreduce_after(pair, torch.cuda.current_stream(dev))
             comm.join(torch.cuda.current_stream(dev))
-            pair = pair.cpu().double()
-            t = pair[:t.numel()] + pair[t.numel():]
+            vals, count = decode_metrics(pair.cpu(), vals.numel())
         else:
+            t = torch.cat([vals, torch.tensor([float(count)], dtype=torch.float64)])
             dist.all_reduce(t)
-    return (t[:-1] / max(float(t[-1]), 1.0)).tolist()
+            vals, count = t[:-1], float(t[-1])
+    return (vals / max(float(count), 1.0)).tolist()
 
 
 class ShardedBatch(list):
@@ -142,12 +169,90 @@ class ShardedFlow(object):
     next = __next__
 
 
+_gpu_comm_kind = [None]         # 'capi' | 'torch', decided once per process, the same on every rank
+
+
+def _decide_gpu_comm(device):
+    """ASR_COMM=torch forces the torch.distributed path; otherwise every rank probes the
+    library's RCCL entry points (dlopen of librccl + ncclGetUniqueId) and the ranks AGREE on the
+    outcome through the process group (MIN of the flags) before any of them enters the collective
+    ncclCommInitRank -- a rank whose dlopen failed would otherwise leave the others hanging in
+    it.  Any failure -> every rank uses TorchDistComm (a warning says so)."""
+    if os.environ.get('ASR_COMM', 'capi') == 'torch':
+        return 'torch'
+    ok = 1
+    try:
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_char * 128)()
+        ok = 1 if _lib.load().asr_comm_unique_id(buf) == 0 else 0
+    except Exception:
+        ok = 0
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([ok], dtype=torch.int32,
+                         device=device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    if not ok:
+        import warnings
+        warnings.warn('asr_comm_* (RCCL behind the C ABI) is unavailable on at least one rank: '
+                      'the gradient all-reduce falls back to torch.distributed on every rank')
+    return 'capi' if ok else 'torch'
+
+
 def grad_comm(device):
-    """The communicator the gradient all-reduce goes through: ONE path per kind of memory --
-    CapiComm (asr_comm_*: RCCL behind the C ABI) for tensors in HBM, HostGroupComm (the host
-    process group, gloo) for CPU tensors, which only the CPU tests have."""
+    """The communicator the gradient all-reduce goes through: CapiComm (asr_comm_*: RCCL behind
+    the C ABI, the product's path) for tensors in HBM -- TorchDistComm (the process group's own
+    RCCL communicator) if ASR_COMM=torch or the library's entry points fail their probe on any
+    rank -- and HostGroupComm (the host process group, gloo) for CPU tensors, which only the CPU
+    tests have."""
     device = torch.device(device)
-    return CapiComm.get() if device.type == 'cuda' else HostGroupComm.get()
+    if device.type != 'cuda':
+        return HostGroupComm.get()
+    if _gpu_comm_kind[0] is None:
+        _gpu_comm_kind[0] = _decide_gpu_comm(device)
+    return CapiComm.get() if _gpu_comm_kind[0] == 'capi' else TorchDistComm.get()
+
+
+class TorchDistComm(object):
+    """Fallback (ASR_COMM=torch, or asr_comm_* unavailable): the same interface on
+    torch.distributed's RCCL communicator, collectives on this object's own stream."""
+
+    _instance = None
+
+    @classmethod
+    def get(cls):
+        if cls._instance is None:
+            cls._instance = cls()
+        return cls._instance
+
+    def __init__(self):
+        self.world = world_size()
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.calls = 0
+
+    def allreduce_after(self, flat, after=None):
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        after = after or torch.cuda.current_stream(flat.device)
+        self.stream.wait_stream(after)
+        flat.record_stream(self.stream)
+        if self.world > 1:
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(flat)
+        self.calls += 1
+        return flat
+
+    def join(self, stream=None):
+        (stream or torch.cuda.current_stream(self.device)).wait_stream(self.stream)
+
+    def allreduce_sum_(self, flat):
+        self.allreduce_after(flat, None)
+        self.join(None)
+        return flat
+
+    def close(self):
+        TorchDistComm._instance = None
 
 
 class HostGroupComm(object):

@@ -42,6 +42,11 @@ CONFIGS = {
     # BASELINE.json configs[1]: brsmv1 defaults, batch 32
     'cfg2': dict(model='brsmv1', F=39, H=256, L=5, C=28, N=32, feat='mfcc',
                  desc='brsmv1 5xBiLSTM(256), MFCC-39, 28-class CTC, batch 32 x 10 s @16 kHz'),
+    # the same topology at a batch that fills the chip (16 chains x 16 workgroups = 256 CUs;
+    # cfg2's own batch of 32 occupies 64): the `cfg2_n128` sub-object of the line
+    'cfg2_n128': dict(model='brsmv1', F=39, H=256, L=5, C=28, N=128, feat='mfcc',
+                      desc='brsmv1 5xBiLSTM(256), MFCC-39, 28-class CTC, batch 128 x 10 s @16 kHz '
+                           '(configs[1] topology, chip-filling batch)'),
     # BASELINE.json configs[2]: 5xBiLSTM(512), 80-dim log-mel, batch 64 (the conv
     # front-end named there does not exist in the reference, SURVEY.md 8: not built)
     'cfg3': dict(model='brsmv1', F=80, H=512, L=5, C=28, N=64, feat='logfbank80',
@@ -147,7 +152,7 @@ def cpu_baseline(cfg):
     # a bounded share of its batch.  The per-timestep matmuls are small (N x 2H @ 2H x 4H), where
     # more BLAS threads are not faster: a short calibration (T = 24 frames) picks the thread
     # count and, from its time per frame, the largest N in {16, 8, 4} whose full-length step is
-    # estimated under ~30 s; then ONE full-length step is timed after a short warm-up.
+    # estimated under ~30 s; then ONE full-length step is timed after a warm-up step at T = 99.
     ncpu = os.cpu_count() or 1
     try:
         import threadpoolctl
@@ -172,6 +177,10 @@ def cpu_baseline(cfg):
     secs = 10.0
     ctx = threadpoolctl.threadpool_limits(best_thr) if threadpoolctl else None
     try:
+        # warm-up: one step of the SAME topology and batch on 1 s utterances (T = 99: BLAS thread
+        # pool at best_thr, allocator, weights in cache; a tenth of the timed step), then ONE
+        # full-length step is timed
+        train_step_fn(cfg['F'], cfg['H'], cfg['L'], cfg['C'], n, 1.0, kind, kw)()
         step = train_step_fn(cfg['F'], cfg['H'], cfg['L'], cfg['C'], n, secs, kind, kw)
         t0 = time.time()
         step()
@@ -180,7 +189,7 @@ def cpu_baseline(cfg):
         if ctx is not None:
             ctx.restore_original_limits()
     out = {'value': round(n * secs / dt, 2), 'unit': 'audio-seconds/s', 'cores': int(ncpu),
-           'blas_threads': int(best_thr), 'kind': 'port',
+           'blas_threads': int(best_thr), 'kind': 'port', 'utterances': int(n),
            'calibration_s_per_24_frames': {str(k): round(v, 3) for k, v in calib.items()},
            'sample': '%d utterances x %.0f s (T=999: the benchmark\'s full length, %d of its %d '
                      'utterances), same topology, ONE step of %.1f s: NumPy/BLAS float32 oracle '
@@ -210,7 +219,7 @@ def cpu_baseline(cfg):
     # (3) cfg1: 26-dim MFCC, 1 x BiLSTM(100), batch 4 x 10 s (the reference's CPU-runnable case)
     dt2, reps2 = timed(train_step_fn(26, 100, 1, 28, 4, 10.0, 'mfcc', {'dd': False}), 2.0, 10.0)
     out['cfg1_step'] = {'value': round(40.0 / dt2, 2), 'unit': 'audio-seconds/s',
-                        'cores': int(threads),
+                        'cores': int(ncpu), 'blas_threads': int(threads),
                         'sample': 'cfg1: 4 x 10 s, 1xBiLSTM(100), %d step(s) of %.2f s' % (reps2, dt2)}
     return out
 
@@ -356,7 +365,8 @@ def _sub_bench(config, env_extra, steps, warmup, dropout):
         keep[k] = {kk: d[k].get(kk) for kk in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
                                                'us_per_timestep', 'avg_launch_ms', 'traffic',
                                                'algorithmic_fp32_tflops', 'ms_per_step',
-                                               'per_role_ms', 'per_role_algorithmic_tflops')
+                                               'per_role_ms', 'per_role_algorithmic_tflops', 'geometry',
+                                               'overlapped')
                    if kk in d[k]}
     keep['roofline_gate_gemm'] = {kk: d['roofline_gate_gemm'].get(kk) for kk in
                                   ('kernel', 'achieved', 'peak', 'unit', 'frac',
@@ -441,6 +451,9 @@ def main():
 
     lstm_ev = {'lstm_seq_fwd': [], 'lstm_seq_bwd': [], 'gemm_hl': [], 'gemm': []}
     conv_ev = []           # (event, event, algorithmic flops, role) of the asr_conv2d_* calls
+    gemm_side = {}         # id(start event) -> launched on the side stream (beside a compact BPTT)
+    compact_ev = []        # BPTT launches in the compact geometry (asr_lstm_args.compact)
+    main_stream = torch.cuda.current_stream(dev)
 
     def _timed_conv(role):
         orig = getattr(ops.Conv2d, role)
@@ -469,10 +482,14 @@ def main():
             if name.startswith('gemm'):
                 # positional (A, B, C, M, N, K): algorithmic flops of the launch
                 lstm_ev[name].append((e0, e1, 2.0 * a[3] * a[4] * a[5]))
+                # launches on the engine's side stream share the chip with a compact BPTT
+                gemm_side[id(e0)] = torch.cuda.current_stream(dev) != main_stream
             else:
                 # a layer's recurrence may be launched in slices (asr_lstm_args.step_count)
                 steps = k.get('steps')
                 lstm_ev[name].append((e0, e1, int(steps[1]) if steps else None))
+                if k.get('compact'):
+                    compact_ev.append((e0, e1))
             return r
         return orig, timed
 
@@ -651,6 +668,15 @@ def main():
             steps = float(sum(T if n is None else n for _, _, n in ev))
             return tot / len(ev), tot, steps        # ms per launch, total ms, total steps
         fwd_t, bwd_t = lstm_times('lstm_seq_fwd'), lstm_times('lstm_seq_bwd')
+        cmp_ids = {id(a) for a, _ in compact_ev}
+        bwd_cmp = [(a, b, n) for a, b, n in lstm_ev['lstm_seq_bwd'] if id(a) in cmp_ids]
+        bwd_def = [(a, b, n) for a, b, n in lstm_ev['lstm_seq_bwd'] if id(a) not in cmp_ids]
+
+        def us_step(evs):
+            if not evs:
+                return None
+            return round(sum(a.elapsed_time(b) for a, b, _ in evs) * 1e3 /
+                         sum(T if n is None else n for _, _, n in evs), 3)
         # dominant kernels: the persistent recurrent kernels (one launch per layer and
         # pass, both directions).  Algorithmic flops per launch = 2*T*n_pad*2 dirs*H*4H
         # (h@U forward, dz@U^T in BPTT); algorithmic HBM bytes per launch:
@@ -702,12 +728,20 @@ def main():
 
         def gemm_roof():
             # every big GEMM of the step (x@W, dz@W^T, x^T dz, h^T dz, Dense), timed in place
-            ev = lstm_ev['gemm_hl'] + lstm_ev['gemm']
-            if not ev:
+            ev_all = lstm_ev['gemm_hl'] + lstm_ev['gemm']
+            if not ev_all:
                 return None
+            # Launches on the side stream run on the CUs a compact BPTT leaves free (128 of 256
+            # at cfg3) or queue behind it: their durations are wall time on a SHARED chip and say
+            # nothing about the kernel -- the family's roofline is taken over the launches that
+            # have the chip to themselves (main stream); the others are listed under `overlapped`
+            ev = [e for e in ev_all if not gemm_side.get(id(e[0]))]
+            ev_side = [e for e in ev_all if gemm_side.get(id(e[0]))]
             exact = os.environ.get('ASR_GEMM_PREC', '1') == '0'
             tot = float(sum(a.elapsed_time(b) for a, b, _ in ev))
             fl = float(sum(f for _, _, f in ev))
+            tot_s = float(sum(a.elapsed_time(b) for a, b, _ in ev_side))
+            fl_s = float(sum(f for _, _, f in ev_side))
             mult, peak = (1, PEAK_F32_MFMA_TFLOPS) if exact else (3, PEAK_F16_MFMA_TFLOPS)
             ach = mult * fl / (tot * 1e-3) / 1e12
             packed = len(lstm_ev['gemm_hl']) > 0
@@ -722,14 +756,25 @@ def main():
                     'avg_launch_ms': round(tot / len(ev), 4),
                     'ms_per_step': round(tot / args.steps, 3),
                     'algorithmic_tflop_per_step': round(fl / args.steps / 1e12, 3),
+                    'overlapped': None if not ev_side else {
+                        'launches_per_step': round(len(ev_side) / float(args.steps), 1),
+                        'stream_ms_per_step': round(tot_s / args.steps, 3),
+                        'algorithmic_tflop_per_step': round(fl_s / args.steps / 1e12, 3),
+                        'executed_tflops_while_sharing': round(mult * fl_s / (tot_s * 1e-3) / 1e12, 2),
+                        'note': 'weight-gradient GEMMs (K-major) on the side stream, beside the '
+                                'compact BPTT of the layer below (which holds half of the CUs): '
+                                'event durations on a shared chip, off the critical path; NOT in '
+                                'achieved / frac / ms_per_step above.  All launches together: '
+                                '%.2f TFLOP/s executed over the summed durations' % (
+                                    mult * (fl + fl_s) / ((tot + tot_s) * 1e-3) / 1e12)},
                     'note': 'achieved = executed MFMA flop/s (split-fp16: 3 fp16 MFMAs per fp32 '
                             'product) summed over the launches, vs the dense fp16 MFMA peak at '
                             '2.4 GHz.  The kernel runs at the 1400 W package power cap: the chip '
                             'holds 1.95-2.0 GHz under it (1.75-1.8 with 32x32x16 MFMAs, which is '
                             'why the tile is built from 16x16x32), where pure 16x16x32 MFMAs on '
                             'random operands sustain 2.0 PF/s (tools/clock_probe.py, '
-                            'tools/micro/mfma_power.hip, DESIGN.md 6); PMC: MFMA pipes 58 % busy '
-                            '(profiles/r3z_pmc_step_cfg3.md)'}
+                            'tools/micro/mfma_power.hip, DESIGN.md 6); PMC: MFMA pipes 54 % '
+                            '(row-major) / 70 % (K-major) busy (profiles/r4z_pmc_step_cfg3.md)'}
         line = {
             'metric': 'audio-seconds/sec trained (MFCC+BiLSTM+CTC)',
             'value': round(value, 1), 'unit': 'audio-seconds/s', 'n_gpus': world,
@@ -743,6 +788,11 @@ def main():
                            'ASR_GEMM_PREC=0 selects exact fp32 MFMA (see exact_fp32)')
             if split else 'exact fp32 MFMA everywhere',
             'config': {'workload': '%s: %s' % (args.config, cfg['desc']),
+                       'baseline_config': {
+                           'cfg3': 'configs[2] minus its conv front-end (BASELINE.md 3 / north-star '
+                                   'targets); as written -> as_written / cfg3_conv',
+                           'cfg3_conv': 'configs[2] as written',
+                           'cfg2': 'configs[1]'}.get(args.config, args.config),
                        'global_batch': world * N, 'utterance_seconds': 10.0, 'frames': T,
                        'dropout': args.dropout, 'optimizer': 'adam(clipnorm=400)',
                        'parallelism': 'dp%d' % world, 'params': model.count_params()},
@@ -751,6 +801,16 @@ def main():
             'roofline_lstm_fwd': roof('fwd', fwd_t, '%s (persistent forward recurrence of one '
                                                      'BiLSTM layer)' % _rec_kernel_name(H, False)),
         }
+        if bwd_cmp:
+            line['roofline']['geometry'] = {
+                'compact_launches_per_step': round(len(bwd_cmp) / float(args.steps), 2),
+                'compact_us_per_timestep': us_step(bwd_cmp),
+                'default_launches_per_step': round(len(bwd_def) / float(args.steps), 2),
+                'default_us_per_timestep': us_step(bwd_def),
+                'note': 'compact = lstm_bwd_kernel_c<.., NBLK = 2>: H/32 workgroups per chain, half '
+                        'of the CUs, with the weight-gradient GEMMs of the layer above on the other '
+                        'half (wall time per step INCLUDES that sharing); default = the layer with '
+                        'nothing to run beside it (the top one) on the whole chip'}
         line.update(extra)
         line['allreduce_model']['ring_share_of_step'] = round(
             line['allreduce_model']['ring_8gpu_ms'] / ms, 4)
@@ -797,7 +857,18 @@ def main():
         if world == 1 and not args.no_extras:
             if args.config == 'cfg3':
                 line['cfg3_conv'] = _sub_bench('cfg3_conv', {}, args.steps, args.warmup, args.dropout)
+                # BASELINE.json configs[2] AS WRITTEN ("5xBiLSTM(512) + 2 conv front-end"): the
+                # headline stays the stack without it (the north-star targets' configuration,
+                # twice the recurrent steps per audio second, continuous since round 1)
+                line['as_written'] = {
+                    k: line['cfg3_conv'].get(k) for k in ('value', 'unit', 'ms_per_step', 'workload')}
+                line['as_written']['note'] = ('BASELINE.json configs[2] as written; the headline '
+                                              '`value` is the same stack WITHOUT the conv front-end')
             line['cfg2'] = _sub_bench('cfg2', {}, args.steps, args.warmup, args.dropout)
+            # the reference's default topology is bounded by its batch of 32 (a quarter of the
+            # CUs for 85 % of the step): the same model at a batch that fills the chip
+            line['cfg2_n128'] = _sub_bench('cfg2_n128', {}, max(5, args.steps // 2), args.warmup,
+                                           args.dropout)
             line['exact_fp32'] = _sub_bench(args.config, {'ASR_LSTM_PREC': '0', 'ASR_GEMM_PREC': '0'},
                                             max(3, args.steps // 2), 2, args.dropout)
             try:

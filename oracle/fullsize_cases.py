@@ -46,6 +46,12 @@ CASES = {
     'cfg3_conv_n16': dict(F=80, H=512, L=5, C=28, N=16, feat=('logfbank', {'num_filt': 80}),
                           ragged=False, masks=False,
                           conv=[(32, 11, 41, 2, 2, 20.0), (32, 11, 21, 1, 2, 20.0)]),
+    # ... and at FULL size (64 x 10 s), generated like 'cfg3': four 16-utterance oracle slices,
+    # gradients added (rows stay independent through the convolutions: 'same' padding over time
+    # and frequency only, tests/test_gpu_conv.py checks it bit for bit on both layers and dgrad)
+    'cfg3_conv': dict(F=80, H=512, L=5, C=28, N=64, feat=('logfbank', {'num_filt': 80}),
+                      ragged=False, masks=False, slices=4,
+                      conv=[(32, 11, 41, 2, 2, 20.0), (32, 11, 21, 1, 2, 20.0)]),
 }
 LOGIT_FRAMES = 50          # frames (spread over T) whose logits a fixture keeps
 GRAD_SAMPLES = 1000        # sampled entries per gradient tensor

@@ -405,3 +405,20 @@ def test_lr_callbacks_and_optimizer_decay():
     finally:
         ops_mod.grad_norm, ops_mod.optim_guard, ops_mod.adam_step = orig
     assert seen == [1.0, 1.0 / 1.5, 1.0 / 2.0]
+
+
+def test_conv_stage_limits_are_checked_when_the_model_is_built(monkeypatch):
+    """asr_conv2d_dgrad exists for time stride 1 only and the kernels keep at most 16 time taps:
+    a model that would fail at its first backward pass (a time-strided convolution behind
+    another trainable stage) or at its first launch (kt > 16) is refused by the factory with a
+    ValueError instead; the shipped geometry builds."""
+    from asr_study_amd.core import engine, models
+    monkeypatch.setattr(engine, 'DEFAULT_DEVICE', 'cpu')
+    kw = dict(num_features=16, num_classes=5, num_hiddens=8, num_layers=1, conv_filters=4,
+              dropout=0.0)
+    m = models.deep_speech2(conv_kernels=((3, 5), (3, 3)), conv_strides=((2, 2), (1, 2)), **kw)
+    assert list(m.time_strides) == [2] and m.out_frames(9) == 5
+    with pytest.raises(ValueError, match='time stride'):
+        models.deep_speech2(conv_kernels=((3, 5), (3, 3)), conv_strides=((1, 2), (2, 2)), **kw)
+    with pytest.raises(ValueError, match='1..16'):
+        models.deep_speech2(conv_kernels=((17, 5), (3, 3)), conv_strides=((2, 2), (1, 2)), **kw)

@@ -233,6 +233,64 @@ def test_conv_rows_are_independent_and_the_op_is_linear_at_full_size():
     assert (sb - gb).abs().max().item() < 2e-5 * gb.abs().max().item()
 
 
+def test_conv_layer2_and_dgrad_rows_are_independent_at_full_size():
+    """The SECOND layer of cfg3's front-end (32 -> 32 channels, 11 x 21 / (1, 2) on the T' = 500 x
+    40-frequency slab the first one leaves) at N = 64: forward AND dgrad of the batch equal those
+    of its 16-row slices, wgrad is additive over the slices.  Not bit for bit as for layer 1:
+    the reduction here is 11 x 21 x 32 deep and the GEMM's split-K factor is chosen from the
+    number of output tiles, which differs between 32000 and 8000 rows -- another summation order
+    of the same products; the bound is 2e-6 of the largest output (fp32 accumulation noise), three
+    orders below anything a cross-row leak would produce.  This is what lets
+    oracle/gen_golden_model.py build the full-size cfg3_conv fixture from four 16-utterance
+    oracle slices."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(6)
+    T, F, Ci, Co = 500, 40, 32, 32
+    x = torch.from_numpy((rs.rand(T, 64, F * Ci) * 2.0).astype(np.float32)).to(dev())
+    W = torch.from_numpy((rs.randn(11, 21, Ci, Co) * 0.02).astype(np.float32)).to(dev())
+    b = torch.from_numpy((rs.randn(Co) * 0.1).astype(np.float32)).to(dev())
+    op = ops.Conv2d(T, 64, F, Ci, Co, 11, 21, 1, 2, 20.0, dev())
+    z = torch.empty(op.T_out, 64, op.F_out * Co, device=dev())
+    y = torch.empty_like(z)
+    op.fwd(x, W, b, z, y)
+    dy = torch.from_numpy((rs.randn(*y.shape) * 1e-3).astype(np.float32)).to(dev())
+    dx = torch.empty_like(x)
+    op.dgrad(dy, z, W, dx)
+    gW, gb = torch.zeros_like(W), torch.zeros_like(b)
+    op.wgrad(x, dy, z, gW, gb, reuse_x=True, reuse_dz=True)
+    sW, sb = torch.zeros_like(W), torch.zeros_like(b)
+    op16 = ops.Conv2d(T, 16, F, Ci, Co, 11, 21, 1, 2, 20.0, dev())
+    for k in range(4):
+        sl = slice(16 * k, 16 * k + 16)
+        xs = x[:, sl].contiguous()
+        zs = torch.empty(op.T_out, 16, op.F_out * Co, device=dev())
+        ys = torch.empty_like(zs)
+        op16.fwd(xs, W, b, zs, ys)
+        assert (ys - y[:, sl]).abs().max().item() <= 2e-6 * y.abs().max().item(), k
+        dxs = torch.empty_like(xs)
+        op16.dgrad(dy[:, sl].contiguous(), zs, W, dxs)
+        assert (dxs - dx[:, sl]).abs().max().item() <= 2e-6 * dx.abs().max().item(), k
+        # a leak between rows would show at the scale of the outputs: perturb ONE other row's
+        # input and gradient -- this slice must not move at all
+        if k == 0:
+            x2, dy2 = x.clone(), dy.clone()
+            x2[:, 37] *= 0.5                # (no new maximum: the operands' scales stay put)
+            dy2[:, 37] *= -0.5
+            z2, y2, dx2 = torch.empty_like(z), torch.empty_like(y), torch.empty_like(dx)
+            op.fwd(x2, W, b, z2, y2)
+            op.dgrad(dy2, z2, W, dx2)
+            keep = [i for i in range(64) if i != 37]
+            assert torch.equal(y2[:, keep], y[:, keep]) and torch.equal(dx2[:, keep], dx[:, keep])
+            op.fwd(x, W, b, z, y)           # (restore the op's packed planes of x for wgrad below)
+            op.dgrad(dy, z, W, dx)
+        tW, tb = torch.zeros_like(W), torch.zeros_like(b)
+        op16.wgrad(xs, dy[:, sl].contiguous(), zs, tW, tb, reuse_x=True, reuse_dz=True)
+        sW += tW
+        sb += tb
+    assert (sW - gW).abs().max().item() < 2e-5 * gW.abs().max().item()
+    assert (sb - gb).abs().max().item() < 2e-5 * gb.abs().max().item()
+
+
 def test_conv_front_end_at_cfg3_geometry_vs_fixture():
     """Both layers at BASELINE configs[2]'s geometry (T = 999, 80 features, 32 x 11 x 41 / (2, 2)
     and 32 x 11 x 21 / (1, 2), clip 20) on a 16-utterance slice, against the float64 oracle's

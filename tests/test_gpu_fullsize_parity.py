@@ -171,12 +171,20 @@ from oracle import fullsize_cases as FC
 from oracle import lstm as OL
 from asr_study_amd import ops
 from asr_study_amd.core import models
-case = FC.build("cfg3")
+case = FC.build(os.environ["ASR_CASE"])
 cfg, T = case["cfg"], case["T"]
 N, F, H, L, C = cfg["N"], cfg["F"], cfg["H"], cfg["L"], cfg["C"]
 dev = torch.device("cuda:0")
-model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L, dropout=0.0,
-                      weight_decay=0.0, seed=1, device=dev)
+if cfg.get("conv"):
+    model = models.deep_speech2(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
+                                conv_filters=cfg["conv"][0][0],
+                                conv_kernels=[c[1:3] for c in cfg["conv"]],
+                                conv_strides=[c[3:5] for c in cfg["conv"]],
+                                max_value=cfg["conv"][0][5], dropout=0.0, weight_decay=0.0,
+                                seed=1, device=dev)
+else:
+    model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L, dropout=0.0,
+                          weight_decay=0.0, seed=1, device=dev)
 model.set_weights([a for _, a in OL.flatten(case["params"])])
 slab = torch.zeros((T, ops.pad16(N), F), dtype=torch.float32, device=dev)
 slab[:, :N] = torch.from_numpy(case["x"]).to(dev)
@@ -190,8 +198,11 @@ np.savez(os.environ["ASR_DUMP"], ctc=ctc.cpu().numpy(), logits=logits[:, :N].cpu
 
 
 @pytest.mark.timeout(900)
-def test_cfg3_split_fp16_vs_exact_fp32_over_every_gradient_element(tmp_path):
-    """The headline arithmetic (fp32 operands as fp16 hi + lo, lo*lo dropped, ONE power-of-two
+@pytest.mark.parametrize('case_name', ['cfg3', 'cfg3_conv'])
+def test_cfg3_split_fp16_vs_exact_fp32_over_every_gradient_element(tmp_path, case_name):
+    """(cfg3_conv: the same stack behind its 2-conv front-end, configs[2] as written -- the
+    convolutions' dW / db included, over every element.)
+    The headline arithmetic (fp32 operands as fp16 hi + lo, lo*lo dropped, ONE power-of-two
     scale per GEMM operand tensor) against the exact-fp32 MFMA path at FULL cfg3 size (5 x
     BiLSTM(512), 64 x 999 frames), over EVERY element of every gradient tensor, the logits and
     the losses -- not samples.  Bounds:
@@ -203,14 +214,14 @@ def test_cfg3_split_fp16_vs_exact_fp32_over_every_gradient_element(tmp_path):
     dumps = {}
     for tag, env_extra in (('split', {}), ('exact', {'ASR_LSTM_PREC': '0', 'ASR_GEMM_PREC': '0'})):
         path = str(tmp_path / (tag + '.npz'))
-        env = dict(os.environ, ASR_ROOT=ROOT, ASR_DUMP=path, **env_extra)
+        env = dict(os.environ, ASR_ROOT=ROOT, ASR_DUMP=path, ASR_CASE=case_name, **env_extra)
         out = subprocess.run([sys.executable, '-c', _GRAD_DUMP], env=env, cwd=ROOT,
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420,
                              stdin=subprocess.DEVNULL)
         assert out.returncode == 0, out.stdout.decode()[-3000:]
         dumps[tag] = np.load(path)
     a, b = dumps['split'], dumps['exact']
-    assert report('cfg3 logits split vs exact (all)', a['logits'], b['logits']) < 2e-5
+    assert report(case_name + ' logits split vs exact (all)', a['logits'], b['logits']) < 2e-5
     np.testing.assert_allclose(a['ctc'], b['ctc'], rtol=2e-6)
     keys = sorted(k for k in a.files if k.startswith('g'))
     worst_abs = worst_rel = worst_p999 = 0.0
@@ -221,15 +232,15 @@ def test_cfg3_split_fp16_vs_exact_fp32_over_every_gradient_element(tmp_path):
         big = np.abs(gb) > 1e-6 * m
         rel = err[big] / np.abs(gb[big])
         p999 = float(np.percentile(rel, 99.9)) if rel.size else 0.0
-        print('[parity] cfg3 %s: n=%d max|g|=%.3e abs err %.2e x max; entries > 1e-6 max: %d, '
+        print('[parity] %s %s: n=%d max|g|=%.3e abs err %.2e x max; entries > 1e-6 max: %d, '
               'rel err worst %.2e, p99.9 %.2e, median %.2e'
-              % (k, ga.size, m, err.max() / m, int(big.sum()), rel.max() if rel.size else 0.0,
+              % (case_name, k, ga.size, m, err.max() / m, int(big.sum()), rel.max() if rel.size else 0.0,
                  p999, float(np.median(rel)) if rel.size else 0.0))
         worst_abs = max(worst_abs, err.max() / m)
         worst_rel = max(worst_rel, rel.max() if rel.size else 0.0)
         worst_p999 = max(worst_p999, p999)
-    print('[parity] cfg3 split-fp16 vs exact fp32, all %d tensors: worst abs %.2e x max|g|, worst '
+    print('[parity] %s split-fp16 vs exact fp32, all %d tensors: worst abs %.2e x max|g|, worst '
           'relative (entries > 1e-6 max) %.2e, worst p99.9 relative %.2e'
-          % (len(keys), worst_abs, worst_rel, worst_p999))
+          % (case_name, len(keys), worst_abs, worst_rel, worst_p999))
     assert worst_abs < 1e-5
     assert worst_p999 < 1e-2 and worst_rel < 1.0

@@ -171,3 +171,102 @@ def test_engine_allreduce_covers_every_gradient_exactly_once(tmp_path):
     got = np.load(out)
     np.testing.assert_array_equal(got[:-1], np.arange(1000, dtype=np.float32) * 3.0)
     assert got[-1] == 2
+
+
+def _w8_problem(N):
+    from oracle import lstm as OL
+    rs = np.random.RandomState(40 + N)
+    T, F, H, C = 9, 4, 3, 5
+    params = OL.init_model(seed=3, num_features=F, num_hiddens=H, num_layers=1, num_classes=C,
+                           dtype=np.float64)
+    for _, a in OL.flatten(params):
+        a += rs.randn(*a.shape) * 0.2
+    x = rs.randn(T, N, F)
+    lens = rs.randint(4, T + 1, size=N)
+    lens[0] = T
+    for n in range(N):
+        x[lens[n]:, n] = 0
+    labels = [rs.randint(0, C - 1, size=rs.randint(1, 3)).tolist() for _ in range(N)]
+    return params, x, labels, lens
+
+
+def _w8_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import types
+    from asr_study_amd import parallel
+    from asr_study_amd.core import engine
+    from oracle import lstm as OL
+    from oracle import ctc as OC
+    torch.set_num_threads(1)
+    parallel.init_from_env(backend='gloo')
+    result = {}
+    # (1) parameters: every rank starts elsewhere, rank 0's weights win -- through a staging copy
+    mdl = types.SimpleNamespace(params=torch.arange(37, dtype=torch.float32) * (rank + 1) + rank)
+    parallel.broadcast_parameters(mdl, src=0)
+    assert torch.equal(mdl.params, torch.arange(37, dtype=torch.float32))
+    for N, bad_rank in ((11, None), (5, 5)):        # 11: shards of 2,2,2,1,..; 5 < world: dummies
+        params, x, labels, lens = _w8_problem(N)
+        keep = np.arange(N)[rank::world]            # ShardedFlow's rule on a sorted batch
+        n_local = len(keep)
+        if n_local == 0:
+            keep = np.arange(N)[:1]                 # zero-weight dummy (sample 0)
+        xs = x[:, keep]
+        logits, caches = OL.model_forward(params, xs)
+        ctc, dlog = OC.ctc_loss_grad(logits, [labels[i] for i in keep], lens[keep])
+        scale = (1.0 / N) if n_local else 0.0       # engine: grad_scale = 1/n_global, 0 for a dummy
+        grads = OL.model_backward(params, caches, dlog * scale)
+        flat = np.concatenate([g.ravel() for _, g in OL.flatten(grads)])
+        n = flat.size
+        gbuf = torch.zeros(n + 4, dtype=torch.float64)
+        gbuf[:n] = torch.from_numpy(flat)
+
+        def collect(gbuf=gbuf, n=n, bad=bad_rank):      # rank `bad`'s forward kernel timed out
+            gbuf[n:] = torch.tensor([1.0 if rank == bad else 0.0, 0.0, 0.0, 0.0],
+                                    dtype=torch.float64)
+        fake = types.SimpleNamespace(n_params=n, _gbuf=gbuf, grads=gbuf[:n],
+                                     _collect_flags=collect, _dist_active=lambda: True,
+                                     _ar_covered=[])
+        w = engine.Model._allreduce(fake)
+        assert w == world
+        flags = engine.Model.veto_flags(fake).tolist()
+        assert flags == ([1.0, 0.0] if bad_rank is not None else [0.0, 0.0]), flags
+        # (2) metrics: the float32 (hi, lo) + count-limb vector the GPU path sends, summed by the
+        # process group in float32 exactly as RCCL would, then the plain float64 path
+        loss_sum = float(np.sum(ctc)) if n_local else 0.0
+        big = 3000000 + rank                        # a sample count beyond 2^24 / world in total
+        vec = parallel.encode_metrics([loss_sum, 1e6 * (rank + 1) + 0.123], big)
+        assert vec.dtype == torch.float32
+        dist.all_reduce(vec)
+        vals, cnt = parallel.decode_metrics(vec, 2)
+        means = parallel.reduce_metrics([loss_sum], n_local)
+        result[N] = dict(grad=gbuf[:n].numpy().copy(), mean=means[0], cnt=cnt,
+                         loss_pair=float(vals[0]), big_pair=float(vals[1]))
+    if rank == 0:
+        np.save(out, result, allow_pickle=True)
+    parallel.finalize()
+
+
+@pytest.mark.timeout(300)
+def test_world_8_bookkeeping_uneven_shards_dummy_ranks_veto_and_metric_pairs(tmp_path):
+    """SURVEY 8e at the world size the driver will launch (8 ranks, gloo / HostGroupComm on the
+    CPU): a global batch of 11 (shards of 2,2,2,1,1,1,1,1) and one of 5 (< world: three ranks
+    carry a zero-weight dummy and still join every collective); sum of the 1/N_global-scaled
+    shard gradients == the whole-batch gradient; a timeout flag raised on ONE rank reaches all;
+    parameters broadcast through a staging copy; metric sums as float32 (hi, lo) pairs to
+    float32 accuracy and the sample count EXACT through its limbs beyond 2^24."""
+    from oracle import lstm as OL
+    out = str(tmp_path / 'w8.npy')
+    port = _free_port()
+    mp.spawn(_w8_worker, args=(8, port, out), nprocs=8, join=True)
+    got = np.load(out, allow_pickle=True).item()
+    for N in (11, 5):
+        params, x, labels, lens = _w8_problem(N)
+        want = OL.loss_and_grads(params, x, labels, lens)
+        ref = np.concatenate([g.ravel() for _, g in OL.flatten(want['grads'])])
+        np.testing.assert_allclose(got[N]['grad'], ref, atol=1e-12)
+        assert abs(got[N]['mean'] - float(np.mean(want['ctc']))) < 1e-12
+        assert got[N]['cnt'] == sum(3000000 + r for r in range(8))          # exact, > 2^24
+        assert abs(got[N]['loss_pair'] - float(np.sum(want['ctc']))) < 1e-5 * float(np.sum(want['ctc']))
+        tot = sum(1e6 * (r + 1) + 0.123 for r in range(8))
+        assert abs(got[N]['big_pair'] - tot) < 4e-7 * tot
