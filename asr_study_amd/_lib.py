@@ -43,7 +43,8 @@ class PackArgs(C.Structure):
                 ('mask', void_p), ('mask_period', C.c_int), ('mask_ld', C.c_int),
                 ('absmax', void_p), ('scale_out', void_p),
                 ('r_hl', void_p), ('ldk_r', C.c_int),
-                ('c_hl', void_p), ('ldk_c', C.c_int)]
+                ('c_hl', void_p), ('ldk_c', C.c_int),
+                ('mask2', void_p), ('r2_hl', void_p)]
 
 
 class GemmHlArgs(C.Structure):

@@ -514,13 +514,15 @@ class Model(object):
         planes: x@W reduces over their columns, dW = x^T dz over their rows (asr_gemm_hl's
         k_major form reads them transposed out of LDS -- no second orientation is packed).
         One entry per direction when masks are on, else one shared entry."""
-        out = []
-        for d in range(2 if BW is not None else 1):
-            r = self._planes('ar%d_%d' % (si, d), rows, s.f_in_pad)
-            ops.pack_hl(a, rows, s.f_in_pad, mask=None if BW is None else BW[d],
-                        mask_period=n_pad, absmax=amax, r=r)
-            out.append(r)
-        return out
+        r0 = self._planes('ar%d_0' % si, rows, s.f_in_pad)
+        if BW is None:
+            ops.pack_hl(a, rows, s.f_in_pad, absmax=amax, r=r0)
+            return [r0]
+        # both directions' planes in ONE pass over the slab (the source is read once)
+        r1 = self._planes('ar%d_1' % si, rows, s.f_in_pad)
+        ops.pack_hl(a, rows, s.f_in_pad, mask=BW[0], mask_period=n_pad, absmax=amax, r=r0,
+                    mask2=BW[1], r2=r1)
+        return [r0, r1]
 
     def _gate_gemm_hl(self, s, si, pa, zx, rows):
         """zx = (a (.) B_W) @ W + b from packed planes (both directions in one GEMM without

@@ -884,13 +884,17 @@ __global__ void __launch_bounds__(256)
 pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
                const float* __restrict__ mask, int mask_period, int mask_ld,
                const float* __restrict__ absmax, float* __restrict__ scale_out,
-               _Float16* __restrict__ r_hl, int ldk_r, _Float16* __restrict__ c_hl, int ldk_c) {
+               _Float16* __restrict__ r_hl, int ldk_r, _Float16* __restrict__ c_hl, int ldk_c,
+               const float* __restrict__ mask2, _Float16* __restrict__ r2_hl) {
   // one 16 KB image per output that is asked for (dynamic LDS: a row-only pack keeps 10
-  // workgroups on a CU)
+  // workgroups on a CU).  mask2 / r2_hl: a SECOND set of row planes of the same source under
+  // another mask (the two directions' variational-dropout masks of a BiLSTM input): the source
+  // is read once for both (asr_pack_args.mask2).
   extern __shared__ __attribute__((aligned(16))) _Float16 pack_lds[];
   typedef _Float16 (*Image)[128];
   Image rimg = reinterpret_cast<Image>(pack_lds);
   Image cimg = reinterpret_cast<Image>(pack_lds + (r_hl ? 64 * 128 : 0));
+  Image rimg2 = reinterpret_cast<Image>(pack_lds + ((r_hl ? 1 : 0) + (c_hl ? 1 : 0)) * 64 * 128);
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -911,12 +915,33 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] = q[e];
       }
+      if (r2_hl) {                              // second row image: the source under mask2
+        float w[4] = {v[0], v[1], v[2], v[3]};
+        const float* m2 = mask2 + (size_t)mod_period(r, mask_period) * mask_ld + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (c + e < cols) w[e] *= m2[e];
+        hx4 h2, l2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = w[e] * s;
+          const _Float16 h = (_Float16)x;
+          h2[e] = h;
+          l2[e] = (_Float16)(x - (float)h);
+        }
+        _Float16* q = &rimg2[4 * ty + i][(tx >> 2) * 32 + (tx & 3) * 4];
+        *reinterpret_cast<hx4*>(q) = h2;
+        *reinterpret_cast<hx4*>(q + 16) = l2;
+      }
       if (mask) {
         // (n_pad is a multiple of 16, not necessarily a power of two: 48, 80, 96 ...)
         const float* m = mask + (size_t)mod_period(r, mask_period) * mask_ld + c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] *= m[e];
       }
+    } else if (r2_hl) {
+      _Float16* q = &rimg2[4 * ty + i][(tx >> 2) * 32 + (tx & 3) * 4];
+      *reinterpret_cast<hx4*>(q) = hx4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      *reinterpret_cast<hx4*>(q + 16) = hx4{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -953,6 +978,9 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
     if (r_hl && r0 + rr < rows && c0 + k0 < ldk_r)       // (columns in [cols, ldk_r): zeros)
       *reinterpret_cast<hx8*>(r_hl + hl_index(r0 + rr, c0 + k0, ldk_r) + (j & 3) * 8) =
           *reinterpret_cast<const hx8*>(&rimg[rr][j * 8]);
+    if (r2_hl && r0 + rr < rows && c0 + k0 < ldk_r)
+      *reinterpret_cast<hx8*>(r2_hl + hl_index(r0 + rr, c0 + k0, ldk_r) + (j & 3) * 8) =
+          *reinterpret_cast<const hx8*>(&rimg2[rr][j * 8]);
     if (c_hl && c0 + rr < cols && r0 + k0 < ldk_c) {     // (rows in [rows, ldk_c): zeros)
       const int f = ((2 * (rr >> 2)) & 14) | (rr >> 5);
       hx8 v = *reinterpret_cast<const hx8*>(&cimg[rr][(j ^ (f >> 1)) * 8]);
@@ -1702,12 +1730,17 @@ extern "C" int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream_) {
   if (a->mask)
     ASR_CHECK_ARG(a->mask_period > 0 && a->mask_ld >= a->cols,
                   "pack_hl: a mask needs a positive row period and mask_ld >= cols");
+  if (a->r2_hl)
+    ASR_CHECK_ARG(a->r_hl && a->mask && a->mask2 && aligned16(a->r2_hl),
+                  "pack_hl: the second row planes need r_hl, mask and mask2 (same period / ld)");
   dim3 grid((a->cols + 63) / 64, (a->rows + 63) / 64);
-  const size_t pack_shm = (size_t)((a->r_hl ? 1 : 0) + (a->c_hl ? 1 : 0)) * 64 * 128 * sizeof(_Float16);
+  const size_t pack_shm = (size_t)((a->r_hl ? 1 : 0) + (a->c_hl ? 1 : 0) + (a->r2_hl ? 1 : 0)) *
+                          64 * 128 * sizeof(_Float16);
   hipLaunchKernelGGL(pack_hl_kernel, grid, dim3(256), pack_shm, stream, a->src, a->rows, a->cols, a->ld,
                      a->mask, a->mask ? a->mask_period : 1, a->mask_ld, a->absmax, a->scale_out,
                      reinterpret_cast<_Float16*>(a->r_hl), a->ldk_r,
-                     reinterpret_cast<_Float16*>(a->c_hl), a->ldk_c);
+                     reinterpret_cast<_Float16*>(a->c_hl), a->ldk_c,
+                     a->r2_hl ? a->mask2 : nullptr, reinterpret_cast<_Float16*>(a->r2_hl));
   ASR_CHECK_LAUNCH();
   return ASR_OK;
 }

@@ -598,9 +598,11 @@ class HlPlanes(object):
 
 
 def pack_hl(src, rows, cols, ld=None, src_off=0, mask=None, mask_period=0, absmax=None,
-            r=None, c=None):
+            r=None, c=None, mask2=None, r2=None):
     """src (rows, cols) float32 (row stride ld, element offset src_off) [* mask[(row % period)]]
-    -> r planes (rows, cols as K) and / or c planes (cols, rows as K); both get the same scale."""
+    -> r planes (rows, cols as K) and / or c planes (cols, rows as K); both get the same scale.
+    mask2 / r2: a second set of row planes of the same source under another mask, written in the
+    same pass (the source is read once)."""
     lib = L.load()
     a = L.PackArgs()
     a.src = src.data_ptr() + 4 * int(src_off)
@@ -617,7 +619,13 @@ def pack_hl(src, rows, cols, ld=None, src_off=0, mask=None, mask_period=0, absma
     if c is not None:
         assert c.rows >= cols and c.k == rows
         a.c_hl, a.ldk_c = c.hl.data_ptr(), c.ld
+    if r2 is not None:
+        assert r is not None and mask is not None and mask2 is not None
+        assert r2.rows >= rows and r2.k == cols and mask2.shape[-1] == mask.shape[-1]
+        a.mask2, a.r2_hl = mask2.data_ptr(), r2.hl.data_ptr()
     L.check(lib.asr_pack_hl(C.byref(a), _stream()), 'asr_pack_hl')
+    if r2 is not None:
+        r2.scale = r.scale                # one scale for both sets
     if r is not None and c is not None:
         c.scale = r.scale               # one scale for both orientations
     return r, c

@@ -163,6 +163,10 @@ typedef struct asr_pack_args {
   float* scale_out;                              /* device float, or NULL             */
   void* r_hl; int ldk_r;                         /* (rows, 2 ldk_r) halfs, or NULL    */
   void* c_hl; int ldk_c;                         /* (cols, 2 ldk_c) halfs, or NULL    */
+  /* optional: a SECOND set of row planes r2_hl (geometry of r_hl) of the same source under   */
+  /* mask2 (period / ld of mask) -- the two directions' dropout masks of a BiLSTM input, the  */
+  /* source read once; both sets share the scale.  NULL = one set.                            */
+  const float* mask2; void* r2_hl;
 } asr_pack_args;
 int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream);
 /* Debug: arm (enable != 0) / read the K-loop phase profile of asr_gemm_hl's workgroup 0:      */

@@ -205,6 +205,39 @@ def test_pack_hl_planes_both_orientations(rows, cols, ld, period):
     assert np.abs(back - x.astype(np.float64) * s).max() < 2.0 ** -21 * m * s
 
 
+@pytest.mark.parametrize('rows,cols,ld,period', [(999 * 16, 80, 80, 16), (333, 100, 104, 48),
+                                                 (64 * 50, 1024, 1024, 64)])
+def test_pack_hl_two_masks_in_one_pass(rows, cols, ld, period):
+    """asr_pack_args.mask2 / r2_hl (the two directions' dropout masks of a BiLSTM input, the
+    slab read once): both plane sets equal, bit for bit, the planes of two separate packs, and
+    share one scale; padding columns are zero in both."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(rows + cols + 1)
+    src = (rs.randn(rows, ld) * 0.3).astype(np.float32)
+    m1 = ((rs.rand(period, cols) > 0.2) / 0.8).astype(np.float32)
+    m2 = ((rs.rand(period, cols) > 0.2) / 0.8).astype(np.float32)
+    sd, d1, d2 = to_dev(src), to_dev(m1), to_dev(m2)
+    amax = ops.absmax(sd)
+    want = []
+    for m in (d1, d2):
+        r = ops.HlPlanes(rows, cols, 'cuda:0')
+        r.hl.fill_(5.0)
+        ops.pack_hl(sd, rows, cols, ld=ld, mask=m, mask_period=period, absmax=amax, r=r)
+        want.append((r.hl.clone(), float(r.scale.item())))
+    ra, rb = ops.HlPlanes(rows, cols, 'cuda:0'), ops.HlPlanes(rows, cols, 'cuda:0')
+    for t in (ra.hl, rb.hl):
+        t.fill_(7.0)
+    ops.pack_hl(sd, rows, cols, ld=ld, mask=d1, mask_period=period, absmax=amax, r=ra,
+                mask2=d2, r2=rb)
+    torch.cuda.synchronize()
+    assert torch.equal(ra.hl, want[0][0]) and torch.equal(rb.hl, want[1][0])
+    assert float(ra.scale.item()) == want[0][1] == float(rb.scale.item())
+    x2 = src[:, :cols] * m2[np.arange(rows) % period]
+    hi, lo = _hl_ref(x2, np.float32(want[1][1]))
+    assert np.array_equal(rb.hi.cpu().numpy()[:, :cols], hi)
+    assert np.array_equal(rb.lo.cpu().numpy()[:, :cols], lo)
+
+
 @pytest.mark.parametrize('M,N,K,sk', [(300, 200, 64, 0), (128, 128, 32, 0), (257, 132, 40, 0),
                                       (700, 512, 160, 0), (1024, 768, 2048, 4),
                                       (80, 1024, 999 * 16, 0), (1000, 260, 96, 0),

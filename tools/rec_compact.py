@@ -91,6 +91,26 @@ def main():
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / reps)
         return best
+    def pair_detail(compact, reps=4):
+        """durations of each stream's own work in the overlapped schedule (HIP events per stream)"""
+        tb = tg = 0.0
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            side.wait_stream(main_s)
+            b0.record(main_s)
+            bptt(compact)
+            b1.record(main_s)
+            with torch.cuda.stream(side):
+                g0.record(side)
+                wgrads()
+                g1.record(side)
+            main_s.wait_stream(side)
+            torch.cuda.synchronize()
+            tb += b0.elapsed_time(b1) / reps
+            tg += g0.elapsed_time(g1) / reps
+        return tb, tg
     for _ in range(4):
         bptt(False); bptt(True); wgrads('gemm')
     torch.cuda.synchronize()
@@ -114,6 +134,20 @@ def main():
           (name, t_pair, t_pair * 1e3 / T))
     print('%s overlap with the DEFAULT geometry (GEMMs queue)      %.3f ms' % (name, t_pair_def))
     print('%s gain per layer: %.3f ms' % (name, t_ser - t_pair))
+    tb, tg = pair_detail(True)
+    print('%s inside the overlap: compact BPTT %.3f ms (%.3f us/step; alone %.3f), GEMM stream '
+          '%.3f ms (alone on the whole chip %.3f)' % (name, tb, tb * 1e3 / T, t_cmp, tg, t_gemm))
+    # the GEMM stream alone on a 128-CU mask (what half of the chip is worth without a neighbour)
+    try:
+        half = ops.cu_masked_stream(dev, 128, 256)
+        def masked():
+            half.wait_stream(main_s)
+            with torch.cuda.stream(half):
+                wgrads()
+            main_s.wait_stream(half)
+        print('%s GEMM stream alone on a 128-CU masked stream: %.3f ms' % (name, timeit(masked)))
+    except Exception as e:
+        print('cu mask unavailable:', repr(e)[:200])
 
 
 if __name__ == '__main__':
