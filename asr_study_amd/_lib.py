@@ -79,7 +79,8 @@ class LstmArgs(C.Structure):
                 ('step_begin', C.c_int), ('step_count', C.c_int),
                 ('mi', void_p), ('uh', void_p), ('zone_c', void_p), ('zone_h', void_p),
                 ('wx', void_p), ('dwx', void_p), ('dmi', void_p), ('db_part', void_p),
-                ('n_valid', C.c_int), ('lds_reserve_kb', C.c_int), ('compact', C.c_int)]
+                ('n_valid', C.c_int), ('lds_reserve_kb', C.c_int), ('compact', C.c_int),
+                ('activation', C.c_int)]
 
 
 class LstmLnArgs(C.Structure):
@@ -88,7 +89,7 @@ class LstmLnArgs(C.Structure):
                 ('zone_c', void_p), ('zone_h', void_p),
                 ('wx', void_p), ('uh', void_p), ('y', void_p), ('cell', void_p),
                 ('gates', void_p), ('dy', void_p), ('duh', void_p), ('dwx', void_p),
-                ('dparams', void_p)]
+                ('dparams', void_p), ('activation', C.c_int)]
 
 
 class GateGemmArgs(C.Structure):

@@ -256,6 +256,7 @@ class Model(object):
                 s.mi = st.get('mi')                     # [alpha, beta1, beta2] inits or None
                 s.zoneout_c = float(st.get('zoneout_c') or 0.0)
                 s.zoneout_h = float(st.get('zoneout_h') or 0.0)
+                s.act = st.get('activation') or 'tanh'      # core/layers.py:452, :463
                 s.oW = take(f_pad * 8 * s.Hp)
                 s.oU = take(2 * s.Hp * 4 * s.Hp)
                 segs += [(s.oW, _pad4(f_pad * 8 * s.Hp), s.l2_W),
@@ -672,7 +673,8 @@ class Model(object):
                     rec['uh'] = uh
                     ops.lstm_ln_seq_fwd(zx, U, self._view(s.ocell, 68 * Hp), uh, y, cell, gates, T,
                                         n_pad, Hp, has_mi=s.mi is not None, mask_u=BU,
-                                        zone_c=var.get('zone_c'), zone_h=var.get('zone_h'))
+                                        zone_c=var.get('zone_c'), zone_h=var.get('zone_h'),
+                                        act=s.act)
                 elif pipe and nxt is not None and nxt.kind == 'bilstm' and not var \
                         and nxt.mi is None and nxt.ln is None:
                     # after S = 13T/16 steps the frames [T-S, S) of y are final in BOTH
@@ -769,7 +771,7 @@ class Model(object):
             return False
         if s.kind != 'bilstm' or s.mi is not None or s.ln is not None or s.Hp not in (256, 512):
             return False
-        if s.zoneout_c > 0 or s.zoneout_h > 0:
+        if s.zoneout_c > 0 or s.zoneout_h > 0 or s.act != 'tanh':
             return False
         if os.environ.get('ASR_LSTM_PREC', '1') == '0':
             return False
@@ -794,6 +796,8 @@ class Model(object):
         """Keyword arguments of the optional cell variants for ops.lstm_seq_fwd (and, with
         the backward extras added later, lstm_seq_bwd): {} for the plain cell."""
         var = {}
+        if s.act != 'tanh' and s.ln is None:        # any other activation: the variant kernels
+            var['act'] = s.act
         if s.mi is not None and s.ln is None:
             var['mi'] = self._view(s.omi, 32 * s.Hp)
             var['uh'] = self._buf('uh%d' % si, (T, n_pad, 2, 4 * s.Hp))
@@ -1064,7 +1068,8 @@ class Model(object):
                     ops.lstm_ln_seq_bwd(da, rec['zx'], U, self._view(s.ocell, 68 * Hp), rec['uh'],
                                         rec['y'], rec['cell'], rec['gates'], dz, gsrc, pgrad[0], T,
                                         n_pad, Hp, has_mi=s.mi is not None, mask_u=BU,
-                                        zone_c=var.get('zone_c'), zone_h=var.get('zone_h'))
+                                        zone_c=var.get('zone_c'), zone_h=var.get('zone_h'),
+                                        act=s.act)
                     # one pre-scale for the gradient GEMMs: max over both gradient slabs
                     ops.absmax(dz, zmx)
                     tmp = ops.absmax(gsrc, self._buf('dzmax_t', (1,)))

@@ -92,8 +92,10 @@ class TimeDistributed(Layer):
 class LSTM(object):
     """core/layers.py:356-479 (reference override of keras.layers.LSTM).
 
-    Implemented: consume_less='gpu' fused layout, hard_sigmoid inner activation,
-    tanh activation, variational dropout_W / dropout_U, W/U l2 regularisers,
+    Implemented: consume_less='gpu' fused layout, hard_sigmoid inner activation, the
+    ``activation`` of the cell candidate and output (core/layers.py:452, :463: tanh by default;
+    relu, sigmoid, hard_sigmoid, linear, softsign, softplus run on the variant kernels),
+    variational dropout_W / dropout_U, W/U l2 regularisers,
     multiplicative integration (mi=[alpha, beta1, beta2] inits), zoneout_c / zoneout_h and
     layer_norm=[gain_init, bias_init] (LN of h@U, x@W and the output cell state).
     """
@@ -110,8 +112,14 @@ class LSTM(object):
         self.mi = None if mi is None else [float(v) for v in mi]
         self.zoneout_h = float(zoneout_h or 0.0)
         self.zoneout_c = float(zoneout_c or 0.0)
-        if activation != 'tanh' or inner_activation != 'hard_sigmoid':
-            raise NotImplementedError('only tanh / hard_sigmoid are implemented')
+        if inner_activation != 'hard_sigmoid':
+            raise NotImplementedError('inner_activation: only hard_sigmoid is implemented')
+        if activation not in ('tanh', 'relu', 'sigmoid', 'hard_sigmoid', 'linear', 'softsign',
+                              'softplus'):
+            raise NotImplementedError('LSTM activation %r (implemented: the Keras-1.2.2 names '
+                                      'tanh, relu, sigmoid, hard_sigmoid, linear, softsign, '
+                                      'softplus)' % (activation,))
+        self.activation = activation
         if not return_sequences:
             raise NotImplementedError('return_sequences=False')
         self.output_dim = int(output_dim)

@@ -57,7 +57,7 @@ def ctc_model(inputs, output, **kwargs):
             spec.append({'type': 'bilstm', 'H': r.output_dim, 'dropout_W': r.dropout_W,
                          'dropout_U': r.dropout_U, 'l2_W': r.l2_W, 'l2_U': r.l2_U,
                          'mi': r.mi, 'zoneout_c': r.zoneout_c, 'zoneout_h': r.zoneout_h,
-                         'layer_norm': r.layer_norm})
+                         'layer_norm': r.layer_norm, 'activation': r.activation})
         else:
             raise NotImplementedError(type(layer).__name__)
     model = Model(spec, inputs.features, device=kwargs.get('device'),

@@ -64,4 +64,31 @@ __device__ __forceinline__ float asr_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// The LSTM's `activation` hyper-parameter (core/layers.py:452, :463: g = act(z_c), h = o act(c);
+// asr_lstm_args.activation / asr_lstm_ln_args.activation, Keras-1.2.2 names): 0 tanh, 1 relu,
+// 2 sigmoid, 3 hard_sigmoid, 4 linear, 5 softsign, 6 softplus.  Only the VARIANT kernels
+// (lstm_*_kernel_hv, lstm_ln.hip) read it; the default kernels are tanh.  asr_act_slope =
+// act'(x) written in terms of y = act(x), which is all the BPTT kernels keep of the candidate.
+__device__ __forceinline__ float asr_act_apply(int id, float x) {
+  switch (id) {
+    case 1: return fmaxf(x, 0.f);
+    case 2: return __fdividef(1.f, 1.f + __expf(-fminf(fmaxf(x, -80.f), 80.f)));
+    case 3: return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f);
+    case 4: return x;
+    case 5: return __fdividef(x, 1.f + fabsf(x));
+    case 6: return x > 20.f ? x : log1pf(__expf(fminf(x, 20.f)));
+    default: return tanhf(x);
+  }
+}
+__device__ __forceinline__ float asr_act_slope(int id, float y) {
+  switch (id) {
+    case 1: return y > 0.f ? 1.f : 0.f;
+    case 2: return y * (1.f - y);
+    case 3: return (y > 0.f && y < 1.f) ? 0.2f : 0.f;
+    case 4: return 1.f;
+    case 5: { const float a = 1.f - fabsf(y); return a * a; }
+    case 6: return 1.f - __expf(-y);
+    default: return 1.f - y * y;
+  }
+}
 #endif

@@ -113,7 +113,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   pl.n1 = 0;
   pl.form_c = 0;
   if (!bwd && a->n_valid == 1 && a->mode == 0 && (H == 256 || H == 512) &&
-      !(a->mi || a->zone_c || a->zone_h || a->uh)) {
+      !(a->mi || a->zone_c || a->zone_h || a->uh || a->activation)) {
     // one utterance: the tile-free exact-fp32 kernel (fwd_body_n1); 2 chains = 2 directions
     pl.R = 0; pl.TPW = 0; pl.NKK = 0; pl.n1 = 1;
     pl.shm = (size_t)(H + 256) * 4;
@@ -130,7 +130,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     if (pl.prec == 0) {
       // exact fp32: the structure of the split-fp16 kernel on v_mfma_f32_16x16x4_f32
       // (fwd_body_x<.., EXACT>) -- built for the widths it is benchmarked and compared at
-      if (!(a->mode == 0 && (H == 256 || H == 512) && !(a->mi || a->zone_c || a->zone_h || a->uh))) {
+      if (!(a->mode == 0 && (H == 256 || H == 512) && !(a->mi || a->zone_c || a->zone_h || a->uh || a->activation))) {
         asr_set_error("lstm fwd: ASR_LSTM_PREC=0 (exact fp32 MFMA) exists for the plain cell at "
                       "H = 256 / 512 in persistent mode; H=%d mode=%d", H, a->mode);
         return ASR_ERR_INVALID;
@@ -143,7 +143,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
       pl.xchain_words = (size_t)2 * (H / 4) * (size_t)(fwd_xstride() / 4);
       const int nkk = (H + 31) / 32;
       pl.NKK = nkk <= 4 ? 4 : nkk <= 8 ? 8 : 16;
-      const bool variants = a->mi || a->zone_c || a->zone_h || a->uh;
+      const bool variants = a->mi || a->zone_c || a->zone_h || a->uh || a->activation;
       // ASR_LSTM_GENERIC=1: the any-H kernels (lstm_*_kernel_h) also where the specialised
       // ones apply (tests compare the two)
       const bool generic = env_int("ASR_LSTM_GENERIC", 0) != 0;
@@ -172,7 +172,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     k = nullptr;
     if (pl.prec == 0) {
       // exact fp32: the two-dimensional split on fp32 MFMAs (bwd_body_c<.., EXACT>)
-      if (!(a->mode == 0 && (H == 256 || H == 512) && !(a->mi || a->zone_c || a->zone_h))) {
+      if (!(a->mode == 0 && (H == 256 || H == 512) && !(a->mi || a->zone_c || a->zone_h || a->activation))) {
         asr_set_error("lstm bwd: ASR_LSTM_PREC=0 (exact fp32 MFMA) exists for the plain cell at "
                       "H = 256 / 512 in persistent mode; H=%d mode=%d", H, a->mode);
         return ASR_ERR_INVALID;
@@ -184,7 +184,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
     }
     if (pl.prec == 1) {
       pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 72 * 2);
-      const bool variants = a->mi || a->zone_c || a->zone_h;
+      const bool variants = a->mi || a->zone_c || a->zone_h || a->activation;
       const bool generic = env_int("ASR_LSTM_GENERIC", 0) != 0;
       const bool wide = !variants && !generic && a->mode == 0 && (H == 256 || H == 512);
       // ASR_LSTM_BWD_2D: 1 = the two-dimensional split (bwd_body_c), 0 = bwd_body_x; default:
@@ -306,6 +306,8 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.gates = a->gates; p.dy = a->dy; p.dz = a->dz;
   p.dz_absmax = bwd ? reinterpret_cast<unsigned*>(a->dz_absmax) : nullptr;
   p.mi = a->mi; p.uh = a->uh; p.zone_c = a->zone_c; p.zone_h = a->zone_h;
+  p.act = a->activation;
+  ASR_CHECK_ARG(a->activation >= 0 && a->activation <= 6, "lstm: activation id %d not in 0..6", a->activation);
   p.wx = a->wx; p.dwx = a->dwx; p.dmi = a->dmi;
   p.db_part = bwd ? a->db_part : nullptr;
   if (a->mi) {
@@ -314,7 +316,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
     ASR_CHECK_ARG(env_int("ASR_LSTM_PREC", 1) == 1 && a->mode == 0,
                   "lstm: the cell variants run on the split-fp16 persistent kernels only");
   }
-  if (a->zone_c || a->zone_h)
+  if (a->zone_c || a->zone_h || a->activation)
     ASR_CHECK_ARG(env_int("ASR_LSTM_PREC", 1) == 1 && a->mode == 0,
                   "lstm: the cell variants run on the split-fp16 persistent kernels only");
   p.status = reinterpret_cast<int*>(ws);

@@ -202,9 +202,9 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
           dhz = (1.f - kh) * dh;
           dh *= kh;
         }
-        const float tch = fast_tanh(cv);
+        const float tch = VAR ? act_apply(p.act, cv) : fast_tanh(cv);
         const float d_o = dh * tch;
-        float dcc = dc + dh * go * (1.f - tch * tch);
+        float dcc = dc + dh * go * (VAR ? act_slope(p.act, tch) : (1.f - tch * tch));
         float dcz = 0.f;
         if (VAR) {                      // c = c_prev + k_c (c~ - c_prev)
           dcz = (1.f - kc) * dcc;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void bwd_body_h(const LstmParams& p, int chain, int c
         dc = dcc * gf + dcz;
         z4.x = d_i * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
         z4.y = d_f * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
-        z4.z = d_g * (1.f - gg * gg);
+        z4.z = d_g * (VAR ? act_slope(p.act, gg) : (1.f - gg * gg));
         z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
         gsum.x += z4.x; gsum.y += z4.y; gsum.z += z4.z; gsum.w += z4.w;
         const size_t zoff = (((size_t)t * p.n_pad + cn) * 2 + dir) * H4 + 4 * cu;

@@ -34,6 +34,7 @@ struct LstmParams {
   float* dc_state;
   unsigned* dz_absmax;     // optional: max |dz| as float bits (atomicMax)
   // optional cell variants (core/layers.py:432-469); all NULL on the default path
+  int act;                 // activation id of the cell candidate / output (variant kernels)
   const float* mi;         // (2, 4, 4H): alpha, beta1, beta2, bias per direction
   float* uh;               // (T, n_pad, 2, 4H) h_prev @ U (fwd writes, BPTT reads)
   const float* zone_c;     // (T, 2, H) zoneout coefficient of the cell state, per frame
@@ -119,6 +120,11 @@ __device__ __forceinline__ float fast_tanh_rcp(float x) {
   const float e = __expf(2.f * xc);
   return (e - 1.f) * __builtin_amdgcn_rcpf(e + 1.f);
 }
+// (the `activation` hyper-parameter of the variant kernels: asr_act_apply / asr_act_slope, common.h)
+__device__ __forceinline__ float act_apply(int id, float x) {
+  return id == 0 ? fast_tanh(x) : asr_act_apply(id, x);
+}
+__device__ __forceinline__ float act_slope(int id, float y) { return asr_act_slope(id, y); }
 __device__ __forceinline__ unsigned tag_word(float v, unsigned tag) {
   return (__float_as_uint(v) & ~1u) | tag;
 }

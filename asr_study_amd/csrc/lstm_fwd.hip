@@ -164,12 +164,12 @@ __device__ __forceinline__ void fwd_body_h(const LstmParams& p, int chain, int w
       }
       const float gi = hard_sigmoid(z0);
       const float gf = hard_sigmoid(z1);
-      const float gg = fast_tanh(z2);
+      const float gg = VAR ? act_apply(p.act, z2) : fast_tanh(z2);
       const float go = hard_sigmoid(z3);
       float cn = gf * c + gi * gg;
       if (VAR) cn = c + kc * (cn - c);              // zoneout of the cell state (:457-459)
       c = cn;
-      float h = go * fast_tanh(c);
+      float h = go * (VAR ? act_apply(p.act, c) : fast_tanh(c));
       if (VAR) { h = hprev + kh * (h - hprev); hprev = h; }   // ... of the hidden state
       if (s + 1 < p.T) {
         const unsigned wtag = (unsigned)(s >> 1) & 1u;

@@ -75,6 +75,7 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) {
 
 struct CellArgs {
   int T, n_pad, H, has_mi, first;       // first: no previous step (h_prev = c_prev = 0)
+  int act;                              // activation id (common.h asr_act_apply)
   int t[2], tp[2];                      // frame of this step / of the previous step, per direction
   const float* cellp;                   // (2, 34H)
   const float* zone_c; const float* zone_h;
@@ -155,7 +156,7 @@ cell_ln_fwd_kernel(CellArgs a) {
     } else {
       z = add4(add4(wnn, unn), ld4(P + o.bias + j));
     }
-    const float gi = hsig(z.x), gf = hsig(z.y), gg = tanhf(z.z), go = hsig(z.w);
+    const float gi = hsig(z.x), gf = hsig(z.y), gg = asr_act_apply(a.act, z.z), go = hsig(z.w);
     g4[m] = make_float4(gi, gf, gg, go);
     float cprev = 0.f;
     if (!a.first) {
@@ -173,7 +174,7 @@ cell_ln_fwd_kernel(CellArgs a) {
   for (int m = 0; m < kMaxU; ++m) {
     if (!ok[m]) continue;
     const float cn = (cnew[m] - mu_c) * rs_c * P[o.gc + un[m]] + P[o.bc + un[m]];
-    float h = g4[m].w * tanhf(cn);
+    float h = g4[m].w * asr_act_apply(a.act, cn);
     h = hprev[m] + kh[m] * (h - hprev[m]);
     a.y[((size_t)t * a.n_pad + n) * 2 * H + d * H + un[m]] = h;
     a.cell[r1 + un[m]] = cnew[m];
@@ -226,9 +227,9 @@ cell_ln_bwd_kernel(CellArgs a) {
     dh *= kh;
     chat[m] = (cval[m] - mu_c) * rs_c;
     const float cn = chat[m] * P[o.gc + un[m]] + P[o.bc + un[m]];
-    const float tc = tanhf(cn);
+    const float tc = asr_act_apply(a.act, cn);
     d_o[m] = dh * tc;
-    dcn[m] = dh * g4[m].w * (1.f - tc * tc);
+    dcn[m] = dh * g4[m].w * asr_act_slope(a.act, tc);
     G[o.gc + un[m]] += dcn[m] * chat[m];
     G[o.bc + un[m]] += dcn[m];
     const float g = dcn[m] * P[o.gc + un[m]];
@@ -253,7 +254,7 @@ cell_ln_bwd_kernel(CellArgs a) {
     float4 dz;
     dz.x = dc * gg * hsig_grad_from_y(gi);
     dz.y = dc * cprev[m] * hsig_grad_from_y(gf);
-    dz.z = dc * gi * (1.f - gg * gg);
+    dz.z = dc * gi * asr_act_slope(a.act, gg);
     dz.w = d_o[m] * hsig_grad_from_y(go);
     uhat[m] = norm4(uh[m], mu_u, rs_u);
     what[m] = norm4(wx[m], mu_w, rs_w);
@@ -320,6 +321,7 @@ static int check_common(const asr_lstm_ln_args* a) {
 
 static void fill_cell(const asr_lstm_ln_args* a, CellArgs* c) {
   c->T = a->T; c->n_pad = a->n_pad; c->H = a->H; c->has_mi = a->has_mi;
+  c->act = a->activation;
   c->cellp = a->cellp; c->zone_c = a->zone_c; c->zone_h = a->zone_h;
   c->wx = a->wx; c->uh = a->uh; c->y = a->y; c->cell = a->cell; c->gates = a->gates;
   c->dy = a->dy; c->duh = a->duh; c->dwx = a->dwx; c->dparams = a->dparams;

@@ -190,10 +190,25 @@ def cu_masked_stream(device, n_cus, total_cus):
     return torch.cuda.ExternalStream(out.value, device=device)
 
 
+# asr_lstm_args.activation: the reference LSTM's `activation` hyper-parameter (Keras-1.2.2 names)
+ACTIVATION_IDS = {'tanh': 0, 'relu': 1, 'sigmoid': 2, 'hard_sigmoid': 3, 'linear': 4,
+                  'softsign': 5, 'softplus': 6}
+
+
+def activation_id(act):
+    if isinstance(act, int):
+        return act
+    try:
+        return ACTIVATION_IDS[act or 'tanh']
+    except KeyError:
+        raise ValueError('LSTM activation %r: one of %s' % (act, sorted(ACTIVATION_IDS)))
+
+
 def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=None,
                dy=None, dz=None, mode=0, dz_absmax=None, steps=None, mi=None, uh=None,
-               zone_c=None, zone_h=None, wx=None, dwx=None, dmi=None, db_part=None):
+               zone_c=None, zone_h=None, wx=None, dwx=None, dmi=None, db_part=None, act=0):
     a = L.LstmArgs()
+    a.activation = activation_id(act)
     a.T, a.n_pad, a.H, a.mode = int(T), int(n_pad), int(H), int(mode)
     a.step_begin, a.step_count = (0, 0) if steps is None else (int(steps[0]), int(steps[1]))
     a.U = U.data_ptr()
@@ -206,13 +221,13 @@ def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=No
 
 
 def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=False,
-                 steps=None, mi=None, uh=None, zone_c=None, zone_h=None, n_valid=0):
+                 steps=None, mi=None, uh=None, zone_c=None, zone_h=None, n_valid=0, act=0):
     """steps=(begin, count): only that slice of the recurrence (consecutive slices from 0
     on the same stream continue one sequence); None = all T steps."""
     lib = L.load()
     _check_f32(zx, U, y, cell, gates, mask_u)
     a = _lstm_args(T, n_pad, H, U, mask_u, zx=zx, y=y, cell=cell, gates=gates, mode=mode,
-                   steps=steps, mi=mi, uh=uh, zone_c=zone_c, zone_h=zone_h)
+                   steps=steps, mi=mi, uh=uh, zone_c=zone_c, zone_h=zone_h, act=act)
     a.n_valid = int(n_valid)            # 1: single-utterance kernel (row 0 only)
     a.lds_reserve_kb = LSTM_LDS_KB
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 0)
@@ -225,7 +240,7 @@ def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=
 
 def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check=False,
                  dz_absmax=None, steps=None, mi=None, uh=None, zone_c=None, zone_h=None,
-                 wx=None, dwx=None, dmi=None, db_part=None, compact=False):
+                 wx=None, dwx=None, dmi=None, db_part=None, compact=False, act=0):
     """db_part: optional (n_pad/16, 2, 4H) buffer receiving the per-batch-tile sums of dz over
     samples and steps (bias-gradient partials; accumulated across the slices of a sequence).
     compact: H/32 workgroups per chain (half the CUs per layer, asr_lstm_args.compact)."""
@@ -233,7 +248,7 @@ def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check
     _check_f32(dy, U, cell, gates, dz, mask_u)
     a = _lstm_args(T, n_pad, H, U, mask_u, cell=cell, gates=gates, dy=dy, dz=dz, mode=mode,
                    dz_absmax=dz_absmax, steps=steps, mi=mi, uh=uh, zone_c=zone_c,
-                   zone_h=zone_h, wx=wx, dwx=dwx, dmi=dmi, db_part=db_part)
+                   zone_h=zone_h, wx=wx, dwx=dwx, dmi=dmi, db_part=db_part, act=act)
     a.lds_reserve_kb = LSTM_LDS_KB
     a.compact = 1 if compact else 0
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 1)
@@ -548,19 +563,21 @@ def _lstm_ln_args(T, n_pad, H, U, cellp, wx, uh, y, cell, gates, has_mi, mask_u=
 
 
 def lstm_ln_seq_fwd(wx, U, cellp, uh, y, cell, gates, T, n_pad, H, has_mi=False, mask_u=None,
-                    zone_c=None, zone_h=None):
+                    zone_c=None, zone_h=None, act=0):
     """Layer-normalised cell, forward over the whole sequence (include/asr_hip.h K5-LN)."""
     _check_f32(wx, U, cellp, uh, y, cell, gates, mask_u, zone_c, zone_h)
     a = _lstm_ln_args(T, n_pad, H, U, cellp, wx, uh, y, cell, gates, has_mi, mask_u, zone_c,
                       zone_h)
+    a.activation = activation_id(act)
     L.check(L.load().asr_lstm_ln_seq_fwd(C.byref(a), _stream()), 'asr_lstm_ln_seq_fwd')
 
 
 def lstm_ln_seq_bwd(dy, wx, U, cellp, uh, y, cell, gates, duh, dwx, dparams, T, n_pad, H,
-                    has_mi=False, mask_u=None, zone_c=None, zone_h=None):
+                    has_mi=False, mask_u=None, zone_c=None, zone_h=None, act=0):
     _check_f32(dy, wx, U, cellp, uh, y, cell, gates, duh, dwx, dparams, mask_u, zone_c, zone_h)
     a = _lstm_ln_args(T, n_pad, H, U, cellp, wx, uh, y, cell, gates, has_mi, mask_u, zone_c,
                       zone_h, dy=dy, duh=duh, dwx=dwx, dparams=dparams)
+    a.activation = activation_id(act)
     lib = L.load()
     nbytes = lib.asr_lstm_ln_workspace_bytes(C.byref(a))
     ws = WS.get('lstm_ln', nbytes, dy.device)

@@ -46,7 +46,8 @@ def _lstm_config(name, s, go_backwards=False):
         'name': name, 'trainable': True, 'return_sequences': True, 'go_backwards': go_backwards,
         'stateful': False, 'unroll': False, 'consume_less': 'gpu', 'input_dim': int(s.f_in),
         'input_length': None, 'output_dim': int(s.H), 'init': 'glorot_uniform',
-        'inner_init': 'orthogonal', 'forget_bias_init': 'one', 'activation': 'tanh',
+        'inner_init': 'orthogonal', 'forget_bias_init': 'one',
+        'activation': getattr(s, 'act', 'tanh'),
         'inner_activation': 'hard_sigmoid', 'W_regularizer': _regularizer(s.l2_W),
         'U_regularizer': _regularizer(s.l2_U), 'b_regularizer': None,
         'dropout_W': float(s.dropout_W), 'dropout_U': float(s.dropout_U),

@@ -362,6 +362,11 @@ typedef struct asr_lstm_args {
   /* left free.  Gate gradients are bit-identical to the default geometry.  Ignored where the */
   /* compact kernel does not exist (other H, cell variants, stepwise mode, forward).          */
   int compact;
+  /* The reference LSTM's `activation` hyper-parameter (core/layers.py:452, :463: cell         */
+  /* candidate g = act(z_c), output h = o * act(c); brsmv1 passes it on, core/models.py:220):  */
+  /* 0 tanh (default), 1 relu, 2 sigmoid, 3 hard_sigmoid, 4 linear, 5 softsign, 6 softplus     */
+  /* (Keras-1.2.2 names).  Anything but 0 runs on the variant kernels (as mi / zoneout do).    */
+  int activation;
 } asr_lstm_args;
 size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
 int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,
@@ -504,6 +509,7 @@ typedef struct asr_lstm_ln_args {
   float* duh;            /* backward out                                       */
   float* dwx;            /* backward out                                       */
   float* dparams;        /* backward out                                       */
+  int activation;        /* as asr_lstm_args.activation (0 = tanh)             */
 } asr_lstm_ln_args;
 size_t asr_lstm_ln_workspace_bytes(const asr_lstm_ln_args* a);
 int asr_lstm_ln_seq_fwd(const asr_lstm_ln_args* a, asr_stream_t stream);

@@ -34,6 +34,20 @@ def hard_sigmoid_grad(x):
     return np.where((y >= 0.0) & (y <= 1.0), 0.2, 0.0).astype(x.dtype)
 
 
+# The ``activation`` hyper-parameter of the reference's LSTM (core/layers.py:452, :463: the cell
+# candidate g = activation(z_c) and the output h = o * activation(c); brsmv1 passes it through,
+# core/models.py:220, :271): a Keras-1.2.2 activation NAME [recalled: keras/activations.py].
+# Each entry: (f(x), f'(x) expressed through y = f(x)) -- the kernels keep only y.
+ACTIVATIONS = {
+    'tanh': (np.tanh, lambda y: 1.0 - y * y),
+    'relu': (lambda x: np.maximum(x, 0.0), lambda y: (y > 0.0).astype(y.dtype)),
+    'sigmoid': (lambda x: 1.0 / (1.0 + np.exp(-x)), lambda y: y * (1.0 - y)),
+    'hard_sigmoid': (hard_sigmoid,
+                     lambda y: np.where((y > 0.0) & (y < 1.0), 0.2, 0.0).astype(y.dtype)),
+    'linear': (lambda x: x, lambda y: np.ones_like(y)),
+    'softsign': (lambda x: x / (1.0 + np.abs(x)), lambda y: (1.0 - np.abs(y)) ** 2),
+    'softplus': (lambda x: np.logaddexp(0.0, x), lambda y: 1.0 - np.exp(-y)),
+}
 LN_EPS = 1e-5       # core/layers_utils.py:16
 
 
@@ -55,7 +69,7 @@ def layer_norm_backward(dy, xhat, rstd, gain):
 
 
 def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, kh=None,
-                 ln=None):
+                 ln=None, act='tanh'):
     """One direction.  x (T,N,in); W (in,4H); U (H,4H); b (4H).
 
     BW (N,in) / BU (N,H): variational dropout masks (already scaled by 1/(1-p))
@@ -68,8 +82,11 @@ def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, 
     (core/layers_utils.py:34-42; :457-467).  ``ln`` = dict with (gain, bias) pairs under
     'Uh' (4H), 'Wx' (4H), 'new_c' (H): layer normalisation of h@U, of x@W and of the cell
     state that feeds the output (:432-436, :460-462; the carried c stays un-normalised).
+    ``act``: the ``activation`` name (ACTIVATIONS), applied to the cell candidate and to the
+    cell state that feeds the output (:452, :463).
     Returns (h_seq (T,N,H), cache).
     """
+    fact = ACTIVATIONS[act][0]
     T, N, _ = x.shape
     H = U.shape[0]
     dt = x.dtype
@@ -96,7 +113,7 @@ def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, 
             z = wx + uh + b
         i = hard_sigmoid(z[:, :H])
         f = hard_sigmoid(z[:, H:2 * H])
-        g = np.tanh(z[:, 2 * H:3 * H])
+        g = fact(z[:, 2 * H:3 * H])
         o = hard_sigmoid(z[:, 3 * H:])
         c_new = f * c + i * g
         if kc is not None:
@@ -106,7 +123,7 @@ def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, 
             lnc[t] = (uhat, urstd, what, wrstd, chat, crstd, cn)
         else:
             cn = c_new
-        h_new = o * np.tanh(cn)
+        h_new = o * fact(cn)
         if kh is not None:
             h_new = h + kh[t][None] * (h_new - h)
         h, c = h_new, c_new
@@ -114,7 +131,7 @@ def lstm_forward(x, W, U, b, reverse=False, BW=None, BU=None, mi=None, kc=None, 
         gates[t] = np.concatenate([i, f, g, o], axis=1)
     cache = dict(x=x, xs=xs, W=W, U=U, BW=BW, BU=BU, hs=hs, cs=cs, zs=zs,
                  gates=gates, reverse=reverse, mi=mi, kc=kc, kh=kh, uhs=uhs, wxs=wxs,
-                 ln=ln, lnc=lnc)
+                 ln=ln, lnc=lnc, act=act)
     return hs, cache
 
 
@@ -129,6 +146,7 @@ def lstm_backward(dhs, cache):
     dln = None if ln is None else {k: [np.zeros_like(v[0]), np.zeros_like(v[1])]
                                    for k, v in ln.items()}
     reverse = cache['reverse']
+    fact, dact = ACTIVATIONS[cache.get('act', 'tanh')]
     T, N, H = hs.shape
     dt = x.dtype
     dW = np.zeros_like(W); dU = np.zeros_like(U); db = np.zeros(4 * H, dt)
@@ -155,13 +173,13 @@ def lstm_backward(dhs, cache):
             dh = kh[t][None] * dh
         if ln is not None:
             uhat, urstd, what, wrstd, chat, crstd, cn = lnc[t]
-            tc = np.tanh(cn)
-            dcn = dh * o * (1.0 - tc * tc)
+            tc = fact(cn)
+            dcn = dh * o * dact(tc)
             dcl, dg_, db_ = layer_norm_backward(dcn, chat, crstd, ln['new_c'][0])
             dln['new_c'][0] += dg_; dln['new_c'][1] += db_
         else:
-            tc = np.tanh(cs[t])
-            dcl = dh * o * (1.0 - tc * tc)
+            tc = fact(cs[t])
+            dcl = dh * o * dact(tc)
         do = dh * tc
         dc = dc_next + dcl
         dc_zone = 0.0
@@ -173,7 +191,7 @@ def lstm_backward(dhs, cache):
         dz = np.concatenate([
             di * hard_sigmoid_grad(z[:, :H]),
             df * hard_sigmoid_grad(z[:, H:2 * H]),
-            dg * (1.0 - g * g),
+            dg * dact(g),
             do * hard_sigmoid_grad(z[:, 3 * H:])], axis=1)
         dzs[t] = dz
         if mi is not None:
@@ -257,7 +275,8 @@ def init_model(seed=0, num_features=39, num_hiddens=256, num_layers=5,
 def model_forward(params, x, masks=None, zone=None):
     """x (T,N,F) -> logits (T,N,C), caches.  masks[l][dir] = (BW, BU) or None;
     zone[l][dir] = (kc, kh) zoneout coefficients ((T,H) each, or None); a direction's
-    parameter dict may carry 'mi' = [alpha, beta1, beta2] (multiplicative integration)."""
+    parameter dict may carry 'mi' = [alpha, beta1, beta2] (multiplicative integration);
+    params['activation'] names the LSTM activation (default 'tanh')."""
     caches = {'layers': []}
     o = x
     # build-defined 2-D convolution front-end (oracle/conv.py; BASELINE configs[2]): a list of
@@ -279,7 +298,7 @@ def model_forward(params, x, masks=None, zone=None):
             if zone is not None and zone[li] is not None:
                 kc, kh = zone[li][dname]
             hs, cache = lstm_forward(o, p['W'], p['U'], p['b'], rev, BW, BU, p.get('mi'), kc, kh,
-                                     ln=p.get('ln'))
+                                     ln=p.get('ln'), act=params.get('activation', 'tanh'))
             outs.append(hs); lc[dname] = cache
         caches['layers'].append(lc)
         new_o = np.concatenate(outs, axis=-1)

@@ -243,6 +243,65 @@ def test_cell_variants_multiplicative_integration_and_zoneout(T, N, H, use_mi, u
     assert np.all(dzh[:, N:] == 0)
 
 
+@pytest.mark.parametrize('act', ['relu', 'sigmoid', 'hard_sigmoid', 'linear', 'softsign', 'softplus'])
+@pytest.mark.parametrize('T,N,H,use_zone', [(23, 5, 16, False), (31, 20, 100, True), (17, 16, 256, False)])
+def test_cell_activation_hyper_parameter(T, N, H, use_zone, act):
+    """asr_lstm_args.activation (the reference LSTM's `activation`: g = act(z_c), h = o act(c),
+    core/layers.py:452, :463; brsmv1 passes it through, core/models.py:220, :271) on the variant
+    kernels vs the oracle: activations 1e-4, gate gradients 1e-4 * max; with and without zoneout,
+    ragged K, the widths of the wide kernels (which must step aside for it)."""
+    from asr_study_amd import ops
+    F = 7
+    rs, x, p, masks = _case(T, N, F, H, 5 * T + H, False)
+    for d in ('fwd', 'bwd'):        # keep relu / linear cells in a sane range
+        p[d]['U'] = p[d]['U'] * 0.5
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    zone = None
+    if use_zone:
+        zone = {d: ((rs.rand(T, H) > 0.3).astype(np.float64), np.full((T, H), 0.85))
+                for d in ('fwd', 'bwd')}
+    dhs = {d: rs.randn(T, N, H) for d in ('fwd', 'bwd')}
+    want = {}
+    for d, rev in (('fwd', False), ('bwd', True)):
+        hs, cache = OL.lstm_forward(x, p[d]['W'], p[d]['U'], p[d]['b'], rev, None, None, None,
+                                    *(zone[d] if zone else (None, None)), act=act)
+        OL.lstm_backward(dhs[d], cache)
+        want[d] = dict(hs=hs, cache=cache)
+    zx = np.zeros((T, n_pad, 2, 4 * H), np.float32)
+    U = np.zeros((2, H, 4 * H), np.float32)
+    for di, d in enumerate(('fwd', 'bwd')):
+        zx[:, :N, di] = gate_major_to_unit_major(x @ p[d]['W'] + p[d]['b'], H)
+        zx[:, N:, di] = gate_major_to_unit_major(p[d]['b'][None, None], H)
+        U[di] = gate_major_to_unit_major(p[d]['U'], H)
+    zc_d = zh_d = None
+    if use_zone:
+        zc_d = to_dev(np.stack([zone['fwd'][0], zone['bwd'][0]], axis=1).astype(np.float32))
+        zh_d = to_dev(np.stack([zone['fwd'][1], zone['bwd'][1]], axis=1).astype(np.float32))
+    zx_d, U_d = to_dev(zx), to_dev(U)
+    y = torch.zeros(T, n_pad, 2 * H, device=dev)
+    cell = torch.zeros(T, n_pad, 2, H, device=dev)
+    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    ops.lstm_seq_fwd(zx_d, U_d, y, cell, gates, T, n_pad, H, check=True, zone_c=zc_d, zone_h=zh_d,
+                     act=act)
+    yh, ch = y.cpu().numpy(), cell.cpu().numpy()
+    tag = 'act=%s T%d N%d H%d z%d' % (act, T, N, H, use_zone)
+    for di, d in enumerate(('fwd', 'bwd')):
+        sc = max(1.0, np.abs(want[d]['cache']['cs']).max())
+        assert report('h %s %s' % (d, tag), yh[:, :N, di * H:(di + 1) * H], want[d]['hs']) < 1e-4 * sc
+        assert report('c %s %s' % (d, tag), ch[:, :N, di], want[d]['cache']['cs']) < 1e-4 * sc
+    dy = np.zeros((T, n_pad, 2 * H), np.float32)
+    dy[:, :N, :H], dy[:, :N, H:] = dhs['fwd'], dhs['bwd']
+    dz = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    ops.lstm_seq_bwd(to_dev(dy), U_d, cell, gates, dz, T, n_pad, H, check=True, zone_c=zc_d,
+                     zone_h=zh_d, act=act)
+    dzh = dz.cpu().numpy()
+    for di, d in enumerate(('fwd', 'bwd')):
+        w = gate_major_to_unit_major(want[d]['cache']['dzs'], H)
+        assert report('dz %s %s' % (d, tag), dzh[:, :N, di], w) < 1e-4 * max(1.0, np.abs(w).max())
+    assert np.all(dzh[:, N:] == 0)
+
+
 @pytest.mark.parametrize('T,N,H,use_mi,use_zone,use_mask', [
     (13, 5, 16, False, False, False),
     (17, 20, 100, True, True, True),      # two batch tiles, ragged units per thread

@@ -397,3 +397,74 @@ def test_side_stream_is_used_only_where_a_gemm_can_run_beside_the_recurrence():
         torch.cuda.synchronize()
         for a, b in zip(g_auto, model.get_gradients()):
             assert np.array_equal(a, b)
+
+
+def test_compact_bptt_schedule_runs_weight_gradients_beside_the_layer_below():
+    """ASR_BPTT_COMPACT=auto (engine.Model._bptt_compact): where a layer's BPTT would fill the chip
+    (5xBiLSTM(512) at batch 64: 256 workgroups) every layer BELOW the top one is launched in the
+    compact geometry (asr_lstm_args.compact: 128 workgroups) with the weight-gradient GEMMs of
+    the layer above on the side stream; the top layer has nothing to run beside it and keeps the
+    whole chip.  The gradients are bit-identical to the serial schedule (the compact kernel is,
+    and the GEMMs only change streams).  BiLSTM(256) at batch 32 never needs it."""
+    from asr_study_amd.core import models
+    rs = np.random.RandomState(12)
+    T, F, C = 11, 16, 6
+    for H, N, L, want in ((512, 64, 3, 2), (256, 32, 2, 0)):
+        model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L,
+                              dropout=0.0, seed=3)
+        x, labels, lens = _batch(rs, N, T, F, C)
+        slab = model.to_slab(x)
+        model.loss_and_grads(slab, labels, lens, training=True)
+        torch.cuda.synchronize()
+        assert model._compact_launches == want, (H, N, model._compact_launches)
+        g_auto = [g.copy() for g in model.get_gradients()]
+        model._compact_mode = '0'
+        model.loss_and_grads(slab, labels, lens, training=True)
+        torch.cuda.synchronize()
+        assert model._compact_launches == 0
+        for a, b in zip(g_auto, model.get_gradients()):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('act,layer_norm', [('relu', None), ('softsign', None), ('sigmoid', [1.0, 0.0]),
+                                            ('softplus', None), ('linear', None), ('hard_sigmoid', None)])
+def test_brsmv1_activation_hyper_parameter(act, layer_norm):
+    """brsmv1(activation=...) (core/models.py:220, :271 -> LSTM(activation=...), core/layers.py:452,
+    :463): logits, CTC loss and every gradient vs the oracle, on the variant kernels and (with
+    layer_norm) on the row-per-workgroup cell; an unknown name is refused when the model is built."""
+    from asr_study_amd.core import models
+    rs = np.random.RandomState(17)
+    N, T, F, C, H, L = 5, 19, 9, 7, 12, 2
+    kw = dict(layer_norm=layer_norm) if layer_norm else {}
+    model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L, dropout=0.0,
+                          weight_decay=0.0, activation=act, seed=5, **kw)
+    w = [a + rs.randn(*a.shape).astype(np.float32) * 0.1 for a in model.get_weights()]
+    model.set_weights(w)
+    it = iter([a.astype(np.float64) for a in w])
+    params = {'layers': [], 'activation': act}
+    for _ in range(L):
+        layer = {}
+        for d in ('fwd', 'bwd'):
+            layer[d] = {'W': next(it), 'U': next(it), 'b': next(it)}
+            if layer_norm:
+                layer[d]['ln'] = {k: [next(it), next(it)] for k in ('Uh', 'Wx', 'new_c')}
+        params['layers'].append(layer)
+    params['dense'] = {'W': next(it), 'b': next(it)}
+    x, labels, lens = _batch(rs, N, T, F, C)
+    xt = np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float64)
+    want = OL.loss_and_grads(params, xt, labels, lens)
+    slab = model.to_slab(x)
+    ctc, logits, _ = model.loss_and_grads(slab, labels, lens, training=True)
+    torch.cuda.synchronize()
+    sc = max(1.0, np.abs(want['logits']).max())
+    assert report('act=%s logits' % act, logits.cpu().numpy()[:, :N], want['logits']) < 1e-4 * sc
+    np.testing.assert_allclose(ctc.cpu().numpy(), want['ctc'], rtol=1e-4)
+    got = model.get_gradients()
+    flat = OL.flatten(want['grads'])
+    assert len(flat) == len(got)
+    for (name, g), gg in zip(flat, got):
+        scale = max(1e-3, np.abs(g).max())
+        assert report('act=%s grad %s' % (act, name), gg, g) < 2e-4 * scale + 1e-6, name
+    assert model.config['kwargs']['activation'] == act
+    with pytest.raises(NotImplementedError):
+        models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=1, activation='elu')

@@ -6,7 +6,16 @@ from oracle import lstm as L
 from oracle import ctc as C
 
 
-def _torch_model(params, x, masks=None):
+_TORCH_ACT = {
+    'tanh': torch.tanh, 'relu': torch.relu, 'sigmoid': torch.sigmoid,
+    'hard_sigmoid': lambda v: torch.clamp(0.2 * v + 0.5, 0.0, 1.0), 'linear': lambda v: v,
+    'softsign': torch.nn.functional.softsign, 'softplus': torch.nn.functional.softplus,
+}
+
+
+def _torch_model(params, x, masks=None, act='tanh'):
+    fact = _TORCH_ACT[act]
+
     def hs(v):
         return torch.clamp(0.2 * v + 0.5, 0.0, 1.0)
 
@@ -20,9 +29,9 @@ def _torch_model(params, x, masks=None):
             hm = h if BU is None else h * BU
             z = xt @ p['W'] + hm @ p['U'] + p['b']
             i, f = hs(z[:, :H]), hs(z[:, H:2 * H])
-            g, oo = torch.tanh(z[:, 2 * H:3 * H]), hs(z[:, 3 * H:])
+            g, oo = fact(z[:, 2 * H:3 * H]), hs(z[:, 3 * H:])
             c = f * c + i * g
-            h = oo * torch.tanh(c)
+            h = oo * fact(c)
             outs[t] = h
         return torch.stack(outs)
 
@@ -42,13 +51,13 @@ def _torch_model(params, x, masks=None):
 
 def _to_torch(tree):
     if isinstance(tree, dict):
-        return {k: _to_torch(v) for k, v in tree.items()}
+        return {k: (v if isinstance(v, str) else _to_torch(v)) for k, v in tree.items()}
     if isinstance(tree, list):
         return [_to_torch(v) for v in tree]
     return torch.tensor(tree, dtype=torch.float64, requires_grad=True)
 
 
-def _check(in_dense, use_masks):
+def _check(in_dense, use_masks, act='tanh'):
     rs = np.random.RandomState(3)
     T, N, F, H, Cc = 13, 3, 5, 4, 6
     params = L.init_model(seed=1, num_features=F, num_hiddens=H, num_layers=2,
@@ -71,10 +80,12 @@ def _check(in_dense, use_masks):
             masks.append(m)
             n_in = 2 * H
     wd = 1e-2
+    if act != 'tanh':
+        params['activation'] = act
     out = L.loss_and_grads(params, x, labels, seq_len, weight_decay=wd, masks=masks)
 
     tp = _to_torch(params)
-    logits = _torch_model(tp, torch.tensor(x), masks)
+    logits = _torch_model(tp, torch.tensor(x), masks, act)
     lp = torch.log_softmax(logits, -1)
     tgt = torch.tensor(sum(labels, []))
     ctc = torch.nn.functional.ctc_loss(lp, tgt, torch.tensor(seq_len),
@@ -96,6 +107,17 @@ def test_bptt_matches_autograd_plain():
 
 def test_bptt_matches_autograd_masks_and_in_dense():
     _check(7, True)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('act', ['relu', 'sigmoid', 'hard_sigmoid', 'linear', 'softsign', 'softplus'])
+def test_bptt_matches_autograd_for_every_activation(act):
+    """The LSTM's ``activation`` hyper-parameter (core/layers.py:452, :463; brsmv1 passes it on,
+    core/models.py:220, :271): g = act(z_c), h = o * act(c), BPTT through act' written in terms
+    of the OUTPUT of act (what the kernels keep) -- against torch.autograd, with masks."""
+    _check(None, True, act)
 
 
 def test_backward_direction_sees_padding():
