@@ -956,6 +956,11 @@ class Model(object):
         compact_any = any(self._bptt_compact(st, n_pad) for st in self.stages)
         overlap = self.overlap or compact_any
         self._compact_launches = 0
+        # split-K of the weight-gradient GEMMs that run beside a compact BPTT: sized to the CUs
+        # that are free there (ASR_SIDE_SLOTS, measurement switch; 0 = as on the whole chip)
+        side_slots = int(os.environ.get('ASR_SIDE_SLOTS', '0'))
+        split_side = ('auto:%d' % side_slots) if (compact_any and not self.overlap and side_slots) \
+            else split
         skip_grads = {}        # stage index -> gradient to add to that stage's OUTPUT
         for si in range(len(self.stages) - 1, -1, -1):
             s = self.stages[si]
@@ -973,7 +978,7 @@ class Model(object):
             if s.kind in ('noise', 'reshape'):
                 continue
             if s.kind == 'conv':
-                flush_side()        # (weight gradients of the stack above: beside this layer)
+                flush_side()
                 op, z = rec['op'], rec['z']
                 nw = s.kt * s.kf * s.C_in * s.C_out
                 da = da.contiguous()
@@ -1111,17 +1116,19 @@ class Model(object):
                         ops.gemm_hl(yu, pdz_r, self.grads, Hp, 4 * Hp, kk,
                                     a_row=0 if d == 0 else n_pad, b_k=d * 4 * Hp,
                                     b_row=n_pad if d == 0 else 0, c_off=s.oU + d * Hp * 4 * Hp,
-                                    split_k=split, ws_name=wsn, k_major=True)
+                                    split_k=split_side if wsn == 'gemm_side' else split,
+                                    ws_name=wsn, k_major=True)
 
                 def grads_W_hl(wsn, s=s, pa=rec.get('pa'), Hp=Hp, pdz_r=pdz_r, pgrad=pgrad):
+                    sp = split_side if wsn == 'gemm_side' else split
                     if len(pa) == 1:
                         ops.gemm_hl(pa[0], pdz_r, self.grads, s.f_in_pad, 8 * Hp, rows,
-                                    c_off=s.oW, split_k=split, ws_name=wsn, k_major=True)
+                                    c_off=s.oW, split_k=sp, ws_name=wsn, k_major=True)
                     else:
                         for d in range(2):
                             ops.gemm_hl(pa[d], pdz_r, self.grads, s.f_in_pad, 4 * Hp, rows,
                                         b_k=d * 4 * Hp, c_off=s.oW + d * 4 * Hp, ldc=8 * Hp,
-                                        split_k=split, ws_name=wsn, k_major=True)
+                                        split_k=sp, ws_name=wsn, k_major=True)
                     buf, nrow, ncol, goff = pgrad
                     ops.colsum(buf, nrow, ncol, ncol, self._gview(goff, ncol), ws_name=wsn + '_cs')
 
@@ -1190,6 +1197,10 @@ class Model(object):
                     dx = self._buf('da_s%d' % si, (T, n_pad, s.f_in_pad))
                     self._dx_gemm(gsrc, s, dx, BW, 0, rows, n_pad, zmx)
                     da = dx
+                # (compact schedule: is there a BiLSTM stage below whose BPTT this layer's
+                # weight gradients could run beside?  A convolution / Dense / nothing below:
+                # chip-filling GEMMs either way -- one stream, as in the serial schedule)
+                below = any(st.kind == 'bilstm' for st in self.stages[:si])
                 if not overlap:
                     weight_grads('gemm')
                     if reduce_now and not first:
@@ -1197,9 +1208,11 @@ class Model(object):
                         # are final on the main stream; their all-reduce runs beside the layers
                         # below instead of after them all
                         reduce_async(s.p_lo, s.p_hi, main)
-                elif first and not self.overlap:
+                elif (first or not below) and not self.overlap:
                     # (compact schedule: the tail's GEMMs each fill the chip -- one stream)
                     weight_grads('gemm')
+                    if not first:
+                        da = dx
                 elif first:
                     # nothing left to hide behind: share the tail between both streams
                     ready = torch.cuda.Event()

@@ -68,10 +68,18 @@ def _resolve_split_hl(split_k, M, N, K, tile=0, batch=1):
     """'auto' for asr_gemm_hl: split K until the launch fills the chip ONCE -- a workgroup of the
     256 x 256 kernel has a CU to itself (256 slots), the 128 x 128 kernel runs two per CU.  (A
     launch a little over one round costs two: 312 workgroups of a 640 x 2048 weight gradient.)"""
+    slots_cap = 0
+    if isinstance(split_k, str) and split_k.startswith('auto:'):
+        # 'auto:<CUs>': a launch that shares the chip (the side stream beside a compact BPTT
+        # has half of the CUs): one round of THAT many workgroups
+        slots_cap = int(split_k[5:])
+        split_k = 'auto'
     if split_k != 'auto':
         return int(split_k)
     big = int(tile) != 128 and int(M) >= 256 and int(N) >= 256
     tl, slots = (256, 256) if big else (128, 512)
+    if slots_cap:
+        slots = slots_cap if big else 2 * slots_cap
     tiles = ((int(M) + tl - 1) // tl) * ((int(N) + tl - 1) // tl) * max(1, int(batch))
     return max(1, min(64, slots // tiles, int(K) // 256))
 
@@ -352,7 +360,7 @@ def beam_decoder_choice(N, width, classes, on_device=True):
     default is decided on measurements (BENCH_r03 eval_beam, 64 x 999 frames on a 256-thread
     host): the host decoder is 4.6x faster at width 100 and 2.4x at width 400 as long as every
     utterance gets its own host thread, so ASR_BEAM=auto (default) takes the host decoder for
-    N <= host threads and the device decoder beyond; ASR_BEAM=device / host force one.  The
+    N <= USABLE host threads (usable_host_threads) and the device decoder beyond; ASR_BEAM=device / host force one.  The
     device kernel handles widths <= 1024 and <= 64 classes."""
     import os
     mode = os.environ.get('ASR_BEAM', 'auto')
@@ -361,7 +369,17 @@ def beam_decoder_choice(N, width, classes, on_device=True):
         return 'host'
     if mode == 'device':
         return 'device'
-    return 'host' if int(N) <= (os.cpu_count() or 1) else 'device'
+    return 'host' if int(N) <= usable_host_threads() else 'device'
+
+
+def usable_host_threads():
+    """Host threads this PROCESS may run on: the affinity mask where the platform has one (a
+    container or a taskset limits it below os.cpu_count()), else the CPU count."""
+    import os
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
 
 
 def ctc_beam_counters(logits_shape, N, beam_width, utterance=0, device='cuda:0'):

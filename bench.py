@@ -819,7 +819,10 @@ def main():
         gr = gemm_roof()
         if gr is not None:
             line['roofline_gemm_step'] = gr
-            shares = {'roofline_gemm_step': gr['ms_per_step'],
+            # (the GEMM family's share of the step counts ALL its launches: those on the main
+            # stream plus the stream time of the weight gradients beside the compact BPTTs)
+            shares = {'roofline_gemm_step': gr['ms_per_step'] + (
+                          (gr.get('overlapped') or {}).get('stream_ms_per_step') or 0.0),
                       'roofline_lstm_fwd': (fwd_t[1] or 0.0) / args.steps,
                       'roofline_lstm_bwd': (bwd_t[1] or 0.0) / args.steps}
             line['roofline_lstm_bwd'] = line['roofline']
