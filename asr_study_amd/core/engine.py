@@ -1109,7 +1109,10 @@ class Model(object):
                         if kk <= 0:
                             self._gview(s.oU + d * Hp * 4 * Hp, Hp * 4 * Hp).zero_()
                             continue
-                        yu = self._planes('yu%d' % d, rows, Hp)
+                        # (one pair of buffers per stream: the bottom layer's gradients run on
+                        # the main stream while the side stream may still read its own pair)
+                        yu = self._planes('yu%d%s' % (d, '' if wsn == 'gemm_side' else '_m'),
+                                          rows, Hp)
                         ops.pack_hl(y, rows, Hp, ld=2 * Hp, src_off=d * Hp,
                                     mask=None if BU is None else BU[d], mask_period=n_pad,
                                     absmax=self._const_one(), r=yu)
