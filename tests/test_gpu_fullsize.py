@@ -101,3 +101,71 @@ def test_frontend_alone_equals_in_batch():
             assert t == int(frames[i])
             assert torch.equal(alone[:t, 0], slab[:t, i])
             assert torch.count_nonzero(slab[t:, i]) == 0        # pad_sequences 'post'
+
+
+@pytest.mark.timeout(600)
+def test_compact_bptt_under_uneven_load_at_full_size_is_bit_identical():
+    """The compact BPTT geometry (asr_lstm_args.compact) at cfg3's FULL size (H = 512, 64 rows,
+    T = 999: 128 workgroups, one per CU) run (a) alone and (b) five times beside a stream of
+    K-major weight-gradient GEMMs and packs on the other CUs -- the load it meets in
+    engine.backward, uneven and at the package power cap -- against the default geometry alone:
+    every word of dz, max|dz| and the bias partials bit for bit, no timeout flag.  (The hand-off
+    protocol is the default kernel's; this is its test under the load the guide asks for:
+    uneven, L1-warm consumers, every word checked.)"""
+    from asr_study_amd import ops
+    T, N, H = 999, 64, 512
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(3)
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(dev)
+    U = rnd(2, H, 4 * H, scale=1.0 / np.sqrt(H))
+    zx = rnd(T, N, 2, 4 * H)
+    y = torch.empty(T, N, 2 * H, device=dev)
+    cell = torch.empty(T, N, 2, H, device=dev)
+    gates = torch.empty(T, N, 2, 4 * H, device=dev)
+    dy = rnd(T, N, 2 * H, scale=0.01)
+    mask = ((torch.rand(2, N, H, generator=g) > 0.2).float() / 0.8).to(dev)
+    ops.lstm_status(ops.lstm_seq_fwd(zx, U, y, cell, gates, T, N, H, mask_u=mask))
+    rows = T * N
+    one = torch.ones(1, device=dev)
+    pdz = ops.HlPlanes(rows, 8 * H, dev)
+    px = ops.HlPlanes(rows, 2 * H, dev)
+    gz = rnd(rows, 8 * H, scale=0.01)
+    ops.pack_hl(gz, rows, 8 * H, absmax=ops.absmax(gz), r=pdz)
+    ops.pack_hl(rnd(rows, 2 * H, scale=0.5), rows, 2 * H, absmax=one, r=px)
+    yu = ops.HlPlanes(rows, H, dev)
+    gW = torch.zeros(2 * H * 8 * H, device=dev)
+
+    def load():                     # what the side stream runs beside a BPTT in the engine
+        ops.pack_hl(y, rows, H, ld=2 * H, absmax=one, r=yu)
+        ops.gemm_hl(yu, pdz, gW, H, 4 * H, (T - 1) * N, b_row=N, split_k='auto',
+                    ws_name='gemm_side', k_major=True)
+        ops.gemm_hl(px, pdz, gW, 2 * H, 8 * H, rows, split_k='auto', ws_name='gemm_side',
+                    k_major=True)
+
+    def bptt(compact):
+        dz = torch.full((T, N, 2, 4 * H), 7.0, device=dev)
+        dbp = torch.full((N // 16, 2, 4 * H), 9.0, device=dev)
+        amax = torch.zeros(1, device=dev)
+        ws = ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, N, H, mask_u=mask, dz_absmax=amax,
+                              db_part=dbp, compact=compact)
+        return dz, dbp, amax, ws
+    want = bptt(False)
+    ops.lstm_status(want[3])
+    alone = bptt(True)
+    ops.lstm_status(alone[3])
+    for a, b in zip(alone[:3], want[:3]):
+        assert torch.equal(a, b)
+    side = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    for rep in range(5):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 3):        # a different amount of work beside it every time
+                load()
+        got = bptt(True)
+        main.wait_stream(side)
+        ops.lstm_status(got[3])
+        for a, b in zip(got[:3], want[:3]):
+            assert torch.equal(a, b), rep
