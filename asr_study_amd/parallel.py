@@ -237,7 +237,7 @@ class TorchDistComm(object):
         after = after or torch.cuda.current_stream(flat.device)
         self.stream.wait_stream(after)
         flat.record_stream(self.stream)
-        if self.world > 1:
+        if dist.is_available() and dist.is_initialized():       # (also at world 1: an identity)
             with torch.cuda.stream(self.stream):
                 dist.all_reduce(flat)
         self.calls += 1

@@ -768,8 +768,15 @@ def main():
                                 '%.2f TFLOP/s executed over the summed durations' % (
                                     mult * (fl + fl_s) / ((tot + tot_s) * 1e-3) / 1e12)},
                     'note': 'achieved = executed MFMA flop/s (split-fp16: 3 fp16 MFMAs per fp32 '
-                            'product) summed over the launches, vs the dense fp16 MFMA peak at '
-                            '2.4 GHz.  The kernel runs at the 1400 W package power cap: the chip '
+                            'product) summed over the MAIN-STREAM launches (x@W, dX, the bottom '
+                            'layer\'s gradients, Dense), vs the dense fp16 MFMA peak at 2.4 GHz.  '
+                            'Since round 5 the weight-gradient launches of the upper layers run on '
+                            'a side stream beside the compact BPTTs (`overlapped`) and their tail '
+                            'still shares the chip with the first main-stream launches behind each '
+                            'BPTT: the same kernels read 0.49 under ASR_BPTT_COMPACT=0 (serial '
+                            'schedule, 2.1 ms per step slower) and 0.42-0.44 here; alone on the chip '
+                            'x@W runs at roofline_gate_gemm.frac.  '
+                            'The kernel runs at the 1400 W package power cap: the chip '
                             'holds 1.95-2.0 GHz under it (1.75-1.8 with 32x32x16 MFMAs, which is '
                             'why the tile is built from 16x16x32), where pure 16x16x32 MFMAs on '
                             'random operands sustain 2.0 PF/s (tools/clock_probe.py, '

@@ -81,7 +81,9 @@ def main():
     out['ranks_seen_by_rccl'] = int(t[1].item())
     out['collectives_during_bptt_chipfill'] = float(t[2].item())
     out['chipfill_loss_finite'] = bool(np.isfinite(m[0]))
-    out['collectives_through_capi'] = parallel.CapiComm.get().calls
+    comm = parallel.grad_comm(dev)
+    out['collectives_through_capi'] = comm.calls
+    out['comm_kind'] = type(comm).__name__
     if rank == 0:
         print('RESULT ' + json.dumps(out))
     dist.barrier()

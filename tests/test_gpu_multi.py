@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_worker(world, port):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', ASR_FORCE_ALLREDUCE='1')
+def _run_worker(world, port, **env_extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', ASR_FORCE_ALLREDUCE='1', **env_extra)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
            str(world), '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(ROOT, 'tests', 'dp_worker.py')]
@@ -41,6 +41,16 @@ def _check(res, world):
 @pytest.mark.timeout(600)
 def test_data_parallel_worker_at_world_one():
     _check(_run_worker(1, 29581), 1)
+
+
+@pytest.mark.timeout(600)
+def test_data_parallel_worker_on_the_torch_distributed_fallback():
+    """ASR_COMM=torch (parallel.TorchDistComm: what every rank falls back to if the library's
+    RCCL entry points fail their probe on any rank): the same worker, the collectives through
+    torch.distributed's own RCCL communicator on the fallback's stream."""
+    res = _run_worker(1, 29585, ASR_COMM='torch')
+    assert res['comm_kind'] == 'TorchDistComm'
+    _check(res, 1)
 
 
 @pytest.mark.timeout(600)
