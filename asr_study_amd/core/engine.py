@@ -953,7 +953,10 @@ class Model(object):
 
         # the side stream is in use if the recurrences leave CUs free by themselves (cfg2) or
         # are made to (compact BPTT geometry, cfg3)
-        compact_any = any(self._bptt_compact(st, n_pad) for st in self.stages)
+        # (decided, like the collective schedule, on the RANK-INVARIANT reference shard: every
+        # rank then walks the same branches below, whatever its own shard of a ragged batch)
+        n_ref = self._ar_ref_pad if self._ar_ref_pad else n_pad
+        compact_any = any(self._bptt_compact(st, n_ref) for st in self.stages)
         overlap = self.overlap or compact_any
         self._compact_launches = 0
         # split-K of the weight-gradient GEMMs that run beside a compact BPTT: sized to the CUs
@@ -1085,7 +1088,7 @@ class Model(object):
                         var['db_part'] = pgrad[0]
                     # compact geometry only while there is work to run beside it (the top
                     # layer's BPTT has none: it keeps the whole chip and the shorter step)
-                    cmp_now = bool(pending) and not self.overlap and self._bptt_compact(s, n_pad)
+                    cmp_now = bool(pending) and not self.overlap and self._bptt_compact(s, n_ref)
                     self._compact_launches += int(cmp_now)
                     rec['ws_b'] = ops.lstm_seq_bwd(
                         da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp, mask_u=BU,
@@ -1214,6 +1217,8 @@ class Model(object):
                 elif (first or not below) and not self.overlap:
                     # (compact schedule: the tail's GEMMs each fill the chip -- one stream)
                     weight_grads('gemm')
+                    if reduce_now and not first:
+                        reduce_async(s.p_lo, s.p_hi, main)
                     if not first:
                         da = dx
                 elif first:
