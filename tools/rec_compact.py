@@ -137,6 +137,31 @@ def main():
     tb, tg = pair_detail(True)
     print('%s inside the overlap: compact BPTT %.3f ms (%.3f us/step; alone %.3f), GEMM stream '
           '%.3f ms (alone on the whole chip %.3f)' % (name, tb, tb * 1e3 / T, t_cmp, tg, t_gemm))
+    # shader clock of the compact BPTT alone and beside the GEMMs: the phase profiler
+    # (ASR_LSTM_DBG=32) counts shader cycles per step in workgroup 0, HIP events give the wall time
+    def ghz(beside):
+        os.environ['ASR_LSTM_DBG'] = '32'
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if beside:
+            side.wait_stream(main_s)
+        e0.record(main_s)
+        bptt(True)
+        e1.record(main_s)
+        if beside:
+            with torch.cuda.stream(side):
+                wgrads()
+            main_s.wait_stream(side)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / T
+        pr = ops.lstm_profile(ops.WS.get('lstm_bwd', 0, dev))
+        os.environ.pop('ASR_LSTM_DBG', None)
+        clk = sum(pr[0]) / float(T - 1)
+        return us, clk, clk / us / 1e3
+    for beside in (False, True, False, True):
+        us, clk, g_ = ghz(beside)
+        print('%s compact BPTT %s: %.3f us/step (profiled), %.0f shader clocks/step -> %.2f GHz' %
+              (name, 'beside the GEMMs' if beside else 'alone           ', us, clk, g_))
     # the GEMM stream alone on a 128-CU mask (what half of the chip is worth without a neighbour)
     try:
         half = ops.cu_masked_stream(dev, 128, 256)
