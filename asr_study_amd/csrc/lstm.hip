@@ -351,7 +351,9 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.dbg = env_int("ASR_LSTM_DBG", 0);
   // naps (64 clocks each) before a step's first poll, measured optimum on MI355X (sweeps of
   // rounds 1-3): forward 12-16 (~0.4 us; flat in that range), BPTT 4 / 2
-  // (the progressive forward step polls at once: a partly stale poll still delivers work)
+  // (the progressive forward step polls at once: a partly stale poll still delivers work;
+  // compact BPTT, r5 sweep of 0 / 1 / 2 / 3 / 4 / 6 / 8 naps: 2.59 / 2.58 / 2.59 / 2.61 / 2.64 /
+  // 2.66 / 2.70 us per step -- flat up to 2, the form_c value stays)
   const bool prog_f = !bwd && pl.prec == 1 && (a->H == 256 || a->H == 512) && fwd_progressive(a->H);
   // (ASR_LSTM_PROG = n > 1: progressive with n naps before the first poll -- measurement switch)
   const int prog_naps = env_int("ASR_LSTM_PROG", 0) > 1 ? env_int("ASR_LSTM_PROG", 0) : 0;
