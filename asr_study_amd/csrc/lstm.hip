@@ -151,9 +151,21 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
         // plain cell, persistent mode, H = 128 NKW: K split over the waves, U fragments in
         // AGPRs (fwd_body_x)
         pl.shm = (size_t)2 * 4 * 4 * 64 * 16;
+        // EIGHT units per workgroup (fwd_body_x<.., NJ = 2>: H/8 workgroups per chain, half the
+        // MFMAs and partial tiles on the step's critical chain, bit-identical results) where the
+        // layer then still leaves half of the CUs to the GEMMs the host runs beside it (cfg2: 4
+        // chains x 32 = 128 of 256); ASR_LSTM_FWD8 = 0 / 1 forbids / forces it
+        // (a chain's workgroups share one XCD -- map_block -- and must all be resident there:
+        // H/8 <= 32 CUs, i.e. H = 256 only)
+        const bool eight = env_int("ASR_LSTM_FWD8", chains * (H / 8) <= num_cu / 2 ? 1 : 0) != 0 &&
+                           chains * (H / 8) <= num_cu && H / 8 <= num_cu / 8;
+        if (eight) {
+          pl.P = H / 8;
+          pl.shm = (size_t)2 * 4 * 2 * 64 * 16;
+        }
         // the progressive step (slabs polled and multiplied separately, lstm_fwd.hip) where it
         // measured faster: H = 256 (ASR_LSTM_PROG=0 / 1 force the single-gather / progressive form)
-        k = ASR_PICK(asr_lstm_pick_fwd_x(H, false, fwd_progressive(H)));
+        k = ASR_PICK(asr_lstm_pick_fwd_x(H, false, fwd_progressive(H), eight));
       } else {
         // any H, the cell variants, stepwise mode: h staged in LDS once per step (fwd_body_h)
         pl.shm = (size_t)4 * 16 * (32 * pl.NKK + 8) * 2;
@@ -275,7 +287,7 @@ size_t xbuf_bytes(const asr_lstm_args* a, bool bwd) {
 }
 size_t xcc_bytes(const asr_lstm_args* a) {
   const size_t chains = (size_t)2 * (a->n_pad / 16);
-  const size_t P = (a->H + 15) / 16;
+  const size_t P = (a->H + 7) / 8;        // (the widest geometry: eight units per workgroup)
   return asr_align_up(chains * P * sizeof(int), 256);
 }
 

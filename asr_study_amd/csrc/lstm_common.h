@@ -272,7 +272,7 @@ __device__ __forceinline__ bool all_tagged(const u32x4 (&v)[NL], unsigned flip) 
 // returns a __global__ function of its translation unit as a launchable pointer.
 typedef void (*asr_lstm_kern_t)(asr_lstm::LstmParams);
 asr_lstm_kern_t asr_lstm_pick_fwd_h(int nkk, bool variants);      // any H <= 512, stepwise mode
-asr_lstm_kern_t asr_lstm_pick_fwd_x(int H, bool exact, bool slab = false);   // plain cell, H = 256 / 512
+asr_lstm_kern_t asr_lstm_pick_fwd_x(int H, bool exact, bool slab = false, bool eight = false);   // plain cell, H = 256 / 512
 asr_lstm_kern_t asr_lstm_pick_fwd_n1(int H);                      // one utterance, H = 256 / 512
 asr_lstm_kern_t asr_lstm_pick_bwd_h(int tpw, bool variants);
 asr_lstm_kern_t asr_lstm_pick_bwd_x(int H);                       // unit split, H = 256 / 512

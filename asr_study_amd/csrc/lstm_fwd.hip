@@ -424,9 +424,49 @@ __device__ __forceinline__ void fwd_slab_mfma(f32x4 (&am)[4], f32x4 (&ac)[4], co
   }
 }
 
-template <int NKW, bool FAST, bool EXACT, bool SLAB = false>
+// the same for a workgroup of TWO gate tiles (NJ = 2, eight units per workgroup): six MFMAs per
+// slab on four accumulators, an accumulator reused four MFMAs (64 cycles of pipe) later
+template <bool FIRST>
+__device__ __forceinline__ void fwd_slab_mfma2(f32x4 (&am)[2], f32x4 (&ac)[2], const f32x4& uh0,
+                                               const f32x4& uh1, const f32x4& ul0, const f32x4& ul1,
+                                               const h8& bh, const h8& bl) {
+  if constexpr (FIRST) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %4, %9, 0\n\t"        // ac_j  = uh_j bl
+        "v_mfma_f32_16x16x32_f16 %3, %5, %9, 0\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %4, %8, 0\n\t"        // am_j  = uh_j bh
+        "v_mfma_f32_16x16x32_f16 %1, %5, %8, 0\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"       // ac_j += ul_j bh
+        "v_mfma_f32_16x16x32_f16 %3, %7, %8, %3\n\t"
+        "s_nop 11"
+        : "=&v"(am[0]), "=&v"(am[1]), "=&v"(ac[0]), "=&v"(ac[1])
+        : "a"(uh0), "a"(uh1), "a"(ul0), "a"(ul1), "v"(bh), "v"(bl));
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %4, %9, %2\n\t"       // ac_j += uh_j bl
+        "v_mfma_f32_16x16x32_f16 %3, %5, %9, %3\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"       // am_j += uh_j bh
+        "v_mfma_f32_16x16x32_f16 %1, %5, %8, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"       // ac_j += ul_j bh
+        "v_mfma_f32_16x16x32_f16 %3, %7, %8, %3\n\t"
+        "s_nop 11"
+        : "+v"(am[0]), "+v"(am[1]), "+v"(ac[0]), "+v"(ac[1])
+        : "a"(uh0), "a"(uh1), "a"(ul0), "a"(ul1), "v"(bh), "v"(bl));
+  }
+}
+
+// NJ = gate tiles (of 4 units) per workgroup: 4 = sixteen units (H/16 workgroups per chain, the
+// default); 2 = EIGHT units (H/8 workgroups per chain; asr_lstm_plan picks it where the layer
+// then still leaves half of the CUs free -- cfg2's 4 chains: 128 of 256 instead of 64): half
+// the MFMAs, partial tiles and LDS traffic on the step's critical chain, the same gather.
+// Waves w < NJ finish a tile each; a (sample, unit)'s products and their summation order (K
+// split over the FOUR waves) do not depend on NJ: results are bit-identical.
+template <int NKW, bool FAST, bool EXACT, bool SLAB = false, int NJ = 4>
 __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg, float* lds) {
   // Requires H == 128 * NKW (every lane's gather groups and units exist)
+  static_assert(NJ == 4 || (NJ == 2 && !EXACT), "gate tiles per workgroup");
   constexpr int NT = 1;                            // batch tiles per workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -435,21 +475,22 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
   const int H = p.H, H4 = 4 * H, H2 = 2 * H;
   const int UG = H >> 2;
   const int dir = unit / p.NB, bt0 = unit % p.NB;
-  const int ug = wg * 4 + w;                       // the unit group this wave FINISHES
+  const bool fin = w < NJ;                         // this wave finishes a gate tile
+  const int ug = wg * NJ + (fin ? w : 0);          // the unit group this wave FINISHES
   const int u = 4 * ug + g;
   const int kbase = 32 * NKW * w;                  // first unit of this wave's K slice
-  f32x4* part = reinterpret_cast<f32x4*>(lds);     // [2 bufs][4 waves][4 gate tiles][64 lanes]
+  f32x4* part = reinterpret_cast<f32x4*>(lds);     // [2 bufs][4 waves][NJ gate tiles][64 lanes]
 
   // EXACT: the products on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate, bitwise an fmaf
   // chain).  MFMA m = (kk, half, e) of a gate tile takes from lane (g, nl) the fp32 word e of
   // its gathered group (kk, half), i.e. k-index g <-> unit kbase + 32 kk + 8 g + 4 half + e: the
   // exchange layout and the gather are those of the split path, the words are plain tagged fp32.
   constexpr int NM = EXACT ? 8 * NKW : 1;          // fp32 MFMAs per gate tile
-  float uf[4][NM];                                 // EXACT: one A-fragment register each (AGPRs)
+  float uf[NJ][NM];                                // EXACT: one A-fragment register each (AGPRs)
   if constexpr (EXACT) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ugj = wg * 4 + j;
+    for (int j = 0; j < NJ; ++j) {
+      const int ugj = wg * NJ + j;
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const int k = kbase + 32 * (m >> 3) + 8 * g + (m & 7);      // (m & 7) = 4 half + e
@@ -458,11 +499,11 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       }
     }
   }
-  f32x4 ufh[4][NKW], ufl[4][NKW];                  // bit patterns of 8 halfs each (AGPRs)
+  f32x4 ufh[NJ][NKW], ufl[NJ][NKW];                // bit patterns of 8 halfs each (AGPRs)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     if constexpr (EXACT) break;
-    const int ugj = wg * 4 + j;
+    const int ugj = wg * NJ + j;
 #pragma unroll
     for (int kk = 0; kk < NKW; ++kk) {
       h8 hv, lv;
@@ -550,6 +591,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
   };
   // cell update of tile x at step s from the recurrent contribution `a`; publishes h
   auto finish_step = [&](int x, int s, const f32x4& a, const float4& zx4) {
+    if (!fin) return;                              // (wave-uniform: waves NJ .. 3 only multiply)
     const int t = dir == 0 ? s : p.T - 1 - s;
     const CellFwd o = cell_forward(a, zx4, c[x], mask[x]);
     c[x] = o.c;
@@ -578,25 +620,26 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     // two LDS buffers by step parity (the one barrier per step keeps the waves at most one
     // step apart)
     const int buf = s & 1;
-    f32x4* mine = part + ((size_t)buf * 4 + w) * 4 * 64;
+    f32x4* mine = part + ((size_t)buf * 4 + w) * NJ * 64;
     if constexpr (EXACT) {
       // the gathered fp32 words ARE the B operands (tag bit left in: <= 1 ulp); the four gate
       // tiles' accumulator chains are interleaved (32 cycles of pipe per MFMA, 40 of latency)
-      f32x4 acc[4];
+      f32x4 acc[NJ];
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const float bw = __uint_as_float(v[x][m >> 2][m & 3]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           if (m == 0)
             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc[j]) : "a"(uf[j][0]), "v"(bw));
           else
             asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "a"(uf[j][m]), "v"(bw));
         }
       }
-      asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+      if constexpr (NJ == 4)
+        asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mine[j * 64 + lane] = acc[j];
+      for (int j = 0; j < NJ; ++j) mine[j * 64 + lane] = acc[j];
     } else {
     // exchanged word = fp16 hi << 16 | fp16 lo (tag = LSB of lo, left in place)
     h8 bh[NKW], bl[NKW];
@@ -616,7 +659,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       bl[kk] = __builtin_bit_cast(h8, lo);
     }
 #pragma unroll
-    for (int j = 0; j < 4; j += 2) {
+    for (int j = 0; j < NJ; j += 2) {
       f32x4 am0, ac0, am1, ac1;
       FwdMfma<NKW>::run2(am0, ac0, am1, ac1, ufh[j], ufl[j], ufh[j + 1], ufl[j + 1], bh, bl);
       f32x4 r0, r1;
@@ -632,8 +675,8 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     prof.stamp(2);
     __syncthreads();
     prof.stamp(3);
-    const f32x4* all = part + (size_t)buf * 4 * 4 * 64 + (size_t)w * 64 + lane;
-    const f32x4 a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
+    const f32x4* all = part + (size_t)buf * 4 * NJ * 64 + (size_t)(fin ? w : 0) * 64 + lane;
+    const f32x4 a = (all[0 * NJ * 64] + all[1 * NJ * 64]) + (all[2 * NJ * 64] + all[3 * NJ * 64]);
     finish_step(x, s, a, zx4);
     if (tr) p.trace[(((size_t)blockIdx.x * 4 + w) * 16 + (s - p.trace_s0)) * 2 + 1] = wall_clock64();
     prof.stamp(4);
@@ -645,7 +688,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     prof.stamp(0);
     const unsigned flip = 0u - ((unsigned)((s - 1) >> 1) & 1u);
     const __amdgpu_buffer_rsrc_t rsrc = slot(0, s - 1);
-    f32x4 am[4], ac[4];
+    f32x4 am[NJ], ac[NJ];
     unsigned pend = (1u << NKW) - 1u;              // wave-uniform: slabs not yet multiplied
     long long t0 = 0;
     int round = 0;
@@ -679,6 +722,14 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
         lo[1] = __builtin_amdgcn_perm(q0[3], q0[2], 0x05040100u);
         lo[2] = __builtin_amdgcn_perm(q1[1], q1[0], 0x05040100u);
         lo[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x05040100u);
+        if constexpr (NJ == 2) {
+          if (kk == 0)
+            fwd_slab_mfma2<true>(am, ac, ufh[0][kk], ufh[1][kk], ufl[0][kk], ufl[1][kk],
+                                 __builtin_bit_cast(h8, hi), __builtin_bit_cast(h8, lo));
+          else
+            fwd_slab_mfma2<false>(am, ac, ufh[0][kk], ufh[1][kk], ufl[0][kk], ufl[1][kk],
+                                  __builtin_bit_cast(h8, hi), __builtin_bit_cast(h8, lo));
+        } else {
         if (kk == 0)
           fwd_slab_mfma<true>(am, ac, ufh[0][kk], ufh[1][kk], ufh[2][kk], ufh[3][kk], ufl[0][kk],
                               ufl[1][kk], ufl[2][kk], ufl[3][kk], __builtin_bit_cast(h8, hi),
@@ -687,6 +738,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
           fwd_slab_mfma<false>(am, ac, ufh[0][kk], ufh[1][kk], ufh[2][kk], ufh[3][kk], ufl[0][kk],
                                ufl[1][kk], ufl[2][kk], ufl[3][kk], __builtin_bit_cast(h8, hi),
                                __builtin_bit_cast(h8, lo));
+        }
         pend &= ~(1u << kk);
       }
       if (pend != 0u) {
@@ -704,9 +756,9 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     if (tr) p.trace[(((size_t)blockIdx.x * 4 + w) * 16 + (s - p.trace_s0)) * 2] = wall_clock64();
     zx_next[0] = load_zx(0, s + 1);
     const int buf = s & 1;
-    f32x4* mine = part + ((size_t)buf * 4 + w) * 4 * 64;
+    f32x4* mine = part + ((size_t)buf * 4 + w) * NJ * 64;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       f32x4 t;
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] = __builtin_fmaf(ac[j][e], 1.f / kLoScale, am[j][e]);
@@ -715,8 +767,8 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     prof.stamp(2);
     __syncthreads();
     prof.stamp(3);
-    const f32x4* all = part + (size_t)buf * 4 * 4 * 64 + (size_t)w * 64 + lane;
-    const f32x4 a = (all[0 * 4 * 64] + all[1 * 4 * 64]) + (all[2 * 4 * 64] + all[3 * 4 * 64]);
+    const f32x4* all = part + (size_t)buf * 4 * NJ * 64 + (size_t)(fin ? w : 0) * 64 + lane;
+    const f32x4 a = (all[0 * NJ * 64] + all[1 * NJ * 64]) + (all[2 * NJ * 64] + all[3 * NJ * 64]);
     finish_step(0, s, a, zx4);
     if (tr) p.trace[(((size_t)blockIdx.x * 4 + w) * 16 + (s - p.trace_s0)) * 2 + 1] = wall_clock64();
     prof.stamp(4);
@@ -746,7 +798,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
   prof.flush(p.status, w);
 }
 
-template <int NKW, bool EXACT, bool SLAB = false>
+template <int NKW, bool EXACT, bool SLAB = false, int NJ = 4>
 __global__ void __launch_bounds__(kThreads)
 lstm_fwd_kernel_x(LstmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -754,8 +806,8 @@ lstm_fwd_kernel_x(LstmParams p) {
   if (!map_block(p, unit_local, wg)) return;
   const int unit = p.chain_begin + unit_local;
   const bool fast = chain_on_one_xcd(p, unit, wg, reinterpret_cast<int*>(lds));
-  if (fast) fwd_body_x<NKW, true, EXACT, SLAB>(p, unit, wg, lds);
-  else fwd_body_x<NKW, false, EXACT, SLAB>(p, unit, wg, lds);
+  if (fast) fwd_body_x<NKW, true, EXACT, SLAB, NJ>(p, unit, wg, lds);
+  else fwd_body_x<NKW, false, EXACT, SLAB, NJ>(p, unit, wg, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -881,7 +933,13 @@ asr_lstm_kern_t asr_lstm_pick_fwd_h(int nkk, bool variants) {
     default: return variants ? ASR_KERN(lstm_fwd_kernel_hv<16>) : ASR_KERN(lstm_fwd_kernel_h<16>);
   }
 }
-asr_lstm_kern_t asr_lstm_pick_fwd_x(int H, bool exact, bool slab) {
+asr_lstm_kern_t asr_lstm_pick_fwd_x(int H, bool exact, bool slab, bool eight) {
+  if (eight && !exact) {          // eight units per workgroup (NJ = 2)
+    if (H == 256) return slab ? ASR_KERN((lstm_fwd_kernel_x<2, false, true, 2>))
+                              : ASR_KERN((lstm_fwd_kernel_x<2, false, false, 2>));
+    return slab ? ASR_KERN((lstm_fwd_kernel_x<4, false, true, 2>))
+                : ASR_KERN((lstm_fwd_kernel_x<4, false, false, 2>));
+  }
   if (slab && !exact)
     return H == 256 ? ASR_KERN((lstm_fwd_kernel_x<2, false, true>))
                     : ASR_KERN((lstm_fwd_kernel_x<4, false, true>));

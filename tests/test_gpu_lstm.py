@@ -384,6 +384,48 @@ def test_layer_normalised_cell(T, N, H, use_mi, use_zone, use_mask):
         assert report('dparams %s %s' % (d, tag), got_p[di], ref) < gtol * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('N,H', [(32, 256), (48, 256), (16, 256), (64, 256)])
+@pytest.mark.parametrize('prog', ['0', '1'])
+def test_forward_eight_units_per_workgroup_is_bit_identical_to_sixteen(N, H, prog, monkeypatch):
+    """lstm_fwd_kernel_x<.., NJ = 2> (eight units per workgroup: H/8 workgroups per chain, what
+    asr_lstm_plan launches where the layer then still leaves half of the CUs free, e.g. cfg2)
+    against NJ = 4 on the same problem: a (sample, unit)'s products and their summation order do
+    not depend on the geometry, so h, c and the gates must agree BIT FOR BIT -- whole and sliced,
+    both transports, single-gather and progressive step, with a recurrent-dropout mask.  (H = 256
+    only: a chain's H/8 workgroups share one XCD of 32 CUs and must all be resident there.)"""
+    from asr_study_amd import ops
+    T = 41
+    rs = np.random.RandomState(7 * H + N)
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
+    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
+    monkeypatch.setenv('ASR_LSTM_PROG', prog)
+
+    def run(eight, ranges):
+        monkeypatch.setenv('ASR_LSTM_FWD8', eight)
+        y = torch.full((T, n_pad, 2 * H), 3.0, device=dev)
+        cell = torch.full((T, n_pad, 2, H), 4.0, device=dev)
+        gates = torch.full((T, n_pad, 2, 4 * H), 5.0, device=dev)
+        for r in ranges:
+            ws = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask, steps=r)
+        ops.lstm_status(ws)
+        return [t.cpu().numpy() for t in (y, cell, gates)]
+    want = run('0', [None])
+    got = run('1', [None])
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    sliced = run('1', [(0, 1), (1, 2), (3, 17), (20, 21)])
+    for a, b in zip(sliced, want):
+        assert np.array_equal(a, b)
+    for transport in ('0', '1'):
+        monkeypatch.setenv('ASR_LSTM_FAST', transport)
+        again = run('1', [None])
+        for a, b in zip(again, want):
+            assert np.array_equal(a, b), transport
+
+
 @pytest.mark.parametrize('N,H', [(32, 256), (64, 512), (16, 512), (48, 256)])
 def test_specialised_kernels_agree_with_the_generic_ones_and_bptt_emits_bias_gradient(N, H, monkeypatch):
     """H = 256 / 512 run on specialised kernels (forward lstm_fwd_kernel_x: K split over the
