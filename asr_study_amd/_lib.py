@@ -80,7 +80,7 @@ class LstmArgs(C.Structure):
                 ('mi', void_p), ('uh', void_p), ('zone_c', void_p), ('zone_h', void_p),
                 ('wx', void_p), ('dwx', void_p), ('dmi', void_p), ('db_part', void_p),
                 ('n_valid', C.c_int), ('lds_reserve_kb', C.c_int), ('compact', C.c_int),
-                ('activation', C.c_int)]
+                ('activation', C.c_int), ('fwd_units', C.c_int)]
 
 
 class LstmLnArgs(C.Structure):

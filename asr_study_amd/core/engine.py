@@ -680,6 +680,9 @@ class Model(object):
                     # after S = 13T/16 steps the frames [T-S, S) of y are final in BOTH
                     # directions: the next layer's input projection of those frames runs
                     # on the pipe stream while this recurrence finishes its last steps
+                    # (nothing runs beside the first S steps: the library's choice of geometry;
+                    # the GEMMs of the next layer run beside the last T - S: sixteen units per
+                    # workgroup there, i.e. the fewest CUs)
                     ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
                                      mode=self.lstm_mode, steps=(0, S))
                     ev = torch.cuda.Event()
@@ -703,7 +706,7 @@ class Model(object):
                         done.record(self._pipe)
                     pre[si + 1] = (done, halves)
                     rec['ws'] = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU,
-                                                 mode=self.lstm_mode, steps=(S, T - S))
+                                                 mode=self.lstm_mode, steps=(S, T - S), units=16)
                 else:
                     rec['ws'] = ops.lstm_seq_fwd(
                         zx, U, y, cell, gates, T, n_pad, Hp, mask_u=BU, mode=self.lstm_mode,

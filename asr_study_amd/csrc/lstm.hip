@@ -157,7 +157,9 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
         // chains x 32 = 128 of 256); ASR_LSTM_FWD8 = 0 / 1 forbids / forces it
         // (a chain's workgroups share one XCD -- map_block -- and must all be resident there:
         // H/8 <= 32 CUs, i.e. H = 256 only)
-        const bool eight = env_int("ASR_LSTM_FWD8", chains * (H / 8) <= num_cu / 2 ? 1 : 0) != 0 &&
+        const int want8 = a->fwd_units == 8 ? 1 : a->fwd_units == 16 ? 0
+                          : (chains * (H / 8) <= num_cu / 2 ? 1 : 0);
+        const bool eight = env_int("ASR_LSTM_FWD8", want8) != 0 &&
                            chains * (H / 8) <= num_cu && H / 8 <= num_cu / 8;
         if (eight) {
           pl.P = H / 8;

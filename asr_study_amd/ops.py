@@ -229,7 +229,8 @@ def _lstm_args(T, n_pad, H, U, mask_u=None, zx=None, y=None, cell=None, gates=No
 
 
 def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=False,
-                 steps=None, mi=None, uh=None, zone_c=None, zone_h=None, n_valid=0, act=0):
+                 steps=None, mi=None, uh=None, zone_c=None, zone_h=None, n_valid=0, act=0,
+                 units=0):
     """steps=(begin, count): only that slice of the recurrence (consecutive slices from 0
     on the same stream continue one sequence); None = all T steps."""
     lib = L.load()
@@ -237,6 +238,7 @@ def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=
     a = _lstm_args(T, n_pad, H, U, mask_u, zx=zx, y=y, cell=cell, gates=gates, mode=mode,
                    steps=steps, mi=mi, uh=uh, zone_c=zone_c, zone_h=zone_h, act=act)
     a.n_valid = int(n_valid)            # 1: single-utterance kernel (row 0 only)
+    a.fwd_units = int(units)            # 0 = the library decides, 8 / 16 = units per workgroup
     a.lds_reserve_kb = LSTM_LDS_KB
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 0)
     ws = WS.get('lstm_fwd', nbytes, zx.device)

@@ -367,6 +367,11 @@ typedef struct asr_lstm_args {
   /* 0 tanh (default), 1 relu, 2 sigmoid, 3 hard_sigmoid, 4 linear, 5 softsign, 6 softplus     */
   /* (Keras-1.2.2 names).  Anything but 0 runs on the variant kernels (as mi / zoneout do).    */
   int activation;
+  /* forward, optional: units per workgroup of the wide kernels -- 0 = the library decides     */
+  /* (eight at H = 256 where the layer then leaves half of the CUs free), 8 / 16 = force.      */
+  /* Slices of one sequence may differ (same exchange layout): the host runs the slice that    */
+  /* has GEMMs beside it on the geometry that occupies fewer CUs.  Results do not depend on it. */
+  int fwd_units;
 } asr_lstm_args;
 size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
 int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,

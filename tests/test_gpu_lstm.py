@@ -403,13 +403,17 @@ def test_forward_eight_units_per_workgroup_is_bit_identical_to_sixteen(N, H, pro
     mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
     monkeypatch.setenv('ASR_LSTM_PROG', prog)
 
-    def run(eight, ranges):
-        monkeypatch.setenv('ASR_LSTM_FWD8', eight)
+    def run(eight, ranges, units=None):
+        if eight is None:
+            monkeypatch.delenv('ASR_LSTM_FWD8', raising=False)
+        else:
+            monkeypatch.setenv('ASR_LSTM_FWD8', eight)
         y = torch.full((T, n_pad, 2 * H), 3.0, device=dev)
         cell = torch.full((T, n_pad, 2, H), 4.0, device=dev)
         gates = torch.full((T, n_pad, 2, 4 * H), 5.0, device=dev)
-        for r in ranges:
-            ws = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask, steps=r)
+        for i, r in enumerate(ranges):
+            ws = ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask, steps=r,
+                                  units=units[i] if units else 0)
         ops.lstm_status(ws)
         return [t.cpu().numpy() for t in (y, cell, gates)]
     want = run('0', [None])
@@ -424,6 +428,13 @@ def test_forward_eight_units_per_workgroup_is_bit_identical_to_sixteen(N, H, pro
         again = run('1', [None])
         for a, b in zip(again, want):
             assert np.array_equal(a, b), transport
+    # asr_lstm_args.fwd_units: slices of ONE sequence on different geometries (what the engine
+    # does: eight units while nothing runs beside the recurrence, sixteen for the slice that
+    # shares the chip with the next layer's GEMMs)
+    monkeypatch.delenv('ASR_LSTM_FAST', raising=False)
+    mixed = run(None, [(0, 5), (5, 20), (25, 16)], units=[8, 16, 8])
+    for a, b in zip(mixed, want):
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize('N,H', [(32, 256), (64, 512), (16, 512), (48, 256)])
