@@ -110,6 +110,8 @@ class Segment(C.Structure):
                 ('reserved', C.c_float)]
 
 
+ABI_VERSION = 106      # include/asr_hip.h ASR_HIP_ABI_VERSION: the struct layouts bound above
+
 # name -> (restype, argtypes); also the list the "exports every symbol" test walks
 SIGNATURES = {
     'asr_last_error': (C.c_char_p, []),
@@ -247,6 +249,10 @@ def load():
         fn = getattr(lib, name)     # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.asr_version() != ABI_VERSION:
+        raise AsrHipError('%s reports ABI version %d, this package binds version %d '
+                          '(include/asr_hip.h ASR_HIP_ABI_VERSION): rebuild the library'
+                          % (LIB_PATH, lib.asr_version(), ABI_VERSION))
     _lib = lib
     return lib
 

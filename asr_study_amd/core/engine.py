@@ -491,6 +491,14 @@ class Model(object):
             self._one = torch.ones(1, dtype=torch.float32, device=self.device)
         return self._one
 
+    @staticmethod
+    def _y_bounded(s):
+        """|h| <= 1 for a BiLSTM stage whose output activation is bounded (h = o * act(c), 0 <= o
+        <= 1): only then may a packed operand built from its y take 1 as the tensor bound (x the
+        inverted-dropout scale, far below the 2^8 head-room of pow2_scale(1)).  relu / linear /
+        softplus carry an unbounded c through: those outputs are measured."""
+        return s.kind == 'bilstm' and s.act in ('tanh', 'sigmoid', 'hard_sigmoid', 'softsign')
+
     def _stage_packed(self, s):
         """Whether a BiLSTM stage's GEMMs run on packed operands (plain cell only)."""
         return (self.packed and s.kind == 'bilstm' and s.mi is None and s.ln is None
@@ -640,10 +648,11 @@ class Model(object):
                 main = torch.cuda.current_stream(self.device)
                 inner_done, halves = pre.pop(si, (None, False))
                 if self._stage_packed(s):
-                    # |y| < 1 behind a BiLSTM stage; anything else is measured
+                    # |y| < 1 behind a BiLSTM stage with a bounded activation; anything else
+                    # is measured
                     prev = self.stages[si - 1] if si > 0 else None
                     bound = self._clip_bound(si)
-                    amax = self._const_one() if (prev is not None and prev.kind == 'bilstm') \
+                    amax = self._const_one() if (prev is not None and self._y_bounded(prev)) \
                         else (bound if bound is not None
                               else ops.absmax(a, self._buf('aamax%d' % si, (1,))))
                     rec['pa'] = self._pack_input(si, s, a, BW, rows, n_pad, amax)
@@ -1106,8 +1115,12 @@ class Model(object):
                     # own max|dz|
                     pdz_r = self._planes('dzr%d' % par, rows, 8 * Hp)
                     ops.pack_hl(dz, rows, 8 * Hp, absmax=zmx, r=pdz_r)
+                # bound of |y| for its planes (dU): 1 behind a bounded activation, else measured
+                # (here, on the main stream, before the side stream's packs read it)
+                ymx = self._const_one() if (not hl or self._y_bounded(s)) \
+                    else ops.absmax(y, self._buf('yamax%d' % si, (1,)))
 
-                def grads_U_hl(wsn, s=s, y=y, BU=BU, Hp=Hp, pdz_r=pdz_r):
+                def grads_U_hl(wsn, s=s, y=y, BU=BU, Hp=Hp, pdz_r=pdz_r, ymx=ymx):
                     # dU[d] = (h_prev (.) B_U)^T dz[d], reduced over the plane rows; h_prev = y
                     # one frame earlier in the direction's processing order = a row offset
                     kk = (T - 1) * n_pad
@@ -1121,7 +1134,7 @@ class Model(object):
                                           rows, Hp)
                         ops.pack_hl(y, rows, Hp, ld=2 * Hp, src_off=d * Hp,
                                     mask=None if BU is None else BU[d], mask_period=n_pad,
-                                    absmax=self._const_one(), r=yu)
+                                    absmax=ymx, r=yu)
                         ops.gemm_hl(yu, pdz_r, self.grads, Hp, 4 * Hp, kk,
                                     a_row=0 if d == 0 else n_pad, b_k=d * 4 * Hp,
                                     b_row=n_pad if d == 0 else 0, c_off=s.oU + d * Hp * 4 * Hp,

@@ -12,7 +12,7 @@ void asr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* asr_last_error(void) { return g_err; }
-extern "C" int asr_version(void) { return 100; }
+extern "C" int asr_version(void) { return ASR_HIP_ABI_VERSION; }
 
 extern "C" int asr_device_info(int* num_cus, int* lds_bytes_per_cu, char* arch,
                                int arch_len) {

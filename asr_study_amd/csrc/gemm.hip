@@ -1288,11 +1288,6 @@ gemm_hlx_kernel(HlSrc A, HlSrc B, int M, int N, int K, int k_per_split, int spli
           fbl[j] = *reinterpret_cast<const hx8*>(Bl + slot);
         }
       }
-#ifdef ASR_VARIANT_SKIPA
-      // TIMING-ONLY build (wrong results): the second half reuses the first half's A fragments,
-      // i.e. a third less LDS fragment traffic per MFMA -- what a 128 x 128 wave tile would save
-      if (hf == 0)
-#endif
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int slot = hl256_slot(wm * (32 * MI) + (hf * MI + i) * 16 + frow, fk);

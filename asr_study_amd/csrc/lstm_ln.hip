@@ -316,6 +316,8 @@ static int check_common(const asr_lstm_ln_args* a) {
                     a->H <= kT * kMaxU,
                 "lstm_ln: need n_pad %% 16 == 0, H %% 4 == 0, H <= %d (T=%d n_pad=%d H=%d)",
                 kT * kMaxU, a->T, a->n_pad, a->H);
+  ASR_CHECK_ARG(a->activation >= 0 && a->activation <= 6,
+                "lstm_ln: activation id %d out of range (0..6, asr_activation)", a->activation);
   return ASR_OK;
 }
 

@@ -240,7 +240,7 @@ class TorchDistComm(object):
         if dist.is_available() and dist.is_initialized():       # (also at world 1: an identity)
             with torch.cuda.stream(self.stream):
                 dist.all_reduce(flat)
-        self.calls += 1
+            self.calls += 1                 # collectives actually issued
         return flat
 
     def join(self, stream=None):

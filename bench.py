@@ -15,15 +15,19 @@ and the explicit torchrun form run 8 ranks); rank 0 prints ONE JSON line.  A "st
 pass of the hot path over one mini-batch whose samples are already resident in HBM when
 the timed region starts.
 
-Besides the contract fields the line carries
-  roofline / roofline_lstm_fwd / roofline_gate_gemm / roofline_ctc   per-kernel figures,
-  cpu_baseline      the NumPy oracle port on this host's cores (bounded sample), N = 1 only,
-  cfg2              the same measurement at BASELINE.json configs[1] (its own process),
+The ONE stdout line is small (< LINE_LIMIT bytes, tests/test_bench_launch.py): the contract
+fields, `config`, ONE `roofline` (the family with the largest share of GPU time, over ALL of
+its launches; the launches that own the chip are its `chip_owning` sub-object), `cpu_baseline`
+(the NumPy oracle port on this host's cores, bounded sample, N = 1 only), and compact
+{value, ms_per_step, frac} objects / scalars for the companion measurements:
+  as_written        BASELINE.json configs[2] WITH its 2-conv front-end (own process),
+  cfg2 / cfg2_n128  configs[1], and its topology at a chip-filling batch (own processes),
   exact_fp32        cfg3 again with every product on the exact-fp32 MFMA instructions,
-  predict_latency   one 10 s utterance end to end (predict.py's unit of work), ms,
-  eval_beam         eval.py's beam-search decode of the bench batch, device and host, seconds,
-  dataset_build     make_dataset.py end to end on 2048 x 10 s through the GPU front-end,
+  lstm_*_us_per_step, gate_gemm_frac, ctc_*, predict_ms, beam_s, dataset_build_audio_s_per_s,
   allreduce         bus bandwidth of the gradient all-reduce, N > 1 only.
+Everything else -- notes, per-role tables, every per-kernel roofline object, calibration --
+is the DETAIL object: written to bench_detail.json next to this script (and gpurun_out/ when
+that directory exists) and echoed on stderr behind the prefix "bench detail: ".
 """
 import argparse
 import json
@@ -47,8 +51,8 @@ CONFIGS = {
     'cfg2_n128': dict(model='brsmv1', F=39, H=256, L=5, C=28, N=128, feat='mfcc',
                       desc='brsmv1 5xBiLSTM(256), MFCC-39, 28-class CTC, batch 128 x 10 s @16 kHz '
                            '(configs[1] topology, chip-filling batch)'),
-    # BASELINE.json configs[2]: 5xBiLSTM(512), 80-dim log-mel, batch 64 (the conv
-    # front-end named there does not exist in the reference, SURVEY.md 8: not built)
+    # BASELINE.json configs[2] minus its conv front-end: 5xBiLSTM(512), 80-dim log-mel, batch 64
+    # (the configuration the north-star targets are quoted on; as written -> cfg3_conv below)
     'cfg3': dict(model='brsmv1', F=80, H=512, L=5, C=28, N=64, feat='logfbank80',
                  desc='5xBiLSTM(512), log-mel-80, 28-class CTC, batch 64 x 10 s @16 kHz'),
     # BASELINE.json configs[2] WITH its "2 conv front-end" (models.deep_speech2; no reference
@@ -347,7 +351,7 @@ def _sub_bench(config, env_extra, steps, warmup, dropout):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(steps),
            '--warmup', str(warmup), '--config', config, '--dropout', str(dropout),
-           '--no-cpu-baseline', '--no-extras']
+           '--no-cpu-baseline', '--no-extras', '--emit', 'detail']
     try:
         r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            timeout=600, stdin=subprocess.DEVNULL)
@@ -366,12 +370,152 @@ def _sub_bench(config, env_extra, steps, warmup, dropout):
                                                'us_per_timestep', 'avg_launch_ms', 'traffic',
                                                'algorithmic_fp32_tflops', 'ms_per_step',
                                                'per_role_ms', 'per_role_algorithmic_tflops', 'geometry',
-                                               'overlapped')
+                                               'chip_owning', 'shared', 'launches_per_step')
                    if kk in d[k]}
     keep['roofline_gate_gemm'] = {kk: d['roofline_gate_gemm'].get(kk) for kk in
                                   ('kernel', 'achieved', 'peak', 'unit', 'frac',
                                    'algorithmic_fp32_tflops', 'avg_launch_ms', 'pack_ms')}
     return keep
+
+
+LINE_LIMIT = 6000                 # bytes of the ONE stdout line (the driver keeps an 8 KB tail)
+CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
+                 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')
+ROOF_KEYS = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms')
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + '...'
+
+
+def _roof_compact(r):
+    """The `roofline` object of the line: the required keys (traffic stays, null when no counter
+    pass covers the kernel), GPU time per step, and the chip-owning / shared subsets' fractions."""
+    out = {k: r.get(k) for k in ROOF_KEYS}
+    out['kernel'] = _short(out['kernel'], 110)
+    for k in ('launches_per_step', 'ms_per_step', 'us_per_timestep'):
+        if r.get(k) is not None:
+            out[k] = r[k]
+    for sub in ('chip_owning', 'shared'):
+        if r.get(sub):
+            out[sub] = {k: r[sub].get(k) for k in ('frac', 'ms_per_step', 'launches_per_step',
+                                                   'avg_launch_ms')}
+    return out
+
+
+def _sub_compact(d):
+    """A companion run (its own process) as {value, ms_per_step, frac, ...}."""
+    if not isinstance(d, dict):
+        return None
+    if 'error' in d:
+        return {'error': _short(d['error'], 120)}
+    out = {'value': d.get('value'), 'ms_per_step': d.get('ms_per_step')}
+    roof = d.get('roofline') or {}
+    out['frac'] = roof.get('frac')
+    out['roofline_kernel'] = _short(roof.get('kernel', ''), 40)
+    for key, name in (('roofline_lstm_fwd', 'fwd_us'), ('roofline_lstm_bwd', 'bwd_us')):
+        if (d.get(key) or {}).get('us_per_timestep') is not None:
+            out[name] = d[key]['us_per_timestep']
+    if (d.get('roofline_gate_gemm') or {}).get('frac') is not None:
+        out['gate_gemm_frac'] = d['roofline_gate_gemm']['frac']
+    return out
+
+
+def compact_line(detail, limit=LINE_LIMIT):
+    """The ONE JSON object bench.py prints on stdout, from the full DETAIL object of a run.
+    Pure function of `detail` (tests/test_bench_launch.py builds it from a canned measurement).
+    Optional keys are dropped from the end of `optional` until the line fits `limit`."""
+    line = {k: detail.get(k) for k in CONTRACT_KEYS}
+    line['dtype'] = _short(line['dtype'], 48)
+    cfg = dict(detail.get('config') or {})
+    cfg['workload'] = _short(cfg.get('workload', ''), 120)
+    if 'baseline_config' in cfg:
+        cfg['baseline_config'] = _short(cfg['baseline_config'], 100)
+    line['config'] = cfg
+    line['roofline'] = _roof_compact(detail['roofline']) if detail.get('roofline') else None
+    cb = detail.get('cpu_baseline')
+    if cb:
+        c = {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind', 'blas_threads', 'utterances')}
+        c['sample'] = _short(cb.get('sample', ''), 150)
+        for k in ('frontend_1core', 'frontend_allcores', 'cfg1_step'):
+            if isinstance(cb.get(k), dict) and cb[k].get('value') is not None:
+                c[k] = cb[k]['value']
+        line['cpu_baseline'] = c
+    optional = []                            # (key, value): most dispensable LAST
+
+    def opt(key, value):
+        if value is not None:
+            optional.append((key, value))
+    opt('fallbacks', detail.get('fallbacks'))
+    for k in ('as_written', 'cfg2', 'cfg2_n128', 'exact_fp32'):
+        src = detail.get('cfg3_conv') if k == 'as_written' else detail.get(k)
+        opt(k, _sub_compact(src))
+    for key, name in (('roofline_lstm_fwd', 'lstm_fwd_us_per_step'),
+                      ('roofline_lstm_bwd', 'lstm_bwd_us_per_step')):
+        opt(name, (detail.get(key) or {}).get('us_per_timestep'))
+    geo = (detail.get('roofline_lstm_bwd') or {}).get('geometry')
+    if geo:
+        opt('lstm_bwd_us_per_step_by_geometry', {'compact': geo.get('compact_us_per_timestep'),
+                                                 'default': geo.get('default_us_per_timestep')})
+    opt('gate_gemm_frac', (detail.get('roofline_gate_gemm') or {}).get('frac'))
+    ctc = detail.get('roofline_ctc') or {}
+    if ctc:
+        opt('ctc', {'hbm_frac': ctc.get('frac'), 'ms': ctc.get('avg_ms'), 'traffic': ctc.get('traffic')})
+    conv = detail.get('roofline_conv') or {}
+    if conv:
+        opt('conv', {'frac': conv.get('frac'), 'ms_per_step': conv.get('ms_per_step')})
+    ar = detail.get('allreduce')
+    if ar:
+        opt('allreduce', {k: ar.get(k) for k in ('bytes', 'ms', 'bus_GBps')})
+    opt('ranks_seen_by_rccl', detail.get('ranks_seen_by_rccl'))
+    arm = detail.get('allreduce_model') or {}
+    opt('allreduce_model_ring_8gpu_ms', arm.get('ring_8gpu_ms'))
+    pl = detail.get('predict_latency') or {}
+    opt('predict_ms', pl.get('n1_kernel_ms', _short(pl.get('error'), 80) if pl.get('error') else None))
+    eb = detail.get('eval_beam') or {}
+    if eb:
+        opt('beam_s', {'decoder': eb.get('default_decoder'), 'w100': eb.get('default_width_100_s'),
+                       'w400': eb.get('default_width_400_s'),
+                       'device_w100': eb.get('device_width_100_s'),
+                       'host_w100': eb.get('host_width_100_s')}
+            if 'error' not in eb else {'error': _short(eb['error'], 80)})
+    db = detail.get('dataset_build') or {}
+    opt('dataset_build_audio_s_per_s', db.get('value', _short(db.get('error'), 80) if db.get('error') else None))
+    opt('detail', detail.get('detail_file'))
+    while True:
+        out = dict(line)
+        out.update(optional)
+        text = json.dumps(out)
+        if len(text) < limit or not optional:
+            return out
+        optional.pop()
+
+
+def emit(detail, stream_out=None, stream_err=None):
+    """Writes the DETAIL object to bench_detail.json (+ gpurun_out/), echoes it on stderr, and
+    prints the compact line as the LAST thing on stdout."""
+    stream_out = stream_out or sys.stdout
+    stream_err = stream_err or sys.stderr
+    path = os.environ.get('ASR_BENCH_DETAIL', os.path.join(ROOT, 'bench_detail.json'))
+    paths = [path]
+    if os.path.isdir(os.path.join(ROOT, 'gpurun_out')):
+        paths.append(os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'))
+    detail['detail_file'] = os.path.basename(path)
+    text = json.dumps(detail)
+    for p_ in paths:
+        try:
+            with open(p_, 'w') as f:
+                f.write(text + '\n')
+        except OSError:
+            pass
+    print('bench detail: ' + text, file=stream_err)
+    stream_err.flush()
+    line = json.dumps(compact_line(detail))
+    assert len(line) < 8192
+    print(line, file=stream_out)
+    stream_out.flush()
+    return line
 
 
 def main():
@@ -385,6 +529,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the cfg2 / exact-fp32 companion runs')
+    ap.add_argument('--emit', default='compact', choices=('compact', 'detail'),
+                    help='stdout line: the compact line (default) or the full detail object '
+                         '(what the companion runs hand to their parent)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -727,61 +874,50 @@ def main():
         split = os.environ.get('ASR_GEMM_PREC', '1') != '0' or os.environ.get('ASR_LSTM_PREC', '1') != '0'
 
         def gemm_roof():
-            # every big GEMM of the step (x@W, dz@W^T, x^T dz, h^T dz, Dense), timed in place
+            # every big GEMM of the step (x@W, dz@W^T, x^T dz, h^T dz, Dense), timed in place.
+            # achieved / frac / avg_launch_ms / ms_per_step are taken over ALL launches of the
+            # family.  Launches on the side stream run on the CUs a compact BPTT leaves free (128
+            # of 256 at cfg3) or queue behind it: their durations are wall time on a SHARED chip;
+            # the launches that have the chip to themselves (main stream) are `chip_owning`, the
+            # others `shared` -- two subsets of the same sum, not a different definition of it.
             ev_all = lstm_ev['gemm_hl'] + lstm_ev['gemm']
             if not ev_all:
                 return None
-            # Launches on the side stream run on the CUs a compact BPTT leaves free (128 of 256
-            # at cfg3) or queue behind it: their durations are wall time on a SHARED chip and say
-            # nothing about the kernel -- the family's roofline is taken over the launches that
-            # have the chip to themselves (main stream); the others are listed under `overlapped`
             ev = [e for e in ev_all if not gemm_side.get(id(e[0]))]
             ev_side = [e for e in ev_all if gemm_side.get(id(e[0]))]
             exact = os.environ.get('ASR_GEMM_PREC', '1') == '0'
-            tot = float(sum(a.elapsed_time(b) for a, b, _ in ev))
-            fl = float(sum(f for _, _, f in ev))
-            tot_s = float(sum(a.elapsed_time(b) for a, b, _ in ev_side))
-            fl_s = float(sum(f for _, _, f in ev_side))
             mult, peak = (1, PEAK_F32_MFMA_TFLOPS) if exact else (3, PEAK_F16_MFMA_TFLOPS)
-            ach = mult * fl / (tot * 1e-3) / 1e12
             packed = len(lstm_ev['gemm_hl']) > 0
-            return {'kernel': ('gemm_hlx_kernel<4,4,2> (256x256 tile; operands packed once into '
-                               'split-fp16 planes)' if packed else
-                               'gemm_f32_mfma_kernel' if exact else 'gemm_f16x2_fast_kernel') +
-                              ': all GEMMs of the step',
-                    'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(ach / peak, 4), 'traffic': pmc.get('gemm'),
-                    'algorithmic_fp32_tflops': round(fl / (tot * 1e-3) / 1e12, 2),
-                    'launches_per_step': round(len(ev) / float(args.steps), 1),
-                    'avg_launch_ms': round(tot / len(ev), 4),
-                    'ms_per_step': round(tot / args.steps, 3),
-                    'algorithmic_tflop_per_step': round(fl / args.steps / 1e12, 3),
-                    'overlapped': None if not ev_side else {
-                        'launches_per_step': round(len(ev_side) / float(args.steps), 1),
-                        'stream_ms_per_step': round(tot_s / args.steps, 3),
-                        'algorithmic_tflop_per_step': round(fl_s / args.steps / 1e12, 3),
-                        'executed_tflops_while_sharing': round(mult * fl_s / (tot_s * 1e-3) / 1e12, 2),
-                        'note': 'weight-gradient GEMMs (K-major) on the side stream, beside the '
-                                'compact BPTT of the layer below (which holds half of the CUs): '
-                                'event durations on a shared chip, off the critical path; NOT in '
-                                'achieved / frac / ms_per_step above.  All launches together: '
-                                '%.2f TFLOP/s executed over the summed durations' % (
-                                    mult * (fl + fl_s) / ((tot + tot_s) * 1e-3) / 1e12)},
-                    'note': 'achieved = executed MFMA flop/s (split-fp16: 3 fp16 MFMAs per fp32 '
-                            'product) summed over the MAIN-STREAM launches (x@W, dX, the bottom '
-                            'layer\'s gradients, Dense), vs the dense fp16 MFMA peak at 2.4 GHz.  '
-                            'Since round 5 the weight-gradient launches of the upper layers run on '
-                            'a side stream beside the compact BPTTs (`overlapped`) and their tail '
-                            'still shares the chip with the first main-stream launches behind each '
-                            'BPTT: the same kernels read 0.49 under ASR_BPTT_COMPACT=0 (serial '
-                            'schedule, 2.1 ms per step slower) and 0.42-0.44 here; alone on the chip '
-                            'x@W runs at roofline_gate_gemm.frac.  '
-                            'The kernel runs at the 1400 W package power cap: the chip '
-                            'holds 1.95-2.0 GHz under it (1.75-1.8 with 32x32x16 MFMAs, which is '
-                            'why the tile is built from 16x16x32), where pure 16x16x32 MFMAs on '
-                            'random operands sustain 2.0 PF/s (tools/clock_probe.py, '
-                            'tools/micro/mfma_power.hip, DESIGN.md 6); PMC: MFMA pipes 54 % '
-                            '(row-major) / 70 % (K-major) busy (profiles/r4z_pmc_step_cfg3.md)'}
+
+            def subset(evs):
+                if not evs:
+                    return None
+                tot = float(sum(a.elapsed_time(b) for a, b, _ in evs))
+                fl = float(sum(f for _, _, f in evs))
+                ach = mult * fl / (tot * 1e-3) / 1e12
+                return {'achieved': round(ach, 2), 'frac': round(ach / peak, 4),
+                        'algorithmic_fp32_tflops': round(fl / (tot * 1e-3) / 1e12, 2),
+                        'launches_per_step': round(len(evs) / float(args.steps), 1),
+                        'avg_launch_ms': round(tot / len(evs), 4),
+                        'ms_per_step': round(tot / args.steps, 3),
+                        'algorithmic_tflop_per_step': round(fl / args.steps / 1e12, 3)}
+            r = {'kernel': ('gemm_hlx_kernel<4,4,2> (256x256 tile; operands packed once into '
+                            'split-fp16 planes)' if packed else
+                            'gemm_f32_mfma_kernel' if exact else 'gemm_f16x2_fast_kernel') +
+                           ': all GEMM launches of the step',
+                 'bound': 'mfma', 'peak': peak, 'unit': 'TFLOP/s', 'traffic': pmc.get('gemm')}
+            r.update(subset(ev_all))
+            r['chip_owning'] = subset(ev)
+            r['shared'] = subset(ev_side)
+            r['note'] = ('achieved = executed MFMA flop/s (split-fp16: 3 fp16 MFMAs per fp32 product) '
+                         'summed over ALL launches of the family / their summed HIP-event durations, vs '
+                         'the dense fp16 MFMA peak.  chip_owning = the main-stream launches (x@W, dX, '
+                         'the bottom layer\'s gradients, Dense); shared = the K-major weight-gradient '
+                         'launches on the side stream beside the compact BPTT of the layer below '
+                         '(wall time on half of a power-capped chip).  Alone on the chip x@W runs at '
+                         'roofline_gate_gemm.frac.  PMC: profiles/r6*_pmc_step_cfg3.md; the power-cap '
+                         'analysis: DESIGN.md 6')
+            return r
         line = {
             'metric': 'audio-seconds/sec trained (MFCC+BiLSTM+CTC)',
             'value': round(value, 1), 'unit': 'audio-seconds/s', 'n_gpus': world,
@@ -826,10 +962,8 @@ def main():
         gr = gemm_roof()
         if gr is not None:
             line['roofline_gemm_step'] = gr
-            # (the GEMM family's share of the step counts ALL its launches: those on the main
-            # stream plus the stream time of the weight gradients beside the compact BPTTs)
-            shares = {'roofline_gemm_step': gr['ms_per_step'] + (
-                          (gr.get('overlapped') or {}).get('stream_ms_per_step') or 0.0),
+            # (GPU time per step of each family, all launches)
+            shares = {'roofline_gemm_step': gr['ms_per_step'],
                       'roofline_lstm_fwd': (fwd_t[1] or 0.0) / args.steps,
                       'roofline_lstm_bwd': (bwd_t[1] or 0.0) / args.steps}
             line['roofline_lstm_bwd'] = line['roofline']
@@ -896,7 +1030,10 @@ def main():
                 line['dataset_build'] = {'error': repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
-        print(json.dumps(line))
+        if args.emit == 'detail':
+            print(json.dumps(line))
+        else:
+            emit(line)
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

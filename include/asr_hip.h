@@ -46,6 +46,12 @@ enum asr_status {
 };
 
 const char* asr_last_error(void);
+/* ABI version of THIS header: bumped whenever an argument struct grows or changes meaning (no
+ * struct carries a size field).  A caller checks asr_version() == ASR_HIP_ABI_VERSION right
+ * after loading the library (asr_study_amd/_lib.py does) and refuses a mismatch.
+ * 100: rounds 1-4.  105: asr_lstm_args +compact +activation +fwd_units, asr_pack_args +mask2
+ * +r2_hl, asr_lstm_ln_args +activation.  106: round 6. */
+#define ASR_HIP_ABI_VERSION 106
 int asr_version(void);
 /* Device facts the host needs for sizing persistent grids (CU count etc). */
 int asr_device_info(int* num_cus, int* lds_bytes_per_cu, char* arch, int arch_len);

@@ -468,3 +468,51 @@ def test_brsmv1_activation_hyper_parameter(act, layer_norm):
     assert model.config['kwargs']['activation'] == act
     with pytest.raises(NotImplementedError):
         models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=1, activation='elu')
+
+
+@pytest.mark.parametrize('act', ['relu', 'linear'])
+def test_unbounded_activation_above_the_packed_planes_fixed_bound(act):
+    """with relu / linear h = o * act(c) is unbounded (c accumulates over the frames), so
+    the packed operands built from y (next layer's x@W, dU) must MEASURE their bound instead of
+    assuming |y| < 1 (pow2_scale(1) = 2^8: anything >= 256 would become an fp16 inf in the hi
+    plane).  Gates saturated open and a constant cell drive of +30 per frame: |y| reaches ~ 30 T
+    >> 256.  Logits, CTC and every gradient stay finite and on the oracle."""
+    from asr_study_amd.core import models
+    rs = np.random.RandomState(23)
+    N, T, F, C, H, L = 4, 21, 8, 6, 16, 2
+    model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L, dropout=0.0,
+                          weight_decay=0.0, activation=act, seed=9)
+    assert model.packed and all(model._stage_packed(s) for s in model.stages if s.kind == 'bilstm')
+    w = [a.copy() for a in model.get_weights()]
+    for k in range(0, 6 * L, 3):                         # [W, U, b] per direction, blocks i f c o
+        w[k] *= 0.05
+        w[k + 1] *= 0.05
+        b = w[k + 2]
+        b[:] = 5.0
+        b[2 * H:3 * H] = 30.0 if k < 6 else 0.5          # the first layer pumps its cell
+    w[-2] *= 0.02
+    model.set_weights(w)
+    it = iter([a.astype(np.float64) for a in w])
+    params = {'layers': [], 'activation': act}
+    for _ in range(L):
+        params['layers'].append({d: {'W': next(it), 'U': next(it), 'b': next(it)}
+                                 for d in ('fwd', 'bwd')})
+    params['dense'] = {'W': next(it), 'b': next(it)}
+    x, labels, lens = _batch(rs, N, T, F, C)
+    lens = [T] * N
+    xt = np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float64)
+    want = OL.loss_and_grads(params, xt, labels, lens)
+    # (|y| of the first layer reaches ~ 30 T: its dU is of that order)
+    assert max(np.abs(g).max() for n, g in OL.flatten(want['grads']) if n.endswith('/U')) > 256.0
+    slab = model.to_slab(x)
+    ctc, logits, _ = model.loss_and_grads(slab, labels, lens, training=True)
+    torch.cuda.synchronize()
+    lg = logits.cpu().numpy()[:, :N]
+    assert np.all(np.isfinite(lg)) and np.all(np.isfinite(ctc.cpu().numpy()))
+    sc = max(1.0, np.abs(want['logits']).max())
+    assert report('act=%s big logits' % act, lg, want['logits']) < 1e-4 * sc
+    np.testing.assert_allclose(ctc.cpu().numpy(), want['ctc'], rtol=1e-4)
+    for (name, g), gg in zip(OL.flatten(want['grads']), model.get_gradients()):
+        assert np.all(np.isfinite(gg)), name
+        scale = max(1e-3, np.abs(g).max())
+        assert report('act=%s big grad %s' % (act, name), gg, g) < 2e-4 * scale + 1e-6, name
