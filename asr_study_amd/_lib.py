@@ -80,7 +80,8 @@ class LstmArgs(C.Structure):
                 ('mi', void_p), ('uh', void_p), ('zone_c', void_p), ('zone_h', void_p),
                 ('wx', void_p), ('dwx', void_p), ('dmi', void_p), ('db_part', void_p),
                 ('n_valid', C.c_int), ('lds_reserve_kb', C.c_int), ('compact', C.c_int),
-                ('activation', C.c_int), ('fwd_units', C.c_int)]
+                ('activation', C.c_int), ('fwd_units', C.c_int),
+                ('dz_hl', void_p), ('dz_bound', void_p), ('dz_scale_out', void_p)]
 
 
 class LstmLnArgs(C.Structure):
@@ -161,6 +162,8 @@ SIGNATURES = {
     'asr_lstm_profile': (C.c_int, [void_p, void_p, C.POINTER(C.c_longlong)]),
     'asr_lstm_plan': (C.c_int, [C.POINTER(LstmArgs), C.c_int, c_int_p, c_int_p, c_int_p,
                                 c_int_p]),
+    'asr_lstm_dz_hl_supported': (C.c_int, [C.POINTER(LstmArgs)]),
+    'asr_lstm_dz_guard': (C.c_int, [void_p, void_p, C.c_int, void_p, void_p]),
     'asr_ctc_workspace_bytes': (C.c_size_t, [C.c_int] * 5),
     'asr_ctc_loss_grad': (C.c_int, [void_p, void_p, void_p, void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_float, void_p, void_p,

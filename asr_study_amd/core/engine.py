@@ -155,6 +155,13 @@ class Model(object):
         # instead of behind it; 0 = never (the serial schedule of rounds 1-4), 1 = wherever the
         # compact kernel exists
         self._compact_mode = _os.environ.get('ASR_BPTT_COMPACT', 'auto')
+        # ASR_BPTT_PLANES=0: BPTT always writes the fp32 dz slab and a pack pass follows (the
+        # round 1-5 path; A/B switch).  Default: BPTT writes the packed planes itself where its
+        # kernel can (backward()); per-stage bounds of max|dz| live in _buf('dzbound<si>')
+        self._dz_planes_mode = _os.environ.get('ASR_BPTT_PLANES', '1') != '0'
+        self._dz_bound_key = {}         # stage -> (fault generation, weights epoch) of its bound
+        self._weights_epoch = 0         # bumped when weights are replaced from outside
+        self._dz_measure_passes = 0     # measuring BPTT passes run so far (first step of a layer)
         self._pipe = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         # big GEMMs on operands packed once into split-fp16 planes (ops.pack_hl / gemm_hl);
         # ASR_GEMM_PACKED=0 keeps the convert-per-tile kernels, ASR_GEMM_PREC=0 (exact fp32) too
@@ -395,6 +402,7 @@ class Model(object):
                 else:
                     host[s.omi:s.omi + mip.size] = mip.ravel()
         self.params.copy_(torch.from_numpy(host))
+        self._weights_epoch += 1        # (bounds measured under the old weights are dropped)
 
     def _unpack(self, flat):
         out = []
@@ -1054,6 +1062,7 @@ class Model(object):
                     # slab for it; the tiles are added up on the side stream
                     dbp = self._buf('dbpart%d' % si, (n_pad // 16, 2, 4 * Hp))
                     pgrad = (dbp, n_pad // 16, 8 * Hp, s.ob)
+                planes_now, pdz_r = False, None
                 pipe_b = (getattr(self, '_pipe_now', False) and self._pipe is not None
                           and not first and self.lstm_mode == 0 and T >= 16 and not var
                           and s.ln is None)
@@ -1102,14 +1111,43 @@ class Model(object):
                     # layer's BPTT has none: it keeps the whole chip and the shorter step)
                     cmp_now = bool(pending) and not self.overlap and self._bptt_compact(s, n_ref)
                     self._compact_launches += int(cmp_now)
-                    rec['ws_b'] = ops.lstm_seq_bwd(
-                        da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp, mask_u=BU,
-                        mode=self.lstm_mode, dz_absmax=zmx, compact=cmp_now, **var)
+                    # BPTT writes dz as packed planes itself where its kernel can (the plain cell
+                    # at H = 256 / 512 on the two-dimensional-split kernels): the pack pass over
+                    # the fp32 slab (2.1 GB per layer at cfg3) disappears.  The planes' scale has
+                    # to be known before the pass: a per-layer bound kept at ~8 x the measured
+                    # max|dz| by asr_lstm_dz_guard (hysteresis: identical inputs see identical
+                    # scales); a layer without a bound yet -- first step, after a fault or new
+                    # weights -- runs one MEASURING pass first (fp32 slab, discarded).
+                    plain = not any(var.get(k) is not None
+                                    for k in ('act', 'zone_c', 'zone_h', 'mi', 'uh'))
+                    planes_now = (self._dz_planes_mode and self._stage_packed(s) and plain
+                                  and self.lstm_mode == 0
+                                  and ops.lstm_dz_hl_supported(T, n_pad, Hp, compact=cmp_now))
+                    if planes_now:
+                        pdz_r = self._planes('dzr%d' % par, rows, 8 * Hp)
+                        bound = self._buf('dzbound%d' % si, (1,))
+                        key = (self._fault_gen, self._weights_epoch)
+                        if self._dz_bound_key.get(si) != key:
+                            bound.zero_()
+                            ops.lstm_seq_bwd(da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp,
+                                             mask_u=BU, mode=self.lstm_mode, dz_absmax=zmx,
+                                             compact=cmp_now, **var)
+                            ops.lstm_dz_guard(zmx, bound, False)
+                            self._dz_bound_key[si] = key
+                            self._dz_measure_passes += 1
+                        rec['ws_b'] = ops.lstm_seq_bwd(
+                            da, U, rec['cell'], rec['gates'], None, T, n_pad, Hp, mask_u=BU,
+                            mode=self.lstm_mode, dz_absmax=zmx, compact=cmp_now,
+                            dz_planes=pdz_r, dz_bound=bound, **var)
+                        ops.lstm_dz_guard(zmx, bound, True)
+                    else:
+                        rec['ws_b'] = ops.lstm_seq_bwd(
+                            da, U, rec['cell'], rec['gates'], dz, T, n_pad, Hp, mask_u=BU,
+                            mode=self.lstm_mode, dz_absmax=zmx, compact=cmp_now, **var)
                     flush_side()    # previous layer's dW/dU/db now overlap this BPTT
                 y = rec['y']
                 hl = self._stage_packed(s)
-                pdz_r = None
-                if hl:
+                if hl and not planes_now:
                     # dz -> (rows, 8H) planes, once: dX reduces over their gate columns, the
                     # weight gradients over their rows (k_major); the scale is the BPTT kernel's
                     # own max|dz|

@@ -64,6 +64,18 @@ __device__ __forceinline__ float asr_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// The power-of-two pre-scale of the packed split-fp16 planes (asr_pack_hl; gemm.hip's
+// pow2_scale): 2^(9 - e) with max = f * 2^e, f in [0.5, 1), i.e. max * scale in [2^8, 2^9);
+// 1 for a null pointer or a zero maximum.
+__device__ __forceinline__ float asr_pow2_scale(const float* absmax) {
+  if (absmax == nullptr) return 1.f;
+  const unsigned b = __float_as_uint(*absmax);
+  const int e = (int)((b >> 23) & 0xff) - 126;
+  if ((b & 0x7fffffffu) == 0u) return 1.f;
+  int k = 9 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  return __uint_as_float((unsigned)(127 + k) << 23);
+}
 // The LSTM's `activation` hyper-parameter (core/layers.py:452, :463: g = act(z_c), h = o act(c);
 // asr_lstm_args.activation / asr_lstm_ln_args.activation, Keras-1.2.2 names): 0 tanh, 1 relu,
 // 2 sigmoid, 3 hard_sigmoid, 4 linear, 5 softsign, 6 softplus.  Only the VARIANT kernels

@@ -75,6 +75,7 @@ struct Plan {
   int R, P, TPW, NKK, prec;
   int n1;                  // 1: single-utterance forward kernel (2 chains = 2 directions)
   int form_c;              // 1: BPTT with the two-dimensional split (lstm_bwd_kernel_c)
+  int planes;              // 1: ... writing dz as packed planes (asr_lstm_args.dz_hl)
   size_t shm;
   size_t xchain_words;
   int chains_per_launch;
@@ -112,6 +113,7 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
   pl.NKK = 0;
   pl.n1 = 0;
   pl.form_c = 0;
+  pl.planes = 0;
   if (!bwd && a->n_valid == 1 && a->mode == 0 && (H == 256 || H == 512) &&
       !(a->mi || a->zone_c || a->zone_h || a->uh || a->activation)) {
     // one utterance: the tile-free exact-fp32 kernel (fwd_body_n1); 2 chains = 2 directions
@@ -214,7 +216,8 @@ int make_plan(const asr_lstm_args* a, bool bwd, Plan* out, kern_t* kout) {
         pl.shm = 2 * ((size_t)16 * 4 + (size_t)2 * 16 * 264 * 2);
         pl.xchain_words = (size_t)4 * 4 * (H / 64) * (H / 64) * 256;
         if (compact) pl.P = H / 32;
-        k = ASR_PICK(asr_lstm_pick_bwd_c(H, false, compact));
+        pl.planes = a->dz_hl != nullptr;
+        k = ASR_PICK(asr_lstm_pick_bwd_c(H, false, compact, pl.planes));
       } else if (wide) {
         k = ASR_PICK(asr_lstm_pick_bwd_x(H));
       } else {
@@ -300,7 +303,7 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
                 "lstm: need n_pad %% 16 == 0 and H %% 4 == 0 (T=%d n_pad=%d H=%d)", a->T,
                 a->n_pad, a->H);
   if (!bwd) ASR_CHECK_ARG(a->zx && a->y && a->cell && a->gates, "lstm fwd: null slab");
-  else ASR_CHECK_ARG(a->dy && a->dz && a->cell && a->gates, "lstm bwd: null slab");
+  else ASR_CHECK_ARG(a->dy && (a->dz || a->dz_hl) && a->cell && a->gates, "lstm bwd: null slab");
   const size_t need = asr_lstm_workspace_bytes(a, bwd ? 1 : 0);
   if (ws_bytes < need) {
     asr_set_error("lstm: workspace %zu < %zu bytes", ws_bytes, need);
@@ -319,6 +322,15 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   p.U = a->U; p.mask_u = a->mask_u; p.zx = a->zx; p.y = a->y; p.cell = a->cell;
   p.gates = a->gates; p.dy = a->dy; p.dz = a->dz;
   p.dz_absmax = bwd ? reinterpret_cast<unsigned*>(a->dz_absmax) : nullptr;
+  p.dz_hl = nullptr; p.dz_bound = nullptr; p.dz_scale_out = nullptr;
+  if (bwd && a->dz_hl) {
+    ASR_CHECK_ARG(pl.planes && a->dz_bound,
+                  "lstm bwd: dz_hl needs dz_bound and a kernel that writes planes "
+                  "(asr_lstm_dz_hl_supported): H=%d mode=%d", a->H, a->mode);
+    p.dz_hl = reinterpret_cast<_Float16*>(a->dz_hl);
+    p.dz_bound = a->dz_bound;
+    p.dz_scale_out = a->dz_scale_out;
+  }
   p.mi = a->mi; p.uh = a->uh; p.zone_c = a->zone_c; p.zone_h = a->zone_h;
   p.act = a->activation;
   ASR_CHECK_ARG(a->activation >= 0 && a->activation <= 6, "lstm: activation id %d not in 0..6", a->activation);
@@ -407,6 +419,42 @@ extern "C" size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward)
   if (!a || a->n_pad <= 0 || a->H <= 0) return 0;
   return kStickyBytes + kStatusBytes + xcc_bytes(a) + xbuf_bytes(a, backward != 0) +
          asr_align_up((size_t)4 * a->n_pad * a->H * sizeof(float), 256);
+}
+
+extern "C" int asr_lstm_dz_hl_supported(const asr_lstm_args* a) {
+  if (!a || a->n_pad <= 0 || a->H <= 0 || a->T <= 0) return 0;
+  asr_lstm_args q = *a;
+  int dummy = 0;
+  q.dz_hl = &dummy;                           // (the plan only looks at whether it is set)
+  Plan pl;
+  if (make_plan(&q, true, &pl, nullptr) != ASR_OK) return 0;
+  return pl.planes ? 1 : 0;
+}
+
+namespace {
+// asr_lstm_dz_guard: one thread; M = max * scale(bound)
+__global__ void lstm_dz_guard_kernel(const float* __restrict__ absmax, float* __restrict__ bound,
+                                     int planes_used, int* __restrict__ sticky) {
+  const float m = *absmax, b = *bound;
+  if (!(m > 0.f)) {                           // an all-zero pass (or NaN): nothing to learn
+    if (planes_used && m != m) atomicExch(sticky, 1);
+    return;
+  }
+  const bool finite = m < __builtin_huge_valf();
+  const float M = b > 0.f ? m * asr_pow2_scale(&b) : 0.f;
+  if (planes_used && (!finite || !(M >= 0.0625f && M <= 32768.f))) atomicExch(sticky, 1);
+  if (finite && !(M >= 4.f && M < 512.f)) *bound = 8.f * m;
+}
+}  // namespace
+
+extern "C" int asr_lstm_dz_guard(const float* dz_absmax, float* dz_bound, int planes_used,
+                                 void* bwd_workspace, asr_stream_t stream_) {
+  ASR_CHECK_ARG(dz_absmax && dz_bound && (bwd_workspace || !planes_used),
+                "lstm_dz_guard: null pointer");
+  hipLaunchKernelGGL(lstm_dz_guard_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, dz_absmax,
+                     dz_bound, planes_used, reinterpret_cast<int*>(bwd_workspace));
+  ASR_CHECK_LAUNCH();
+  return ASR_OK;
 }
 
 extern "C" int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,

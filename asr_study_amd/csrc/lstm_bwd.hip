@@ -706,8 +706,16 @@ __device__ __forceinline__ void mfma_settle(f32x4& am, f32x4& a1, f32x4& a2) {
 // half of the chip beside the BPTT of this one (engine.backward).  Same exchange layout
 // ([output tile][slice a][256 words]), same products; a (sample, unit)'s partial sums are added
 // in the same order, so the gate gradients are bit-identical to NBLK = 4.
-template <int OT, bool FAST, bool EXACT, int NBLK = 4>
+//
+// PL (asr_lstm_args.dz_hl): the gate gradients leave as the packed planes of asr_pack_hl instead
+// of the fp32 slab.  A thread's 16 values (4 units x 4 gates) are one (16 hi, 16 lo) group of
+// the plane row at the byte offset of its fp32 values: the same four 16-byte stores, other
+// contents -- and they ARE the LDS tile of the dz @ U^T products (hi = fp16(x s), lo = fp16(x s -
+// hi), s = the power of two of *dz_bound, known before the pass), so the per-sample scale (a DPP
+// row maximum, frexp / ldexp, the 1 / scale word in LDS) drops out of the dependent chain.
+template <int OT, bool FAST, bool EXACT, int NBLK = 4, bool PL = false>
 __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw, float* lds) {
+  static_assert(!(PL && EXACT), "planes are a split-fp16 format");
   constexpr int PA = 4 * OT;                       // reduction slices (H / 64)
   constexpr int KS = 8;                            // K-steps of 32 columns per slice
   constexpr int NTILE = 16 * OT / NBLK;            // output tiles of a workgroup
@@ -785,6 +793,12 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   bool dead = false;
   StepProf prof;
   prof.init(false);
+  float sc_g = 1.f, us_g = 1.f;                    // PL: the planes' scale and its inverse
+  if constexpr (PL) {
+    sc_g = asr_pow2_scale(p.dz_bound);
+    us_g = 1.f / sc_g;
+    if (p.dz_scale_out && blockIdx.x == 0 && tid == 0) *p.dz_scale_out = sc_g;
+  }
 
   // Slab values of the next TWO steps (sets A / B, used alternately, so that no register holding
   // a value still in flight is ever copied -- a copy is waited for on the spot): a step's values
@@ -813,7 +827,8 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   const float* ld_dy = p.dy + (size_t)tt0 * fr_dy;
   const float* ld_c = p.cell + (size_t)tt0 * fr_dy;                 // (cell rows are 2 H wide too)
   const float* ld_g = p.gates + (size_t)tt0 * fr_g;
-  float* st_dz = p.dz + (size_t)tt0 * fr_g;
+  // (PL: the plane row of a (frame, sample) starts at the byte offset of its fp32 row)
+  float* st_dz = (PL ? reinterpret_cast<float*>(p.dz_hl) : p.dz) + (size_t)tt0 * fr_g;
   // loads the slab values of step ss (the frame the ld_* bases point at), then advances them
   auto load_slabs = [&](int ss, Slabs& S) {
     const bool has_prev = ss + 1 < p.T;            // the sequence's first frame has c_prev = 0
@@ -914,6 +929,7 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     _Float16* dzh = reinterpret_cast<_Float16*>(sinv + 16);   // [16][DZS] hi
     _Float16* dzl = dzh + 16 * DZS;                           // [16][DZS] lo
     float z[4][4];
+    h8 pl_hi[2], pl_lo[2];                         // PL: the thread's plane group
     {
       const float dr[4] = {dh_rec.x, dh_rec.y, dh_rec.z, dh_rec.w};
       const float cm[4] = {cmask[0], cmask[1], cmask[2], cmask[3]};
@@ -940,6 +956,27 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<f32x4*>(row + 4 * j) = f32x4{z[j][0], z[j][1], z[j][2], z[j][3]};
+    } else if constexpr (PL) {
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(z[j][0]), fabsf(z[j][1])), fmaxf(fabsf(z[j][2]), fabsf(z[j][3]))));
+      zmax = fmaxf(zmax, m);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = z[j][e] * sc_g;
+          const _Float16 h = (_Float16)x;
+          pl_hi[j >> 1][4 * (j & 1) + e] = h;
+          pl_lo[j >> 1][4 * (j & 1) + e] = (_Float16)(x - (float)h);
+        }
+      _Float16* rh = dzh + n * DZS + 8 * q;       // (tile layout: see the scaled form below)
+      _Float16* rl = dzl + n * DZS + 8 * q;
+      *reinterpret_cast<h8*>(rh) = pl_hi[0];
+      *reinterpret_cast<h8*>(rh + 128) = pl_hi[1];
+      *reinterpret_cast<h8*>(rl) = pl_lo[0];
+      *reinterpret_cast<h8*>(rl + 128) = pl_lo[1];
     } else {
     // power-of-two scale of this sample's 256 columns: max over its 16 threads (one DPP row)
     float m = 0.f;
@@ -999,10 +1036,18 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
       // (no branch around them, so that the compiler can count them in its waits: the lanes
       // that do not own the row store beyond the resource's range, which the hardware drops)
       const __amdgpu_buffer_rsrc_t rz = rs(st_dz, fr_g);
+      if constexpr (PL) {
+        // [16 hi][16 lo] of reduction indices 16 q' .. (q' = the thread's group in the row)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_hi[0]), rz, vo_z, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_hi[1]), rz, vo_z, 16, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_lo[0]), rz, vo_z, 32, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_lo[1]), rz, vo_z, 48, 0);
+      } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4 zz = {z[j][0], z[j][1], z[j][2], z[j][3]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rz, vo_z, 16 * j, 0);
+      }
       }
     }
     st_dz += fstep * (long long)fr_g;
@@ -1051,7 +1096,9 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
         bh[kk] = *reinterpret_cast<const h8*>(dzh + nl * DZS + 128 * (g & 1) + 16 * kk + 8 * (g >> 1));
         bl[kk] = *reinterpret_cast<const h8*>(dzl + nl * DZS + 128 * (g & 1) + 16 * kk + 8 * (g >> 1));
       }
-      const float us = sinv[nl];
+      // (PL: the tile's lo halfs are NOT scaled by kLoScale -- the planes' convention -- while the
+      // U^T fragments' are: hi x lo joins hi x hi, lo x hi keeps the 1 / 2048)
+      const float us = PL ? us_g : sinv[nl];
       const float usl = us * (1.f / kLoScale);
       const unsigned wtag = (unsigned)(s >> 2) & 1u;
       // (the last step's tiles are published too: nobody reads them, and no branch is needed)
@@ -1062,7 +1109,8 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          o[e] = tag_word(__builtin_fmaf(a1[e] + a2[e], usl, am[e] * us), wtag);
+          o[e] = PL ? tag_word(__builtin_fmaf(a2[e], usl, (am[e] + a1[e]) * us), wtag)
+                    : tag_word(__builtin_fmaf(a1[e] + a2[e], usl, am[e] * us), wtag);
         // output tile w + 4 i of this block: 4 PA KB further on
         __builtin_amdgcn_raw_buffer_store_b128(o, wr, soff, i * (4 * PA * 1024), FAST ? 0 : kSc1);
       };
@@ -1163,7 +1211,7 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
   }
 }
 
-template <int OT, bool EXACT, int NBLK = 4>
+template <int OT, bool EXACT, int NBLK = 4, bool PL = false>
 __global__ void __launch_bounds__(kThreads)
 lstm_bwd_kernel_c(LstmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1171,8 +1219,8 @@ lstm_bwd_kernel_c(LstmParams p) {
   if (!map_block(p, unit_local, cw)) return;
   const int unit = p.chain_begin + unit_local;
   const bool fast = chain_on_one_xcd(p, unit, cw, reinterpret_cast<int*>(lds));
-  if (fast) bwd_body_c<OT, true, EXACT, NBLK>(p, unit, cw, lds);
-  else bwd_body_c<OT, false, EXACT, NBLK>(p, unit, cw, lds);
+  if (fast) bwd_body_c<OT, true, EXACT, NBLK, PL>(p, unit, cw, lds);
+  else bwd_body_c<OT, false, EXACT, NBLK, PL>(p, unit, cw, lds);
 }
 
 
@@ -1190,7 +1238,14 @@ asr_lstm_kern_t asr_lstm_pick_bwd_h(int tpw, bool variants) {
 asr_lstm_kern_t asr_lstm_pick_bwd_x(int H) {
   return H == 256 ? ASR_KERN(lstm_bwd_kernel_x<4>) : ASR_KERN(lstm_bwd_kernel_x<8>);
 }
-asr_lstm_kern_t asr_lstm_pick_bwd_c(int H, bool exact, bool compact) {
+asr_lstm_kern_t asr_lstm_pick_bwd_c(int H, bool exact, bool compact, bool planes) {
+  if (planes && !exact) {
+    if (compact)
+      return H == 256 ? ASR_KERN((lstm_bwd_kernel_c<1, false, 2, true>))
+                      : ASR_KERN((lstm_bwd_kernel_c<2, false, 2, true>));
+    return H == 256 ? ASR_KERN((lstm_bwd_kernel_c<1, false, 4, true>))
+                    : ASR_KERN((lstm_bwd_kernel_c<2, false, 4, true>));
+  }
   if (compact && !exact)
     return H == 256 ? ASR_KERN((lstm_bwd_kernel_c<1, false, 2>)) : ASR_KERN((lstm_bwd_kernel_c<2, false, 2>));
   if (H == 256) return exact ? ASR_KERN((lstm_bwd_kernel_c<1, true>)) : ASR_KERN((lstm_bwd_kernel_c<1, false>));

@@ -33,6 +33,9 @@ struct LstmParams {
   float* dz;
   float* dc_state;
   unsigned* dz_absmax;     // optional: max |dz| as float bits (atomicMax)
+  _Float16* dz_hl;         // BPTT, optional (bwd_body_c): dz as packed planes instead of the fp32
+  const float* dz_bound;   //   slab, pre-scaled by asr_pow2_scale(*dz_bound), which is written
+  float* dz_scale_out;     //   to *dz_scale_out (asr_lstm_args.dz_hl)
   // optional cell variants (core/layers.py:432-469); all NULL on the default path
   int act;                 // activation id of the cell candidate / output (variant kernels)
   const float* mi;         // (2, 4, 4H): alpha, beta1, beta2, bias per direction
@@ -276,4 +279,4 @@ asr_lstm_kern_t asr_lstm_pick_fwd_x(int H, bool exact, bool slab = false, bool e
 asr_lstm_kern_t asr_lstm_pick_fwd_n1(int H);                      // one utterance, H = 256 / 512
 asr_lstm_kern_t asr_lstm_pick_bwd_h(int tpw, bool variants);
 asr_lstm_kern_t asr_lstm_pick_bwd_x(int H);                       // unit split, H = 256 / 512
-asr_lstm_kern_t asr_lstm_pick_bwd_c(int H, bool exact, bool compact = false);   // two-dimensional split
+asr_lstm_kern_t asr_lstm_pick_bwd_c(int H, bool exact, bool compact = false, bool planes = false);   // two-dimensional split

@@ -250,10 +250,14 @@ def lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=None, mode=0, check=
 
 def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check=False,
                  dz_absmax=None, steps=None, mi=None, uh=None, zone_c=None, zone_h=None,
-                 wx=None, dwx=None, dmi=None, db_part=None, compact=False, act=0):
+                 wx=None, dwx=None, dmi=None, db_part=None, compact=False, act=0,
+                 dz_planes=None, dz_bound=None):
     """db_part: optional (n_pad/16, 2, 4H) buffer receiving the per-batch-tile sums of dz over
     samples and steps (bias-gradient partials; accumulated across the slices of a sequence).
-    compact: H/32 workgroups per chain (half the CUs per layer, asr_lstm_args.compact)."""
+    compact: H/32 workgroups per chain (half the CUs per layer, asr_lstm_args.compact).
+    dz_planes (HlPlanes of (T n_pad, 8H)) + dz_bound (device float): the gate gradients leave
+    as packed planes pre-scaled for *dz_bound INSTEAD of the fp32 slab `dz` (may be None then;
+    asr_lstm_args.dz_hl, see lstm_dz_hl_supported / lstm_dz_guard)."""
     lib = L.load()
     _check_f32(dy, U, cell, gates, dz, mask_u)
     a = _lstm_args(T, n_pad, H, U, mask_u, cell=cell, gates=gates, dy=dy, dz=dz, mode=mode,
@@ -261,12 +265,38 @@ def lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=None, mode=0, check
                    zone_h=zone_h, wx=wx, dwx=dwx, dmi=dmi, db_part=db_part, act=act)
     a.lds_reserve_kb = LSTM_LDS_KB
     a.compact = 1 if compact else 0
+    if dz_planes is not None:
+        assert dz_bound is not None and dz_planes.rows == T * n_pad and dz_planes.ld == 8 * H
+        a.dz_hl = dz_planes.hl.data_ptr()
+        a.dz_bound = dz_bound.data_ptr()
+        a.dz_scale_out = dz_planes.scale.data_ptr()
     nbytes = lib.asr_lstm_workspace_bytes(C.byref(a), 1)
     ws = WS.get('lstm_bwd', nbytes, dy.device)
     L.check(lib.asr_lstm_seq_bwd(C.byref(a), _ptr(ws), nbytes, _stream()), 'asr_lstm_seq_bwd')
     if check:
         L.check(lib.asr_lstm_status(_ptr(ws), _stream()), 'asr_lstm_status(bwd)')
     return ws
+
+
+def lstm_dz_hl_supported(T, n_pad, H, mode=0, compact=False, act=0):
+    """Whether lstm_seq_bwd would write packed planes for this geometry (asr_lstm_dz_hl_supported:
+    the plain cell on the two-dimensional-split BPTT kernels, persistent mode, split-fp16)."""
+    a = L.LstmArgs()
+    a.T, a.n_pad, a.H, a.mode = int(T), int(n_pad), int(H), int(mode)
+    a.compact = 1 if compact else 0
+    a.activation = activation_id(act)
+    a.lds_reserve_kb = LSTM_LDS_KB
+    return bool(L.load().asr_lstm_dz_hl_supported(C.byref(a)))
+
+
+def lstm_dz_guard(dz_absmax, dz_bound, planes_used, device=None):
+    """Device-side upkeep of a layer's dz bound behind a BPTT pass (asr_lstm_dz_guard): keeps or
+    renews *dz_bound from the measured *dz_absmax; with planes_used, a maximum outside the
+    planes' safe range raises the BPTT workspace's sticky flag (the step is vetoed and re-run)."""
+    ws = WS.get('lstm_bwd', 0, dz_absmax.device) if planes_used else None
+    L.check(L.load().asr_lstm_dz_guard(_ptr(dz_absmax), _ptr(dz_bound), 1 if planes_used else 0,
+                                       _ptr(ws) if ws is not None else None, _stream()),
+            'asr_lstm_dz_guard')
 
 
 def lstm_status(ws):

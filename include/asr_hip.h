@@ -50,7 +50,7 @@ const char* asr_last_error(void);
  * struct carries a size field).  A caller checks asr_version() == ASR_HIP_ABI_VERSION right
  * after loading the library (asr_study_amd/_lib.py does) and refuses a mismatch.
  * 100: rounds 1-4.  105: asr_lstm_args +compact +activation +fwd_units, asr_pack_args +mask2
- * +r2_hl, asr_lstm_ln_args +activation.  106: round 6. */
+ * +r2_hl, asr_lstm_ln_args +activation.  106: asr_lstm_args +dz_hl +dz_bound +dz_scale_out. */
 #define ASR_HIP_ABI_VERSION 106
 int asr_version(void);
 /* Device facts the host needs for sizing persistent grids (CU count etc). */
@@ -378,7 +378,34 @@ typedef struct asr_lstm_args {
   /* Slices of one sequence may differ (same exchange layout): the host runs the slice that    */
   /* has GEMMs beside it on the geometry that occupies fewer CUs.  Results do not depend on it. */
   int fwd_units;
+  /* backward, optional: dz_hl != NULL makes BPTT write the gate gradients as the PACKED PLANES  */
+  /* of asr_pack_hl ((T n_pad) rows x 8H reduction indices: row = frame * n_pad + sample, the    */
+  /* r-plane layout, ld = 8H) INSTEAD of the fp32 slab dz (which may then be NULL): a thread's   */
+  /* 16 gate gradients are exactly one (16 hi, 16 lo) group at the byte offset of its fp32       */
+  /* values, so the kernel stores the same 64 bytes either way and the separate pack pass over   */
+  /* dz (2.1 GB per layer at H = 512, 64 utterances) disappears.  The planes' power-of-two       */
+  /* scale must be known BEFORE the pass: it is asr_pack_hl's scale of *dz_bound (a device       */
+  /* float >= the max |dz| this call will produce, e.g. 8 x the previous training step's         */
+  /* maximum -- asr_lstm_dz_guard maintains it), written to *dz_scale_out for asr_gemm_hl.  The  */
+  /* kernel then also splits dz with THAT scale for its own dz @ U^T products (instead of a      */
+  /* per-sample scale): same 2^-22 product accuracy while max |dz| stays within                  */
+  /* [2^-11, 2^7] x bound.  Exists on the two-dimensional-split kernels only                    */
+  /* (asr_lstm_dz_hl_supported); dz_absmax and db_part work as before.                          */
+  void* dz_hl;
+  const float* dz_bound;
+  float* dz_scale_out;
 } asr_lstm_args;
+/* 1 if asr_lstm_seq_bwd would honour a->dz_hl for this geometry / mode / arithmetic, else 0.   */
+int asr_lstm_dz_hl_supported(const asr_lstm_args* a);
+/* Keeps a layer's *dz_bound in step with the measured *dz_absmax of the pass just enqueued     */
+/* (device-side, no synchronisation): with M = max * scale(bound), the bound is kept while M    */
+/* stays in [2^2, 2^9) (so that identical inputs see identical scales) and becomes 8 * max      */
+/* otherwise.  planes_used != 0: the pass wrote planes with this bound -- if M left             */
+/* [2^-4, 2^15] (fp16 overflow of the hi plane at 2^16, precision loss below) the sticky        */
+/* timeout flag of `bwd_workspace` is raised, i.e. the step is vetoed and re-run exactly like   */
+/* a step whose persistent kernel gave up (asr_lstm_status).                                    */
+int asr_lstm_dz_guard(const float* dz_absmax, float* dz_bound, int planes_used,
+                      void* bwd_workspace, asr_stream_t stream);
 size_t asr_lstm_workspace_bytes(const asr_lstm_args* a, int backward);
 int asr_lstm_seq_fwd(const asr_lstm_args* a, void* workspace, size_t ws_bytes,
                      asr_stream_t stream);

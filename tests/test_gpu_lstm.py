@@ -717,3 +717,127 @@ def test_single_utterance_forward_kernel(H):
     assert np.abs(yb[:, 0] - y1[:, 0]).max() < 5e-6 and np.abs(cb[:, 0] - c1[:, 0]).max() < 5e-6
     ys, cs, gs = run(1, [(0, 1), (1, 40), (41, 19)])
     assert np.array_equal(ys, y1) and np.array_equal(cs, c1) and np.array_equal(gs, g1)
+
+
+def _planes_to_float(pl, rows, cols):
+    """(hi + lo) / scale of packed planes -> float64 (rows, cols)."""
+    hi = pl.hi[:rows, :cols].double().cpu().numpy()
+    lo = pl.lo[:rows, :cols].double().cpu().numpy()
+    return (hi + lo) / float(pl.scale.item())
+
+
+@pytest.mark.parametrize('N,H,compact', [(64, 512, False), (64, 512, True), (16, 512, True),
+                                         (32, 256, True), (48, 256, False)])
+def test_bptt_writes_packed_planes_instead_of_the_fp32_slab(N, H, compact, monkeypatch):
+    """asr_lstm_args.dz_hl (lstm_bwd_kernel_c<.., PL>): BPTT stores the gate gradients as the
+    packed planes asr_pack_hl would make of them -- pre-scaled for a bound handed in BEFORE the
+    pass -- and uses that split for its own dz @ U^T products.  Against the fp32-slab kernel on the
+    same activations: planes == dz to 2^-21 of max|dz| (a split's resolution) + the recurrence's
+    own rounding differences (1e-6 of the maximum), for a tight bound (8 x max) and for bounds
+    256 x too large / 16 x too small; the scale word is asr_pack_hl's scale of the bound; max|dz|
+    and the bias partials agree; compact == default and sliced == whole bit for bit; the planes
+    feed asr_gemm_hl like packed ones (dz @ W^T against float64)."""
+    from asr_study_amd import ops
+    T = 45
+    rs = np.random.RandomState(11 * H + N + int(compact))
+    n_pad = ops.pad16(N)
+    dev = 'cuda:0'
+    zx = torch.from_numpy(rs.randn(T, n_pad, 2, 4 * H).astype(np.float32)).to(dev)
+    U = torch.from_numpy((rs.randn(2, H, 4 * H) / np.sqrt(H)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy((rs.randn(T, n_pad, 2 * H) * 0.03).astype(np.float32)).to(dev)
+    mask = torch.from_numpy(((rs.rand(2, n_pad, H) > 0.2) / 0.8).astype(np.float32)).to(dev)
+    y = torch.zeros(T, n_pad, 2 * H, device=dev)
+    cell = torch.zeros(T, n_pad, 2, H, device=dev)
+    gates = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    ops.lstm_status(ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H, mask_u=mask))
+    monkeypatch.setenv('ASR_LSTM_BWD_2D', '1')
+    assert ops.lstm_dz_hl_supported(T, n_pad, H, compact=compact)
+    assert not ops.lstm_dz_hl_supported(T, n_pad, H, mode=1)          # stepwise kernels: no
+    assert not ops.lstm_dz_hl_supported(T, n_pad, 100)                # any-H kernels: no
+    rows = T * n_pad
+
+    dz = torch.zeros(T, n_pad, 2, 4 * H, device=dev)
+    dbw = torch.zeros(n_pad // 16, 2, 4 * H, device=dev)
+    amw = torch.zeros(1, device=dev)
+    ops.lstm_status(ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, mask_u=mask,
+                                     dz_absmax=amw, db_part=dbw, compact=compact))
+    want = dz.double().cpu().numpy().reshape(rows, 8 * H)
+    zmax = float(amw.item())
+    assert zmax > 0 and abs(zmax - np.abs(want).max()) <= 1e-6 * zmax
+
+    def run(bound_value, ranges=(None,), cmp=compact):
+        pl = ops.HlPlanes(rows, 8 * H, dev)
+        pl.hl.fill_(3.0)
+        bound = torch.full((1,), bound_value, device=dev)
+        dbp = torch.full((n_pad // 16, 2, 4 * H), 9.0, device=dev)
+        am = torch.zeros(1, device=dev)
+        for r in ranges:
+            ws = ops.lstm_seq_bwd(dy, U, cell, gates, None, T, n_pad, H, mask_u=mask, dz_absmax=am,
+                                  steps=r, db_part=dbp, compact=cmp, dz_planes=pl, dz_bound=bound)
+        ops.lstm_status(ws)
+        return pl, dbp.cpu().numpy(), float(am.item())
+
+    for factor, tol in ((8.0, 2.0 ** -21), (2048.0, 2.0 ** -21), (1.0 / 16, 2.0 ** -21)):
+        pl, dbp, am = run(zmax * factor)
+        # the scale: asr_pack_hl's power of two of the BOUND
+        e = np.frexp(np.float32(zmax * factor))[1]
+        assert float(pl.scale.item()) == 2.0 ** (9 - e), (factor, pl.scale.item())
+        got = _planes_to_float(pl, rows, 8 * H)
+        err = np.abs(got - want).max()
+        assert err <= (tol + 1e-6) * zmax, (factor, err / zmax)
+        assert abs(am - zmax) <= 1e-6 * zmax
+        assert np.abs(dbp - dbw.cpu().numpy()).max() <= 2e-6 * max(1.0, np.abs(dbw.cpu().numpy()).max()) * T
+    pl, dbp, am = run(zmax * 8.0)
+    hl0 = pl.hl.cpu().numpy().copy()
+    # compact == default geometry, sliced == whole: bit for bit
+    other, dbo, amo = run(zmax * 8.0, cmp=not compact)
+    assert np.array_equal(other.hl.cpu().numpy(), hl0) and amo == am and np.array_equal(dbo, dbp)
+    sliced, _, ams = run(zmax * 8.0, ranges=[(0, 1), (1, 2), (3, 17), (20, 25)])
+    assert np.array_equal(sliced.hl.cpu().numpy(), hl0) and ams == am
+    # the planes as a GEMM operand: dx = dz @ W^T
+    K = 8 * H
+    W = (rs.randn(256, K) * 0.05).astype(np.float32)
+    Wd = torch.from_numpy(W).to(dev)
+    pw = ops.HlPlanes(256, K, dev)
+    ops.pack_hl(Wd, 256, K, absmax=ops.absmax(Wd), r=pw)
+    out = torch.zeros(rows, 256, device=dev)
+    ops.gemm_hl(pl, pw, out, rows, 256, K)
+    ref = want @ W.astype(np.float64).T
+    assert np.abs(out.double().cpu().numpy() - ref).max() <= 3e-6 * np.abs(ref).max()
+
+
+def test_dz_guard_keeps_renews_and_flags_the_bound():
+    """asr_lstm_dz_guard: M = max * scale(bound); the bound stays while M is in [2^2, 2^9) and
+    becomes 8 max otherwise; a pass that WROTE planes with a bound that let M leave
+    [2^-4, 2^15] raises the BPTT workspace's sticky flag (asr_lstm_status -> timeout -> the step is
+    vetoed and re-run); zero / measuring passes never flag."""
+    from asr_study_amd import ops
+    from asr_study_amd._lib import AsrHipError
+    dev = 'cuda:0'
+    ws = ops.WS.get('lstm_bwd', 4096, dev)
+    ops.lstm_status(ws)
+
+    def guard(m, b, used):
+        am = torch.full((1,), m, device=dev)
+        bd = torch.full((1,), b, device=dev)
+        ops.lstm_dz_guard(am, bd, used)
+        flagged = False
+        try:
+            ops.lstm_status(ws)
+        except AsrHipError:
+            flagged = True
+        return float(bd.item()), flagged
+    b0 = float(np.float32(8.0) * np.float32(0.01))
+    assert guard(0.01, 0.0, False) == (b0, False)                         # no bound yet -> 8 max
+    for m in (0.01, 0.0101, 0.02, 0.0014, 0.09):                          # inside the window: kept
+        assert guard(m, b0, True) == (b0, False), m
+    nb, fl = guard(1.0, b0, True)                                         # 100 x: renewed, not flagged
+    assert nb == 8.0 and not fl
+    nb, fl = guard(1e-4, b0, True)                                        # shrank 100 x: renewed
+    assert nb == np.float32(np.float32(8.0) * np.float32(1e-4)) and not fl
+    nb, fl = guard(0.01 * 2 ** 11, b0, True)                              # overflow range: flagged
+    assert fl and nb == b0 * 2 ** 11
+    assert guard(0.01 * 2 ** 11, b0, False)[1] is False                   # measuring pass: never
+    nb, fl = guard(0.01 * 2 ** -12, b0, True)                             # far below: flagged
+    assert fl
+    assert guard(0.0, b0, True) == (b0, False)                            # all-zero pass: untouched

@@ -471,7 +471,7 @@ def test_brsmv1_activation_hyper_parameter(act, layer_norm):
 
 
 @pytest.mark.parametrize('act', ['relu', 'linear'])
-def test_unbounded_activation_above_the_packed_planes_fixed_bound(act):
+def test_unbounded_activation_above_the_packed_planes_fixed_bound(act, monkeypatch):
     """with relu / linear h = o * act(c) is unbounded (c accumulates over the frames), so
     the packed operands built from y (next layer's x@W, dU) must MEASURE their bound instead of
     assuming |y| < 1 (pow2_scale(1) = 2^8: anything >= 256 would become an fp16 inf in the hi
@@ -480,6 +480,7 @@ def test_unbounded_activation_above_the_packed_planes_fixed_bound(act):
     from asr_study_amd.core import models
     rs = np.random.RandomState(23)
     N, T, F, C, H, L = 4, 21, 8, 6, 16, 2
+    monkeypatch.setenv('ASR_GEMM_PACKED', '1')           # ('auto' packs from 512 hidden units on)
     model = models.brsmv1(num_features=F, num_classes=C, num_hiddens=H, num_layers=L, dropout=0.0,
                           weight_decay=0.0, activation=act, seed=9)
     assert model.packed and all(model._stage_packed(s) for s in model.stages if s.kind == 'bilstm')
