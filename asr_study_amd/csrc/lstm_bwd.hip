@@ -1035,18 +1035,23 @@ __device__ __forceinline__ void bwd_body_c(const LstmParams& p, int unit, int cw
     {
       // (no branch around them, so that the compiler can count them in its waits: the lanes
       // that do not own the row store beyond the resource's range, which the hardware drops)
+      // NT (streaming) stores: written once, read by a later kernel -- without the hint the dirty
+      // dz lines displace the exchange slots from L2 and those are written back to HBM step after
+      // step (r6, PMC WRITE_SIZE per cfg3 layer 2.18 -> 1.59 GB, isolated step 2.07 -> 1.98 us;
+      // the same hint on the slab LOADS removes the rest of the excess -- 1.05 GB = dz alone -- but
+      // costs 0.3 us per step)
       const __amdgpu_buffer_rsrc_t rz = rs(st_dz, fr_g);
       if constexpr (PL) {
         // [16 hi][16 lo] of reduction indices 16 q' .. (q' = the thread's group in the row)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_hi[0]), rz, vo_z, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_hi[1]), rz, vo_z, 16, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_lo[0]), rz, vo_z, 32, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_lo[1]), rz, vo_z, 48, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_hi[0]), rz, vo_z, 0, kNt);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_hi[1]), rz, vo_z, 16, kNt);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_lo[0]), rz, vo_z, 32, kNt);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl_lo[1]), rz, vo_z, 48, kNt);
       } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4 zz = {z[j][0], z[j][1], z[j][2], z[j][3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rz, vo_z, 16 * j, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), rz, vo_z, 16 * j, kNt);
       }
       }
     }

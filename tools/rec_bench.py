@@ -2,7 +2,9 @@
 """Recurrent kernels in isolation at cfg2 / cfg3 shapes: us per step and, with the phase
 profiler (ASR_LSTM_DBG=32), shader clocks per phase and wave of workgroup 0.
 
-    python tools/rec_bench.py cfg3 [--fwd] [--bwd] VAR=VALUE[,VAR=VALUE...] ...
+    python tools/rec_bench.py cfg3 [--fwd] [--bwd] [--planes] VAR=VALUE[,VAR=VALUE...] ...
+
+--planes: BPTT writes dz as packed planes (asr_lstm_args.dz_hl) with a bound of 8 x max|dz|.
 
 Each positional VAR=VALUE group is one variant (environment switches read per launch by
 csrc/lstm.hip: ASR_LSTM_BWD_2D, ASR_LSTM_PROG, ASR_LSTM_FAST ...); 'base' = no switch."""
@@ -59,6 +61,12 @@ def main():
         ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H)
         ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H)
     torch.cuda.synchronize()
+    planes = bound = None
+    if '--planes' in sys.argv:
+        amax = torch.zeros(1, device=dev)
+        ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, dz_absmax=amax)
+        bound = amax * 8.0
+        planes = ops.HlPlanes(T * n_pad, 8 * H, dev)
     base_env = dict(os.environ)
     for var in variants:
         os.environ.clear()
@@ -69,7 +77,9 @@ def main():
                 os.environ[k] = v
         for kind, on, fn, wsn in (
                 ('fwd', do_f, lambda: ops.lstm_seq_fwd(zx, U, y, cell, gates, T, n_pad, H), 'lstm_fwd'),
-                ('bwd', do_b, lambda: ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H), 'lstm_bwd')):
+                ('bwd', do_b, lambda: ops.lstm_seq_bwd(
+                    dy, U, cell, gates, dz, T, n_pad, H, dz_planes=planes if planes is not None and
+                    ops.lstm_dz_hl_supported(T, n_pad, H) else None, dz_bound=bound), 'lstm_bwd')):
             if not on:
                 continue
             os.environ.pop('ASR_LSTM_DBG', None)
