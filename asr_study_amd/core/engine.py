@@ -936,17 +936,26 @@ class Model(object):
 
         # ASR_AR_OVERLAP: auto (default) = per-layer asynchronous all-reduces beside the BPTT of
         # the layers below ONLY while a recurrence leaves CUs free (cfg2: 64 of 256).  Where a
-        # recurrence fills the chip (cfg3) its spin-waiting workgroups must all be resident, and
-        # an RCCL kernel that takes CUs first stalls the whole chain: there the gradients are
-        # reduced by ONE collective over the flat buffer after BPTT (110.6 MB: 0.6-2.5 ms of a
-        # ~50 ms step).  1 = always overlap, 0 = never.  The decision must be the SAME on every
+        # recurrence fills the chip with no compact schedule (ASR_BPTT_COMPACT=0) its
+        # spin-waiting workgroups must all be resident, and an RCCL kernel that takes CUs first
+        # stalls the whole chain: there the gradients are reduced by ONE collective over the flat
+        # buffer after BPTT (110.6 MB: 0.6-2.5 ms of a ~40 ms step).  1 = always overlap, 0 = never.  The decision must be the SAME on every
         # rank (mismatched collective sequences hang RCCL): it is taken on the rank-invariant
         # reference shard pad16(ceil(n_global / world)), never on this rank's own n_pad -- the
         # shards of a ragged last batch differ by one utterance and can straddle a multiple of 16.
+        # Round 6: the COMPACT backward schedule leaves half of the CUs to the side stream during
+        # every BPTT below the top layer, so the same per-layer collectives run there too: layer
+        # l + 1's bucket goes out on the communicator's stream once its weight-gradient GEMMs have
+        # finished on the side stream, i.e. beside the compact BPTT of layer l - 1 (the top
+        # layer's chip-filling BPTT comes first and has no collective beside it); what is left
+        # for the end of the step is the bottom layer + Dense + the flag slots.  compact_any is
+        # a function of the reference shard as well.
         ar_mode = os.environ.get('ASR_AR_OVERLAP', 'auto')
+        n_ref = self._ar_ref_pad if self._ar_ref_pad else n_pad
+        compact_any = any(self._bptt_compact(st, n_ref) for st in self.stages)
         reduce_now = (self._dist_active() and ar_mode != '0'
-                      and (ar_mode == '1' or not self._recurrence_fills_chip(
-                          self._ar_ref_pad if self._ar_ref_pad else n_pad)))
+                      and (ar_mode == '1' or not self._recurrence_fills_chip(n_ref)
+                           or compact_any))
         self._ar_covered = []
         self._ar_decision = reduce_now
 
@@ -975,8 +984,6 @@ class Model(object):
         # are made to (compact BPTT geometry, cfg3)
         # (decided, like the collective schedule, on the RANK-INVARIANT reference shard: every
         # rank then walks the same branches below, whatever its own shard of a ragged batch)
-        n_ref = self._ar_ref_pad if self._ar_ref_pad else n_pad
-        compact_any = any(self._bptt_compact(st, n_ref) for st in self.stages)
         overlap = self.overlap or compact_any
         self._compact_launches = 0
         # split-K of the weight-gradient GEMMs that run beside a compact BPTT: sized to the CUs

@@ -6,9 +6,10 @@ data-parallel step at world size W on real GPUs.  Prints ONE line ``RESULT {json
      by 1 / N_global), the flat buffer is summed by the step's own all-reduce (asr_comm_*: RCCL
      through the C ABI) -- and must equal the gradient of the WHOLE batch computed by the same
      process without any collective (1e-6 of the maximum).
-  2. cfg3 width (BiLSTM(512), 64 utterances per rank: the recurrence fills the chip): no
-     collective is issued during BPTT (one flat all-reduce behind it), no recurrent-kernel
-     timeout, no fallback, on any rank.
+  2. cfg3 width (3 x BiLSTM(512), 64 utterances per rank: the recurrence fills the chip, the
+     backward pass runs the compact schedule): the buckets of the two layers above the bottom
+     one are all-reduced beside the compact BPTTs below them (r6), no recurrent-kernel timeout,
+     no fallback, on any rank.
 Runs at W = 1 too (ASR_FORCE_ALLREDUCE=1: the collective is an identity, the code path is the
 same), which is what a single-GPU box exercises."""
 import json
@@ -66,16 +67,22 @@ def main():
                           for r in range(world)]
 
     # ---- 2. chip-filling width: one collective behind BPTT, no timeout on any rank
-    big = models.brsmv1(num_features=16, num_classes=7, num_hiddens=512, num_layers=2,
+    big = models.brsmv1(num_features=16, num_classes=7, num_hiddens=512, num_layers=3,
                         dropout=0.0, seed=1, device=dev)
     big.compile(optimizer=optimizers.Adam(lr=1e-3, clipnorm=400))
     rb = np.random.RandomState(10 + rank)
     xb = rb.randn(64, 40, 16).astype(np.float32)
     lb = [rb.randint(0, 6, size=3).tolist() for _ in range(64)]
+    covered = []
+    orig = big._allreduce
+    def counting():
+        covered.append(len(big._ar_covered))
+        return orig()
+    big._allreduce = counting
     for _ in range(3):
         m = big.train_on_batch(parallel.ShardedBatch([xb, lb, [40] * 64], 64 * world, 64))
     flags = float(ops.lstm_timeout_flags(dev).ne(0).sum().item()) + float(big.fallbacks)
-    t = torch.tensor([flags, 1.0, float(bool(big._ar_decision))], dtype=torch.float32, device=dev)
+    t = torch.tensor([flags, 1.0, float(covered[-1])], dtype=torch.float32, device=dev)
     parallel.grad_comm(dev).allreduce_sum_(t)
     out['timeouts_or_fallbacks_any_rank'] = float(t[0].item())
     out['ranks_seen_by_rccl'] = int(t[1].item())

@@ -75,15 +75,34 @@ xb = rs.randn(64, 6, 16).astype(np.float32)
 lb = [rs.randint(0, 6, size=2).tolist() for _ in range(64)]
 big.loss_and_grads(big.to_slab(xb), lb, [6] * 64, training=False)
 out["layers_reduced_during_bptt_auto_chipfill"] = len(big._ar_covered)
+out["compact_launches_chipfill"] = big._compact_launches
+g_layerwise = big.grads.clone()
+# ... and none without the compact schedule (every BPTT fills the chip: one collective behind them)
+big._compact_mode = "0"
+big.loss_and_grads(big.to_slab(xb), lb, [6] * 64, training=False)
+out["layers_reduced_during_bptt_auto_chipfill_serial"] = len(big._ar_covered)
+big._allreduce()
+torch.cuda.synchronize()
+g_single = big.grads.clone()
+big._compact_mode = "auto"
+big.loss_and_grads(big.to_slab(xb), lb, [6] * 64, training=False)
+big._allreduce()
+torch.cuda.synchronize()
+out["chipfill_layerwise_equals_single_collective"] = bool(torch.equal(big.grads, g_single))
+big._compact_mode = "0"
 # the decision is taken on the rank-invariant reference shard pad16(ceil(n_global / world)),
 # not on this rank's own n_pad: a 48-row local shard of a global batch whose reference shard
-# pads to 64 rows (fills the chip) must NOT start per-layer collectives (ADVICE r3)
+# pads to 64 rows (fills the chip; compact schedule off) must NOT start per-layer collectives
+# (ADVICE r3)
 x48 = rs.randn(48, 6, 16).astype(np.float32)
 l48 = [rs.randint(0, 6, size=2).tolist() for _ in range(48)]
 big.loss_and_grads(big.to_slab(x48), l48, [6] * 48, training=False, n_global=49, n_ref=49)
 out["layers_reduced_ragged_ref64_local48"] = len(big._ar_covered)
 big.loss_and_grads(big.to_slab(x48), l48, [6] * 48, training=False, n_global=48, n_ref=48)
 out["layers_reduced_ragged_ref48_local48"] = len(big._ar_covered)
+big._compact_mode = "auto"
+big.loss_and_grads(big.to_slab(x48), l48, [6] * 48, training=False, n_global=49, n_ref=49)
+out["layers_reduced_ragged_ref64_local48_compact"] = len(big._ar_covered)
 from asr_study_amd import parallel
 out["collectives_through_capi"] = parallel.CapiComm.get().calls
 # the veto of an update is collective: the flags travel behind the gradients through the
@@ -136,7 +155,17 @@ def test_layerwise_allreduce_overlap_equals_single_allreduce():
     assert res['layers_reduced_during_bptt_noside'] == 2
     assert res['layers_reduced_during_bptt_noside0'] == 0
     assert res['layers_reduced_during_bptt_auto_small'] == 2
-    assert res['layers_reduced_during_bptt_auto_chipfill'] == 0
+    # chip-filling recurrences (3 x BiLSTM(512), batch 64): with the compact backward schedule
+    # (r6) the buckets of the two layers above the bottom one go out beside the compact BPTTs
+    # below them; with ASR_BPTT_COMPACT=0 every BPTT fills the chip and there is ONE collective
+    # behind them; the reduced gradients are bit-equal either way
+    assert res['compact_launches_chipfill'] == 2
+    assert res['layers_reduced_during_bptt_auto_chipfill'] == 2
+    assert res['layers_reduced_during_bptt_auto_chipfill_serial'] == 0
+    assert res['chipfill_layerwise_equals_single_collective']
+    # (the reference shard decides, not the local one: a 48-row shard of a batch whose reference
+    # shard fills the chip follows the chip-filling schedule of the other ranks)
+    assert res['layers_reduced_ragged_ref64_local48_compact'] == 2
     assert res['veto_slots'] == [0.0, 1.0, 0.0, 0.0] and res['veto_params_unchanged']
     assert res['veto_metrics_none'] and res['veto_state'] == [1, 1, 0] and res['veto_recovered']
 
