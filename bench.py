@@ -493,8 +493,10 @@ def compact_line(detail, limit=LINE_LIMIT):
 
 
 def emit(detail, stream_out=None, stream_err=None):
-    """Writes the DETAIL object to bench_detail.json (+ gpurun_out/), echoes it on stderr, and
-    prints the compact line as the LAST thing on stdout."""
+    """Writes the DETAIL object to bench_detail.json (+ gpurun_out/), names that file on stderr
+    (ONE short line: a reader that keeps only a tail of stdout + stderr together must still find
+    the whole compact line in it; ASR_BENCH_ECHO_DETAIL=1 echoes the detail object there as
+    well) and prints the compact line as the LAST thing on stdout."""
     stream_out = stream_out or sys.stdout
     stream_err = stream_err or sys.stderr
     path = os.environ.get('ASR_BENCH_DETAIL', os.path.join(ROOT, 'bench_detail.json'))
@@ -509,7 +511,10 @@ def emit(detail, stream_out=None, stream_err=None):
                 f.write(text + '\n')
         except OSError:
             pass
-    print('bench detail: ' + text, file=stream_err)
+    if os.environ.get('ASR_BENCH_ECHO_DETAIL') == '1':
+        print('bench detail: ' + text, file=stream_err)
+    else:
+        print('bench detail: %d bytes in %s' % (len(text), ', '.join(paths)), file=stream_err)
     stream_err.flush()
     line = json.dumps(compact_line(detail))
     assert len(line) < 8192
