@@ -351,3 +351,97 @@ def test_gemm_hl_k_major_matches_float64(M, N, K, sk, tile):
     want = 0.75 * (As.T @ Bs) + 0.5 * C0
     err = report('gemm_hl k_major %dx%dx%d sk=%s tile=%d' % (M, N, K, sk, tile), Cd.cpu().numpy(), want)
     assert err < 2e-6 * np.abs(A).max() * np.abs(B).max() * K + 2e-5
+
+
+@pytest.mark.parametrize('M,N,K,opts', [
+    (8192, 4352, 160, 'plain'),           # 32 x 17 interior tiles, the shortest K loop (5 slabs)
+    (8292, 4200, 328, 'plain'),           # edge tiles in both directions, K tail of 8
+    (16384, 2304, 1024, 'bias'),          # x@W form
+    (8292, 4200, 256, 'mask'),            # dX form: old C, row mask, alpha / beta
+    (8192, 4352, 192, 'view'),            # output = a column range of a wider matrix (ldc > N)
+])
+def test_gemm_hl_persistent_form_is_bit_identical(M, N, K, opts, monkeypatch):
+    """gemm_hlp_kernel (round 6: one workgroup per CU walks the output tiles, the K loop runs on
+    into the next tile, dynamic per-XCD tile hand-out) against gemm_hlx_kernel
+    (ASR_GEMM_PERSIST=0): same planes, same products in the same order -> every output bit equal;
+    launched four times in a row (the control block re-arms itself) and against float64."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    A = rs.randn(M, K).astype(np.float32)
+    B = (rs.randn(K, N) * 0.05).astype(np.float32)
+    pa = ops.HlPlanes(M, K, 'cuda:0')
+    pb = ops.HlPlanes(N, K, 'cuda:0')
+    Ad, Bd = to_dev(A), to_dev(B)
+    ops.pack_hl(Ad, M, K, absmax=ops.absmax(Ad), r=pa)
+    ops.pack_hl(Bd, K, N, absmax=ops.absmax(Bd), c=pb)
+    ldc = N + 64 if opts == 'view' else N
+    C0 = rs.randn(M, ldc).astype(np.float32)
+    bias = to_dev(rs.randn(N).astype(np.float32))
+    cm_h = ((rs.rand(16, N) > 0.3) / 0.7).astype(np.float32)
+    cm = to_dev(cm_h)
+    kw = {}
+    if opts == 'bias':
+        kw = dict(bias=bias)
+    elif opts == 'mask':
+        kw = dict(alpha=0.75, beta=0.5, bias=bias, c_scale=cm, c_scale_period=16)
+    elif opts == 'view':
+        kw = dict(c_off=32, ldc=ldc)
+
+    def run(persist, reps=1):
+        monkeypatch.setenv('ASR_GEMM_PERSIST', persist)
+        outs = []
+        for _ in range(reps):
+            Cd = to_dev(C0)
+            ops.gemm_hl(pa, pb, Cd, M, N, K, **kw)
+            torch.cuda.synchronize()
+            outs.append(Cd)
+        return outs
+    plain = run('0')[0]
+    pers = run('1', reps=4)
+    for o in pers:
+        assert torch.equal(o, plain)
+    got = plain.cpu().numpy()
+    Aw, Bw = A.astype(np.float64), B.astype(np.float64)
+    if opts == 'mask':
+        want = (0.75 * (Aw @ Bw) + bias.cpu().numpy()) * cm_h[np.arange(M) % 16] + 0.5 * C0
+    elif opts == 'view':
+        prod = Aw @ Bw
+        for r in range(0, M, 997):                                    # sampled rows
+            assert np.abs(got.reshape(-1)[32 + r * ldc:32 + r * ldc + N] - prod[r]).max() < \
+                2e-6 * np.abs(A).max() * np.abs(B).max() * K + 2e-5
+        # nothing outside the view was touched
+        keep = np.ones(M * ldc, bool)
+        for r in range(M):
+            keep[32 + r * ldc:32 + r * ldc + N] = False
+        assert np.array_equal(got.reshape(-1)[keep], C0.reshape(-1)[keep])
+        return
+    else:
+        want = Aw @ Bw + (bias.cpu().numpy() if opts == 'bias' else 0.0)
+    assert np.abs(got - want).max() < 2e-6 * np.abs(A).max() * np.abs(B).max() * K + 2e-5
+
+
+def test_gemm_hl_persistent_launches_on_two_streams_do_not_share_a_control_block(monkeypatch):
+    """Two persistent launches in flight at once (two streams) take different control blocks of
+    the ring: both results equal the plain kernel's."""
+    from asr_study_amd import ops
+    M, N, K = 8192, 4352, 512
+    rs = np.random.RandomState(5)
+    Ad = to_dev(rs.randn(M, K).astype(np.float32))
+    Bd = to_dev((rs.randn(K, N) * 0.05).astype(np.float32))
+    pa = ops.HlPlanes(M, K, 'cuda:0')
+    pb = ops.HlPlanes(N, K, 'cuda:0')
+    ops.pack_hl(Ad, M, K, absmax=ops.absmax(Ad), r=pa)
+    ops.pack_hl(Bd, K, N, absmax=ops.absmax(Bd), c=pb)
+    monkeypatch.setenv('ASR_GEMM_PERSIST', '0')
+    want = torch.empty((M, N), dtype=torch.float32, device='cuda:0')
+    ops.gemm_hl(pa, pb, want, M, N, K)
+    torch.cuda.synchronize()
+    monkeypatch.setenv('ASR_GEMM_PERSIST', '1')
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [torch.zeros((M, N), dtype=torch.float32, device='cuda:0') for _ in range(6)]
+    for i, o in enumerate(outs):
+        with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+            ops.gemm_hl(pa, pb, o, M, N, K)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, want)
