@@ -210,36 +210,40 @@ class DatasetIterator(Iterator):
         return batch_inputs, batch_inputs_len
 
     def _make_out(self, labels, batch_size=None):
-        if self.labels is None or self.mode == 'predict':
+        """The batch's label sequences as ONE sparse int32 matrix (utterance, position) -> class
+        id, the form Keras's sparse CTC input takes (datasets/dataset_generator.py:237-251);
+        None when the iterator has no labels to give (no label set, or predict mode)."""
+        if self.mode == 'predict' or self.labels is None:
             return None
-        if self.label_parser is not None:
-            labels = [self.label_parser(l) for l in labels]
-        rows, cols, data = [], [], []
-        for row, label in enumerate(labels):
-            cols.extend(range(len(label)))
-            rows.extend(len(label) * [row])
-            data.extend(label)
-        return scipy.sparse.coo_matrix((data, (rows, cols)), dtype='int32')
+        seqs = list(labels) if self.label_parser is None else [self.label_parser(l) for l in labels]
+        lens = np.fromiter((len(q) for q in seqs), dtype=np.int64, count=len(seqs))
+        # COO coordinates built with array arithmetic: entry k of utterance u sits at (u, k)
+        utt = np.repeat(np.arange(len(seqs)), lens)
+        first = np.cumsum(lens) - lens                       # index of every utterance's entry 0
+        pos = np.arange(int(lens.sum())) - np.repeat(first, lens)
+        ids = np.fromiter((c for q in seqs for c in q), dtype=np.int64, count=int(lens.sum()))
+        return scipy.sparse.coo_matrix((ids, (utt, pos)), dtype='int32')
 
 
 class H5Iterator(DatasetIterator):
-    """datasets/dataset_generator.py:254-277."""
+    """An iterator over one split of the HDF5 layout extras/make_dataset.py writes: the group's
+    'inputs' / 'labels' / 'durations' datasets; stored features are flat rows whose width the
+    'num_feats' attribute of 'inputs' gives (datasets/dataset_generator.py:254-277)."""
 
     def __init__(self, h5group, **kwargs):
-        inputs = h5group['inputs']
-        labels = h5group['labels']
         if kwargs.get('label_parser') is None:
             raise ValueError("label_parser must be set")
-        self.num_feats = None
-        if 'num_feats' in inputs.attrs.keys():
-            self.num_feats = int(inputs.attrs['num_feats'])
+        feats = h5group['inputs']
+        width = feats.attrs['num_feats'] if 'num_feats' in feats.attrs.keys() else None
+        self.num_feats = None if width is None else int(width)
         self.durations = h5group['durations']
-        super(H5Iterator, self).__init__(inputs, labels, **kwargs)
+        super(H5Iterator, self).__init__(feats, h5group['labels'], **kwargs)
 
     def _make_in(self, inputs, batch_size=None):
-        if self.num_feats is not None:
-            inputs = [np.asarray(i).reshape((-1, self.num_feats)) for i in inputs]
-        return super(H5Iterator, self)._make_in(inputs)
+        if self.num_feats is None:
+            return super(H5Iterator, self)._make_in(inputs)
+        rows = [np.asarray(flat).reshape((-1, self.num_feats)) for flat in inputs]
+        return super(H5Iterator, self)._make_in(rows)
 
 
 class _NpzData(_ListData):

@@ -66,6 +66,20 @@ def logit_frames(T):
     return np.unique(np.round(np.linspace(0, T - 1, LOGIT_FRAMES)).astype(np.int64))
 
 
+GRAD_BLOCK = 256           # gradient checksums: sums over this many contiguous flat entries
+
+
+def grad_block_sums(flat):
+    """Sums over GRAD_BLOCK contiguous entries of a flattened gradient tensor (tail block zero
+    padded), float64: EVERY entry of every tensor enters one checksum, so a wrong stripe that
+    1000 random probes in 27.6 M entries can miss moves a block sum (VERDICT r5 next #6)."""
+    flat = np.asarray(flat, np.float64).reshape(-1)
+    nb = (flat.size + GRAD_BLOCK - 1) // GRAD_BLOCK
+    pad = np.zeros(nb * GRAD_BLOCK, np.float64)
+    pad[:flat.size] = flat
+    return pad.reshape(nb, GRAD_BLOCK).sum(axis=1)
+
+
 def grad_sample_index(i, size):
     """Flat indices of the sampled entries of gradient tensor number i."""
     rs = np.random.RandomState(9000 + i)

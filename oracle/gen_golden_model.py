@@ -15,8 +15,8 @@ here) -- these fixtures pin the HIP path on the oracle, not the oracle on the re
 
 Per case the fixture keeps: the logits of 50 frames spread over T for every utterance; the
 per-utterance CTC loss; every frame's argmax and top-1/top-2 margin (float64 oracle) and
-the greedy decode; per gradient tensor its L2 norm, max |g| and 1000 sampled entries
-(gradient of mean_n ctc_n, no l2 term); layer-1 and layer-L hidden / cell states of the
+the greedy decode; per gradient tensor its L2 norm, max |g|, 1000 sampled entries and
+(r6) the sums over every block of 256 contiguous entries (gradient of mean_n ctc_n, no l2 term); layer-1 and layer-L hidden / cell states of the
 first 8 utterances at t in {0, 1, T/2, T-2, T-1}; 64 probe values of the input features.
 
     python oracle/gen_golden_model.py [case ...]
@@ -108,6 +108,9 @@ def run(name):
         idx = FC.grad_sample_index(i, flat.size)
         fix['g%02d_samples' % i] = flat[idx]
         fix['g%02d_stats' % i] = np.array([np.sqrt(np.sum(flat ** 2)), np.abs(flat).max()])
+        # every entry in one checksum: sums over FC.GRAD_BLOCK contiguous entries (float32 is
+        # 6e-8 relative: far below the 1e-4 max|g| the test allows per entry)
+        fix['g%02d_blocks' % i] = FC.grad_block_sums(flat).astype(np.float32)
     fix['grad_names'] = np.array([n for n, _ in glist])
     sf = FC.state_frames(T)
     for li in (0, L - 1):

@@ -11,6 +11,8 @@ products) and under ASR_LSTM_PREC=0 ASR_GEMM_PREC=0 (exact fp32 MFMA):
   layer-1 / layer-5 h and c at t in {0,1,T/2,T-2,T-1}      atol 1e-4
   per-utterance CTC loss                                    rtol 1e-4
   1000 sampled entries of every gradient tensor             atol 1e-4 * max|g| of the tensor
+  sums over every 256 contiguous gradient entries (r6:      atol 16e-4 * max|g|
+      EVERY entry of every tensor is in one checksum)
   every gradient tensor's L2 norm                           rtol 1e-3
   per-frame argmax (the greedy decoder's decision)          EXACT on every frame the oracle
       decides by more than 2e-4 (twice the activation tolerance; with random-init weights
@@ -110,7 +112,7 @@ def _check(name):
     names = [str(n) for n in fix['grad_names']]
     got = model.get_gradients()
     assert len(got) == len(names)
-    worst = 0.0
+    worst, worst_b, nblocks = 0.0, 0.0, 0
     for i, (gname, g) in enumerate(zip(names, got)):
         flat = np.asarray(g, np.float64).reshape(-1)
         want = fix['g%02d_samples' % i]
@@ -119,8 +121,20 @@ def _check(name):
         worst = max(worst, err / max(gmax, 1e-30))
         assert err < 1e-4 * gmax + 1e-9, (gname, err, gmax)
         assert abs(np.sqrt(np.sum(flat ** 2)) - norm) < 1e-3 * norm + 1e-9, gname
-    print('[parity] %-28s worst sampled-gradient error = %.3e x max|g| over %d tensors'
-          % (name, worst, len(names)))
+        # EVERY entry: sums over blocks of 256 contiguous entries against the oracle's (a
+        # per-entry error e moves a block sum by at most 256 e, by ~ sqrt(256) e when the errors
+        # are independent: the bound below is the latter at e = 1e-4 max|g|, so one wrong entry
+        # of 1.6e-3 max|g|, or a wrong stripe, fails it)
+        bs = FC.grad_block_sums(flat)
+        wantb = fix['g%02d_blocks' % i].astype(np.float64)
+        assert bs.shape == wantb.shape, gname
+        berr = np.abs(bs - wantb).max()
+        worst_b = max(worst_b, berr / max(gmax, 1e-30))
+        assert berr < 1e-4 * gmax * np.sqrt(FC.GRAD_BLOCK) + 1e-9, (gname, berr, gmax)
+        nblocks += bs.size
+    print('[parity] %-28s worst sampled-gradient error = %.3e x max|g| over %d tensors; worst '
+          'block-sum error = %.3e x max|g| over %d blocks of %d (every entry)'
+          % (name, worst, len(names), worst_b, nblocks, FC.GRAD_BLOCK))
     # decoder decisions
     am = np.argmax(lg, axis=-1)
     valid = np.arange(T)[:, None] < np.asarray(lens_out)[None, :]
