@@ -498,10 +498,36 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
     }
   };
 
+  // factors of one step that do not depend on the recurrent gradient (r6: computed from the
+  // slab values prefetched a step ahead WHILE the gather is in flight, as bwd_body_c does; they
+  // used to sit behind the await, ~200 clocks of the step's dependent chain):
+  //   dz_o = dh A_o ; dcc = dc + dh B ; dz_{i,f,g} = dcc C_{i,f,g} ; dc' = dcc gf
+  struct Pre { float dy, Ao, B, Ci, Cf, Cg, gf; };
+  auto precompute = [&](int x) -> Pre {
+#pragma clang fp contract(off)
+    const float4 gt = nx_g[x];
+    const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
+    const float tch = fast_tanh(nx_c[x]);
+    Pre r;
+    r.dy = nx_dy[x];
+    r.Ao = tch * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
+    r.B = go * __builtin_fmaf(-tch, tch, 1.f);
+    r.Ci = gg * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
+    r.Cf = nx_cp[x] * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
+    r.Cg = gi * __builtin_fmaf(-gg, gg, 1.f);
+    r.gf = gf;
+    // keep all of it AHEAD of the await (the compiler would sink it to its uses behind the
+    // polling loop, i.e. back onto the critical path)
+    asm volatile("" : "+v"(r.dy), "+v"(r.Ao), "+v"(r.B), "+v"(r.Ci), "+v"(r.Cf), "+v"(r.Cg),
+                 "+v"(r.gf));
+    return r;
+  };
+
   // everything of one step of tile x after its recurrent gradient dh_rec is known: cell
   // gradient, dz slab + LDS tile, barrier, partial dh tiles = U^T-slice x dz, publish.
   // ISSUE: whether the gather of this tile's partial tiles of step os is issued on the way.
-  auto tail = [&](auto xc, auto issue_c, int s, float dh_rec, int os) {
+  auto tail = [&](auto xc, auto issue_c, int s, const Pre& pre, float dh_rec, int os) {
+#pragma clang fp contract(off)
     constexpr int x = decltype(xc)::value;
     constexpr bool ISSUE = decltype(issue_c)::value;
     float* sinv = lds + (size_t)(s & 1) * kTileFloats;        // [16] 1/scale
@@ -509,21 +535,15 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
     _Float16* dzl = dzh + 16 * DZH;                           // [16][DZH] lo
     const int t = dir == 0 ? p.T - 1 - s : s;
     {
-      const float4 gt = nx_g[x];
-      const float dyv = nx_dy[x], cv = nx_c[x], cpv = nx_cp[x];
       load_slabs(x, s + 1);
-      const float gi = gt.x, gf = gt.y, gg = gt.z, go = gt.w;
-      const float dh = dyv + cmask[x] * dh_rec;
-      const float tch = fast_tanh(cv);
-      const float d_o = dh * tch;
-      const float dcc = dc[x] + dh * go * (1.f - tch * tch);
-      const float d_i = dcc * gg, d_g = dcc * gi, d_f = dcc * cpv;
-      dc[x] = dcc * gf;
+      const float dh = __builtin_fmaf(cmask[x], dh_rec, pre.dy);
+      const float dcc = __builtin_fmaf(dh, pre.B, dc[x]);
+      dc[x] = dcc * pre.gf;
       float4 z4;
-      z4.x = d_i * ((gi > 0.f && gi < 1.f) ? 0.2f : 0.f);
-      z4.y = d_f * ((gf > 0.f && gf < 1.f) ? 0.2f : 0.f);
-      z4.z = d_g * (1.f - gg * gg);
-      z4.w = d_o * ((go > 0.f && go < 1.f) ? 0.2f : 0.f);
+      z4.x = dcc * pre.Ci;
+      z4.y = dcc * pre.Cf;
+      z4.z = dcc * pre.Cg;
+      z4.w = dh * pre.Ao;
       *reinterpret_cast<float4*>(p.dz + (((size_t)t * p.n_pad + cn[x]) * 2 + dir) * H4 + 4 * cu) = z4;
       gsum[x].x += z4.x; gsum[x].y += z4.y; gsum[x].z += z4.z; gsum[x].w += z4.w;
       // power-of-two scale of this batch column: max over its 16 threads (one DPP row)
@@ -581,6 +601,7 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
   // one phase = one step (s >= 1) of tile x: finish its gather, reduce, then `tail`.
   auto phase = [&](auto xc, int s) {
     constexpr int x = decltype(xc)::value;
+    const Pre pre = precompute(x);
     prof.stamp(0);
     await(x, s - 1, (unsigned)((s - 1) >> 1) & 1u);
     prof.stamp(1);
@@ -597,13 +618,13 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
     const float dh_rec = sub == 0 ? acc.x : sub == 1 ? acc.y : sub == 2 ? acc.z : acc.w;
     // the gather issued on the way: this tile's partial tiles of step s (after the last step a
     // harmless unused read)
-    tail(xc, std::true_type{}, s, dh_rec, s);
+    tail(xc, std::true_type{}, s, pre, dh_rec, s);
   };
   using T0 = std::integral_constant<int, 0>;
   int s = p.s_begin;
   if (s == 0) {
     // step 0: no recurrent gradient yet, nothing to gather
-    tail(T0{}, std::false_type{}, 0, 0.f, 0);
+    tail(T0{}, std::false_type{}, 0, precompute(0), 0.f, 0);
     s = 1;
   }
   // (first phase peeled so that every gather the loop waits for was issued by the same
