@@ -385,15 +385,22 @@ def ctc_beam_search(logits, seq_len, N, beam_width=100, merge_repeated=True):
     return dec, dlen, score
 
 
+HOST_BEAM_MAX_UTTERANCES = 64
+
+
 def beam_decoder_choice(N, width, classes, on_device=True):
     """Which K9 decoder serves a batch of N utterances: 'host' (decode_host.cpp: one utterance
     per host thread, after a D2H copy of the logits) or 'device' (beam.hip: one wave per
     utterance, logits stay in HBM).  Both give the same strings (tests/test_gpu_beam.py); the
-    default is decided on measurements (BENCH_r03 eval_beam, 64 x 999 frames on a 256-thread
-    host): the host decoder is 4.6x faster at width 100 and 2.4x at width 400 as long as every
-    utterance gets its own host thread, so ASR_BEAM=auto (default) takes the host decoder for
-    N <= USABLE host threads (usable_host_threads) and the device decoder beyond; ASR_BEAM=device / host force one.  The
-    device kernel handles widths <= 1024 and <= 64 classes."""
+    default is decided on measurements (profiles/r6_beam_crossover.md, tools/beam_crossover.py:
+    N x 999 frames x 28 classes on a 256-thread host).  The device decoder's time is FLAT in N up
+    to one wave per CU (0.118 s at 64, 256 and 0.126 s at 512 utterances, width 100) while the
+    host decoder's grows faster than N once more than ~64 threads decode at once (0.08 s at 64,
+    0.82 s at 256, 2.1 s at 512; on 8 host threads 0.35 s at 64): ASR_BEAM=auto (default) takes
+    the host decoder for N <= min(USABLE host threads, 64) and the device decoder beyond -- the
+    BASELINE eval batch (64 utterances) decodes on the host of a many-core box, larger batches and
+    small hosts on the device; ASR_BEAM=device / host force one.  The device kernel handles
+    widths <= 1024 and <= 64 classes."""
     import os
     mode = os.environ.get('ASR_BEAM', 'auto')
     device_ok = on_device and int(width) <= 1024 and int(classes) <= 64
@@ -401,7 +408,7 @@ def beam_decoder_choice(N, width, classes, on_device=True):
         return 'host'
     if mode == 'device':
         return 'device'
-    return 'host' if int(N) <= usable_host_threads() else 'device'
+    return 'host' if int(N) <= min(usable_host_threads(), HOST_BEAM_MAX_UTTERANCES) else 'device'
 
 
 def usable_host_threads():

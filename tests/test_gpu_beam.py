@@ -151,7 +151,12 @@ def test_ctc_utils_decode_beam_branch_runs_on_the_device(monkeypatch):
     dev = ctc_utils.decode((slab, lens), is_greedy=False, beam_width=100)
     assert dev == host == auto and any(len(h) for h in host)
     monkeypatch.delenv('ASR_BEAM')
-    threads = os.cpu_count() or 1
-    assert ops.beam_decoder_choice(min(5, threads), 100, C) == 'host'
-    assert ops.beam_decoder_choice(threads + 1, 100, C) == 'device'
-    assert ops.beam_decoder_choice(threads + 1, 2048, C) == 'host'      # beyond the kernel's width
+    # auto: the host decoder up to min(usable host threads, 64) utterances (r6: its time grows
+    # faster than the batch beyond that, the device decoder's is flat up to one wave per CU:
+    # profiles/r6_beam_crossover.md), the device decoder beyond
+    cap = min(ops.usable_host_threads(), ops.HOST_BEAM_MAX_UTTERANCES)
+    assert ops.beam_decoder_choice(min(5, cap), 100, C) == 'host'
+    assert ops.beam_decoder_choice(cap, 100, C) == 'host'
+    assert ops.beam_decoder_choice(cap + 1, 100, C) == 'device'
+    assert ops.beam_decoder_choice(256, 100, C) == 'device'
+    assert ops.beam_decoder_choice(cap + 1, 2048, C) == 'host'          # beyond the kernel's width
