@@ -778,7 +778,7 @@ def main():
         extra['roofline_gate_gemm'] = {
             'kernel': '%s %dx%dx%d (x@W, one BiLSTM layer)' % (
                 'gemm_f32_mfma_kernel' if exact else
-                'gemm_hlx_kernel<4,4,2>' if packed else 'gemm_f16x2_fast_kernel', rows, 8 * H, 2 * H),
+                'gemm_hlp_kernel<4,4,2>' if packed else 'gemm_f16x2_fast_kernel', rows, 8 * H, 2 * H),
             'pack_ms': None if t_pack is None else round(t_pack, 4),
             'bound': 'mfma', 'achieved': round(mult * gf / tg / 1e9, 2), 'peak': peak,
             'unit': 'TFLOP/s', 'frac': round(mult * gf / tg / 1e9 / peak, 4),
@@ -906,8 +906,9 @@ def main():
                         'avg_launch_ms': round(tot / len(evs), 4),
                         'ms_per_step': round(tot / args.steps, 3),
                         'algorithmic_tflop_per_step': round(fl / args.steps / 1e12, 3)}
-            r = {'kernel': ('gemm_hlx_kernel<4,4,2> (256x256 tile; operands packed once into '
-                            'split-fp16 planes)' if packed else
+            r = {'kernel': ('gemm_hlx_kernel<4,4,2> / gemm_hlp_kernel<4,4,2> (256x256 tile, K-major / '
+                            'persistent row-major; operands packed once into split-fp16 planes)'
+                            if packed else
                             'gemm_f32_mfma_kernel' if exact else 'gemm_f16x2_fast_kernel') +
                            ': all GEMM launches of the step',
                  'bound': 'mfma', 'peak': peak, 'unit': 'TFLOP/s', 'traffic': pmc.get('gemm')}

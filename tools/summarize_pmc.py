@@ -73,8 +73,18 @@ def families(rd, wr, layers):
             t += fetch_mult * sum(rd.get(k, [])) + sum(wr.get(k, []))
         return t * 1e3 / steps
     out = {'_steps_profiled': steps}
+    # (r6) BPTT kernels that write dz as packed planes (`lstm_bwd_kernel_c<.., true>`) are preceded,
+    # in the FIRST step of a run only, by one MEASURING pass per layer of the fp32-slab kernel
+    # (`<.., false>`, engine.backward): not part of a steady-state step, so left out of `bwd`
+    planes_on = any(k.startswith('lstm_bwd_kernel_c<') and k.rstrip().endswith('true>')
+                    for k in set(rd) | set(wr))
+
+    def is_bwd(k):
+        if not k.startswith('lstm_bwd_kernel'):
+            return False
+        return not (planes_on and k.startswith('lstm_bwd_kernel_c<') and k.rstrip().endswith('false>'))
     for key, pred in (('fwd', lambda k: k.startswith('lstm_fwd_kernel')),
-                      ('bwd', lambda k: k.startswith('lstm_bwd_kernel')),
+                      ('bwd', is_bwd),
                       ('pack', lambda k: k.startswith('pack_hl'))):
         t, n = total(pred)
         if n:
@@ -89,7 +99,7 @@ def families(rd, wr, layers):
                              k.startswith('norm_partial'), 2)):
         if names_of(pred):
             out[key] = round((per_step_sum if key == 'conv' else per_launch_sum)(pred, mult), 1)
-    t, n = total(lambda k: k.startswith('gemm_hlx_kernel'))
+    t, n = total(lambda k: k.startswith(('gemm_hlx_kernel', 'gemm_hlp_kernel')))
     if n:
         out['gemm'] = round(t / n, 1)               # per LAUNCH (average over both forms)
         out['gemm_launches_per_step'] = round(n / float(steps), 2)
