@@ -57,7 +57,14 @@ fl = 2.0 * rows * N * K
 print('%d launches in %.2f s: %.3f ms each, %.1f TF/s algorithmic, %.2f PF/s executed'
       % (n, dt, dt / n * 1e3, fl * n / dt / 1e12, 3 * fl * n / dt / 1e15))
 v = [out[i] for i in range(7)]
-print('in-kernel: %.0f clocks per slab, loop %.1f us -> shader clock %.2f GHz'
-      % (sum(v[:5]) / (K // 32), v[6] / 100.0, sum(v[:5]) / (v[6] * 10.0)))
-for t, k in samples[:: max(1, len(samples) // 8)]:
+if v[6] > 0:        # (the persistent form, gemm_hlp_kernel, carries no phase profiler)
+    print('in-kernel: %.0f clocks per slab, loop %.1f us -> shader clock %.2f GHz'
+          % (sum(v[:5]) / (K // 32), v[6] / 100.0, sum(v[:5]) / (v[6] * 10.0)))
+import re
+mhz = sorted(int(m.group(1)) for t, k in samples for m in [re.search(r'\((\d+)Mhz\)', ' '.join(k))] if m)
+watt = sorted(float(m.group(1)) for t, k in samples for m in [re.search(r'Power \(W\): ([0-9.]+)', ' '.join(k))] if m)
+if mhz and watt:
+    print('rocm-smi over the run: sclk median %d MHz (min %d, max %d), package power median %.0f W'
+          % (mhz[len(mhz) // 2], mhz[0], mhz[-1], watt[len(watt) // 2]))
+for t, k in samples[:: max(1, len(samples) // 4)]:
     print('  t=%.1fs %s' % (t - t0, ' | '.join(k)))
