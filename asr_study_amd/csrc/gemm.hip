@@ -2029,8 +2029,11 @@ static int hlp_num_cu() {
   }
   return ncu[dev];
 }
+// (a __device__ array: zero at module load, one instance per device, no allocation -- the library
+// still owns no device memory it had to ask for)
+constexpr int kHlpRing = 256, kHlpWords = 16;
+__device__ unsigned g_hlp_ctl[kHlpRing * kHlpWords];
 static unsigned* hlp_control_block() {
-  constexpr int kRing = 256, kWords = 16;
   static unsigned* ring[16] = {nullptr};
   static std::atomic<unsigned> next[16];
   static std::mutex mu;
@@ -2039,17 +2042,12 @@ static unsigned* hlp_control_block() {
   if (!ring[dev]) {
     std::lock_guard<std::mutex> lock(mu);
     if (!ring[dev]) {
-      unsigned* p = nullptr;
-      if (hipMalloc(reinterpret_cast<void**>(&p), (size_t)kRing * kWords * sizeof(unsigned)) != hipSuccess)
-        return nullptr;
-      if (hipMemset(p, 0, (size_t)kRing * kWords * sizeof(unsigned)) != hipSuccess) {
-        (void)hipFree(p);
-        return nullptr;
-      }
-      ring[dev] = p;
+      void* p = nullptr;
+      if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_hlp_ctl)) != hipSuccess || !p) return nullptr;
+      ring[dev] = reinterpret_cast<unsigned*>(p);
     }
   }
-  return ring[dev] + (size_t)(next[dev].fetch_add(1u) % kRing) * kWords;
+  return ring[dev] + (size_t)(next[dev].fetch_add(1u) % kHlpRing) * kHlpWords;
 }
 
 static int hl_splits(const asr_gemm_hl_args* a, int* kps_out) {
