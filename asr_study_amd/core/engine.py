@@ -1121,7 +1121,7 @@ class Model(object):
                     # BPTT writes dz as packed planes itself where its kernel can (the plain cell
                     # at H = 256 / 512 on the two-dimensional-split kernels): the pack pass over
                     # the fp32 slab (2.1 GB per layer at cfg3) disappears.  The planes' scale has
-                    # to be known before the pass: a per-layer bound kept at ~8 x the measured
+                    # to be known before the pass: a per-layer bound kept at ~64 x the measured
                     # max|dz| by asr_lstm_dz_guard (hysteresis: identical inputs see identical
                     # scales); a layer without a bound yet -- first step, after a fault or new
                     # weights -- runs one MEASURING pass first (fp32 slab, discarded).

@@ -385,7 +385,7 @@ typedef struct asr_lstm_args {
   /* values, so the kernel stores the same 64 bytes either way and the separate pack pass over   */
   /* dz (2.1 GB per layer at H = 512, 64 utterances) disappears.  The planes' power-of-two       */
   /* scale must be known BEFORE the pass: it is asr_pack_hl's scale of *dz_bound (a device       */
-  /* float >= the max |dz| this call will produce, e.g. 8 x the previous training step's         */
+  /* float >= the max |dz| this call will produce, e.g. 64 x the previous training step's        */
   /* maximum -- asr_lstm_dz_guard maintains it), written to *dz_scale_out for asr_gemm_hl.  The  */
   /* kernel then also splits dz with THAT scale for its own dz @ U^T products (instead of a      */
   /* per-sample scale): same 2^-22 product accuracy while max |dz| stays within                  */
@@ -399,9 +399,11 @@ typedef struct asr_lstm_args {
 int asr_lstm_dz_hl_supported(const asr_lstm_args* a);
 /* Keeps a layer's *dz_bound in step with the measured *dz_absmax of the pass just enqueued     */
 /* (device-side, no synchronisation): with M = max * scale(bound), the bound is kept while M    */
-/* stays in [2^2, 2^9) (so that identical inputs see identical scales) and becomes 8 * max      */
-/* otherwise.  planes_used != 0: the pass wrote planes with this bound -- if M left             */
-/* [2^-4, 2^15] (fp16 overflow of the hi plane at 2^16, precision loss below) the sticky        */
+/* stays in [2^-1, 2^6) (so that identical inputs see identical scales); otherwise it becomes    */
+/* 64 * max when the maximum shrank and sqrt(bound * 64 * max) when it grew (a spike is usually  */
+/* gone a step later; persistent growth settles within three steps).  planes_used != 0: the     */
+/* pass wrote planes with this bound -- if M                                                    */
+/* left [2^-7, 2^15] (fp16 overflow of the hi plane at 2^16, precision loss below) the sticky   */
 /* timeout flag of `bwd_workspace` is raised, i.e. the step is vetoed and re-run exactly like   */
 /* a step whose persistent kernel gave up (asr_lstm_status).                                    */
 int asr_lstm_dz_guard(const float* dz_absmax, float* dz_bound, int planes_used,

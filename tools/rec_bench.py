@@ -4,7 +4,7 @@ profiler (ASR_LSTM_DBG=32), shader clocks per phase and wave of workgroup 0.
 
     python tools/rec_bench.py cfg3 [--fwd] [--bwd] [--planes] VAR=VALUE[,VAR=VALUE...] ...
 
---planes: BPTT writes dz as packed planes (asr_lstm_args.dz_hl) with a bound of 8 x max|dz|.
+--planes: BPTT writes dz as packed planes (asr_lstm_args.dz_hl) with a bound of 64 x max|dz|.
 
 Each positional VAR=VALUE group is one variant (environment switches read per launch by
 csrc/lstm.hip: ASR_LSTM_BWD_2D, ASR_LSTM_PROG, ASR_LSTM_FAST ...); 'base' = no switch."""
@@ -65,7 +65,7 @@ def main():
     if '--planes' in sys.argv:
         amax = torch.zeros(1, device=dev)
         ops.lstm_seq_bwd(dy, U, cell, gates, dz, T, n_pad, H, dz_absmax=amax)
-        bound = amax * 8.0
+        bound = amax * 64.0
         planes = ops.HlPlanes(T * n_pad, 8 * H, dev)
     base_env = dict(os.environ)
     for var in variants:
