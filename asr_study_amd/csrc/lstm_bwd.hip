@@ -27,6 +27,43 @@ __device__ __forceinline__ void mfma_hl_tile(f32x4& am, f32x4& ac, const f32x4& 
       : "a"(uh0), "a"(ul0), "a"(uh1), "a"(ul1), "v"(bh0), "v"(bl0), "v"(bh1), "v"(bl1));
 }
 
+// Two output tiles (a, b) against the same dz tile, their MFMAs alternating: per accumulator the
+// products are added in the order of mfma_hl_tile (am = Uh0 Bh0 + Uh1 Bh1; ac = Uh0 Bl0 + Ul0 Bh0
+// + Uh1 Bl1 + Ul1 Bh1), so the results are bit-identical to two calls of it; an accumulator is
+// reused two MFMAs (32 cycles of pipe) later at the earliest.  Two halves (K step 0 / 1), so that
+// the caller can put the previous pair's combine-and-publish between them; no trailing wait
+// states: the caller reads the results behind the next pair's MFMAs (or pads itself).
+template <int HALF>
+__device__ __forceinline__ void mfma_hl_tile2(f32x4& ama, f32x4& aca, f32x4& amb, f32x4& acb,
+                                              const f32x4& uh0a, const f32x4& ul0a,
+                                              const f32x4& uh1a, const f32x4& ul1a,
+                                              const f32x4& uh0b, const f32x4& ul0b,
+                                              const f32x4& uh1b, const f32x4& ul1b, const h8& bh0,
+                                              const h8& bl0, const h8& bh1, const h8& bl1) {
+  if constexpr (HALF == 0) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %4, %8, 0\n\t"       // ama  = uh0a bh0
+        "v_mfma_f32_16x16x32_f16 %1, %4, %9, 0\n\t"       // aca  = uh0a bl0
+        "v_mfma_f32_16x16x32_f16 %2, %6, %8, 0\n\t"       // amb  = uh0b bh0
+        "v_mfma_f32_16x16x32_f16 %3, %6, %9, 0\n\t"       // acb  = uh0b bl0
+        "v_mfma_f32_16x16x32_f16 %1, %5, %8, %1\n\t"      // aca += ul0a bh0
+        "v_mfma_f32_16x16x32_f16 %3, %7, %8, %3"            // acb += ul0b bh0
+        : "=&v"(ama), "=&v"(aca), "=&v"(amb), "=&v"(acb)
+        : "a"(uh0a), "a"(ul0a), "a"(uh0b), "a"(ul0b), "v"(bh0), "v"(bl0));
+  } else {
+    asm volatile(
+        "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"      // ama += uh1a bh1
+        "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"      // amb += uh1b bh1
+        "v_mfma_f32_16x16x32_f16 %1, %4, %9, %1\n\t"      // aca += uh1a bl1
+        "v_mfma_f32_16x16x32_f16 %3, %6, %9, %3\n\t"      // acb += uh1b bl1
+        "v_mfma_f32_16x16x32_f16 %1, %5, %8, %1\n\t"      // aca += ul1a bh1
+        "v_mfma_f32_16x16x32_f16 %3, %7, %8, %3"            // acb += ul1b bh1
+        : "+v"(ama), "+v"(aca), "+v"(amb), "+v"(acb)
+        : "a"(uh1a), "a"(ul1a), "a"(uh1b), "a"(ul1b), "v"(bh1), "v"(bl1));
+  }
+}
+
 // Sum over the 16 samples of a batch tile of every thread's float4 (thread = (sample tid>>4,
 // unit tid&15)) -> dst[64 gate columns of this workgroup], in a fixed order (deterministic).
 __device__ __forceinline__ void tile_gate_sums(float4 gsum, float* lds, float* dst,
@@ -581,18 +618,43 @@ __device__ __forceinline__ void bwd_body_x(const LstmParams& p, int unit, int cw
       const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
           xch[x] + (size_t)(s & 1) * slot_words, 0, (unsigned)(slot_words * 4), 0x00020000);
       const unsigned soff = (unsigned)((((size_t)w * P + cw) * 256 + nl * 16 + 4 * g) * 4);
-#pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        f32x4 am, ac;
-        mfma_hl_tile(am, ac, ufh[i][0], ufl[i][0], ufh[i][1], ufl[i][1], bh[0], bl[0], bh[1],
-                     bl[1]);
+      // r6: the output tiles go through the pipe in PAIRS whose MFMAs alternate (twelve MFMAs on
+      // four accumulators: an accumulator is reused two MFMAs later at the earliest, where one
+      // tile's `ac` chain of four had them back to back), and a pair is combined and published in
+      // the issue slots of the NEXT pair's MFMAs.  Per accumulator the products are added in the
+      // order of mfma_hl_tile: the published words are unchanged.
+      static_assert(TPW % 2 == 0, "tiles in pairs");
+      auto finish = [&](int i, const f32x4& am, const f32x4& ac) {
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           o[e] = tag_word(__builtin_fmaf(ac[e], usl, am[e] * us), wtag);
         // partial tile of the output units 16 (w + 4 i) ..: 4 P KB apart
         __builtin_amdgcn_raw_buffer_store_b128(o, wr, soff, i * (4 * P * 1024), FAST ? 0 : kSc1);
+        // A 16-byte store reads its data registers over several cycles, and hipcc pads that
+        // hazard only for stores WITHOUT a register in the soffset field: with one, the next
+        // tile's combine may overwrite `o` at once -- measured on gfx950 as the second dword of
+        // lanes 12..15 of each row going out stale in about one wave per launch.  Two wait
+        // states behind every publish.
+        asm volatile("s_nop 1" : "+v"(o));
+      };
+      f32x4 am[TPW], ac[TPW];
+#pragma unroll
+      for (int i = 0; i < TPW; i += 2) {
+        mfma_hl_tile2<0>(am[i], ac[i], am[i + 1], ac[i + 1], ufh[i][0], ufl[i][0], ufh[i][1],
+                         ufl[i][1], ufh[i + 1][0], ufl[i + 1][0], ufh[i + 1][1], ufl[i + 1][1],
+                         bh[0], bl[0], bh[1], bl[1]);
+        // (the previous pair left the pipe six MFMAs ago: >= 96 cycles)
+        if (i > 0) finish(i - 2, am[i - 2], ac[i - 2]);
+        mfma_hl_tile2<1>(am[i], ac[i], am[i + 1], ac[i + 1], ufh[i][0], ufl[i][0], ufh[i][1],
+                         ufl[i][1], ufh[i + 1][0], ufl[i + 1][0], ufh[i + 1][1], ufl[i + 1][1],
+                         bh[0], bl[0], bh[1], bl[1]);
+        if (i > 0) finish(i - 1, am[i - 1], ac[i - 1]);
       }
+      asm volatile("s_nop 11" : "+v"(am[TPW - 2]), "+v"(ac[TPW - 2]), "+v"(am[TPW - 1]),
+                   "+v"(ac[TPW - 1]));
+      finish(TPW - 2, am[TPW - 2], ac[TPW - 2]);
+      finish(TPW - 1, am[TPW - 1], ac[TPW - 1]);
     }
     prof.stamp(4);
     if (ISSUE) issue(x, os);
