@@ -365,6 +365,90 @@ template <> struct FwdMfma<4> {
   }
 };
 
+// r6: ONE K step (32 units) of TWO gate tiles -- the six MFMAs of FwdMfma::run2's kk-th group,
+// same order per accumulator -- with, in the issue slots between them (an MFMA holds the pipe 16
+// cycles, a v_perm_b32 issues in 4), the UNPACK of the next K step's gathered words (NEXT): the
+// 32 v_perm_b32 of a step used to run ahead of the first MFMA, ~160 clocks of the dependent
+// chain of a wave that is alone on its SIMD.  FIRST: the accumulators start at 0.  No trailing
+// wait states (the caller reads the results >= 6 MFMAs later, or pads itself).
+template <bool FIRST, bool NEXT>
+__device__ __forceinline__ void fwd_pair_step(f32x4& am0, f32x4& ac0, f32x4& am1, f32x4& ac1,
+                                              const f32x4& uh0, const f32x4& ul0, const f32x4& uh1,
+                                              const f32x4& ul1, const h8& bh, const h8& bl,
+                                              const u32x4& q0, const u32x4& q1, h8& nbh, h8& nbl) {
+  if constexpr (NEXT) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    const unsigned selh = 0x07060302u, sell = 0x05040100u;
+    if constexpr (FIRST) {
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_mfma_f32_16x16x32_f16 %1, %12, %17, 0\n\t"     // ac0  = uh0 bl
+          "v_perm_b32 %4, %19, %18, %26\n\t"
+          "v_perm_b32 %5, %21, %20, %26\n\t"
+          "v_mfma_f32_16x16x32_f16 %3, %14, %17, 0\n\t"     // ac1  = uh1 bl
+          "v_perm_b32 %6, %23, %22, %26\n\t"
+          "v_perm_b32 %7, %25, %24, %26\n\t"
+          "v_mfma_f32_16x16x32_f16 %0, %12, %16, 0\n\t"     // am0  = uh0 bh
+          "v_perm_b32 %8, %19, %18, %27\n\t"
+          "v_perm_b32 %9, %21, %20, %27\n\t"
+          "v_mfma_f32_16x16x32_f16 %1, %13, %16, %1\n\t"    // ac0 += ul0 bh
+          "v_perm_b32 %10, %23, %22, %27\n\t"
+          "v_perm_b32 %11, %25, %24, %27\n\t"
+          "v_mfma_f32_16x16x32_f16 %3, %15, %16, %3\n\t"    // ac1 += ul1 bh
+          "v_mfma_f32_16x16x32_f16 %2, %14, %16, 0"         // am1  = uh1 bh
+          : "=&v"(am0), "=&v"(ac0), "=&v"(am1), "=&v"(ac1), "=&v"(h0), "=&v"(h1), "=&v"(h2),
+            "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+          : "a"(uh0), "a"(ul0), "a"(uh1), "a"(ul1), "v"(bh), "v"(bl), "v"(q0[0]), "v"(q0[1]),
+            "v"(q0[2]), "v"(q0[3]), "v"(q1[0]), "v"(q1[1]), "v"(q1[2]), "v"(q1[3]), "s"(selh),
+            "s"(sell));
+    } else {
+      asm volatile(
+          "v_mfma_f32_16x16x32_f16 %1, %12, %17, %1\n\t"    // ac0 += uh0 bl
+          "v_perm_b32 %4, %19, %18, %26\n\t"
+          "v_perm_b32 %5, %21, %20, %26\n\t"
+          "v_mfma_f32_16x16x32_f16 %3, %14, %17, %3\n\t"    // ac1 += uh1 bl
+          "v_perm_b32 %6, %23, %22, %26\n\t"
+          "v_perm_b32 %7, %25, %24, %26\n\t"
+          "v_mfma_f32_16x16x32_f16 %0, %12, %16, %0\n\t"    // am0 += uh0 bh
+          "v_perm_b32 %8, %19, %18, %27\n\t"
+          "v_perm_b32 %9, %21, %20, %27\n\t"
+          "v_mfma_f32_16x16x32_f16 %1, %13, %16, %1\n\t"    // ac0 += ul0 bh
+          "v_perm_b32 %10, %23, %22, %27\n\t"
+          "v_perm_b32 %11, %25, %24, %27\n\t"
+          "v_mfma_f32_16x16x32_f16 %3, %15, %16, %3\n\t"    // ac1 += ul1 bh
+          "v_mfma_f32_16x16x32_f16 %2, %14, %16, %2"        // am1 += uh1 bh
+          : "+v"(am0), "+v"(ac0), "+v"(am1), "+v"(ac1), "=&v"(h0), "=&v"(h1), "=&v"(h2),
+            "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+          : "a"(uh0), "a"(ul0), "a"(uh1), "a"(ul1), "v"(bh), "v"(bl), "v"(q0[0]), "v"(q0[1]),
+            "v"(q0[2]), "v"(q0[3]), "v"(q1[0]), "v"(q1[1]), "v"(q1[2]), "v"(q1[3]), "s"(selh),
+            "s"(sell));
+    }
+    nbh = __builtin_bit_cast(h8, u32x4{h0, h1, h2, h3});
+    nbl = __builtin_bit_cast(h8, u32x4{l0, l1, l2, l3});
+  } else if constexpr (FIRST) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %4, %9, 0\n\t"         // ac0  = uh0 bl
+        "v_mfma_f32_16x16x32_f16 %3, %6, %9, 0\n\t"         // ac1  = uh1 bl
+        "v_mfma_f32_16x16x32_f16 %0, %4, %8, 0\n\t"         // am0  = uh0 bh
+        "v_mfma_f32_16x16x32_f16 %1, %5, %8, %1\n\t"        // ac0 += ul0 bh
+        "v_mfma_f32_16x16x32_f16 %3, %7, %8, %3\n\t"        // ac1 += ul1 bh
+        "v_mfma_f32_16x16x32_f16 %2, %6, %8, 0"             // am1  = uh1 bh
+        : "=&v"(am0), "=&v"(ac0), "=&v"(am1), "=&v"(ac1)
+        : "a"(uh0), "a"(ul0), "a"(uh1), "a"(ul1), "v"(bh), "v"(bl));
+  } else {
+    asm volatile(
+        "v_mfma_f32_16x16x32_f16 %1, %4, %9, %1\n\t"        // ac0 += uh0 bl
+        "v_mfma_f32_16x16x32_f16 %3, %6, %9, %3\n\t"        // ac1 += uh1 bl
+        "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"        // am0 += uh0 bh
+        "v_mfma_f32_16x16x32_f16 %1, %5, %8, %1\n\t"        // ac0 += ul0 bh
+        "v_mfma_f32_16x16x32_f16 %3, %7, %8, %3\n\t"        // ac1 += ul1 bh
+        "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2"            // am1 += uh1 bh
+        : "+v"(am0), "+v"(ac0), "+v"(am1), "+v"(ac1)
+        : "a"(uh0), "a"(ul0), "a"(uh1), "a"(ul1), "v"(bh), "v"(bl));
+  }
+}
+
 // PROGRESSIVE step (fwd_body_x<.., SLAB>): the 32-deep slabs of a wave's K slice are polled
 // SEPARATELY.  A slab whose two producer workgroups have published is multiplied as soon as the
 // slabs before it are done, the others are polled again -- their loads only: a finished slab's
@@ -643,8 +727,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
     } else {
     // exchanged word = fp16 hi << 16 | fp16 lo (tag = LSB of lo, left in place)
     h8 bh[NKW], bl[NKW];
-#pragma unroll
-    for (int kk = 0; kk < NKW; ++kk) {
+    auto unpack = [&](int kk) {
       const u32x4 q0 = v[x][2 * kk], q1 = v[x][2 * kk + 1];
       u32x4 hi, lo;
       hi[0] = __builtin_amdgcn_perm(q0[1], q0[0], 0x07060302u);
@@ -657,7 +740,53 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       lo[3] = __builtin_amdgcn_perm(q1[3], q1[2], 0x05040100u);
       bh[kk] = __builtin_bit_cast(h8, hi);
       bl[kk] = __builtin_bit_cast(h8, lo);
-    }
+    };
+    if constexpr (NKW == 4 && NJ == 4) {
+      // r6 (H = 512): K step by K step.  The first pair of gate tiles unpacks the NEXT K step's
+      // words between its MFMAs (fwd_pair_step<.., NEXT>); the second pair combines and stores
+      // the first pair's partial tiles between its own K steps.  Per accumulator the products
+      // are added in FwdMfma<4>::run2's order: the partial tiles are bit-identical to it.
+      const u32x4 none = {0u, 0u, 0u, 0u};
+      h8 nob, nol;
+      unpack(0);
+      f32x4 am0, ac0, am1, ac1, bm0, bc0, bm1, bc1;
+      fwd_pair_step<true, true>(am0, ac0, am1, ac1, ufh[0][0], ufl[0][0], ufh[1][0], ufl[1][0],
+                                bh[0], bl[0], v[x][2], v[x][3], bh[1], bl[1]);
+      fwd_pair_step<false, true>(am0, ac0, am1, ac1, ufh[0][1], ufl[0][1], ufh[1][1], ufl[1][1],
+                                 bh[1], bl[1], v[x][4], v[x][5], bh[2], bl[2]);
+      fwd_pair_step<false, true>(am0, ac0, am1, ac1, ufh[0][2], ufl[0][2], ufh[1][2], ufl[1][2],
+                                 bh[2], bl[2], v[x][6], v[x][7], bh[3], bl[3]);
+      fwd_pair_step<false, false>(am0, ac0, am1, ac1, ufh[0][3], ufl[0][3], ufh[1][3], ufl[1][3],
+                                  bh[3], bl[3], none, none, nob, nol);
+      fwd_pair_step<true, false>(bm0, bc0, bm1, bc1, ufh[2][0], ufl[2][0], ufh[3][0], ufl[3][0],
+                                 bh[0], bl[0], none, none, nob, nol);
+      // (the first pair left the pipe six MFMAs ago)
+      f32x4 r0, r1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        r0[e] = __builtin_fmaf(ac0[e], 1.f / kLoScale, am0[e]);
+        r1[e] = __builtin_fmaf(ac1[e], 1.f / kLoScale, am1[e]);
+      }
+      fwd_pair_step<false, false>(bm0, bc0, bm1, bc1, ufh[2][1], ufl[2][1], ufh[3][1], ufl[3][1],
+                                  bh[1], bl[1], none, none, nob, nol);
+      mine[0 * 64 + lane] = r0;
+      mine[1 * 64 + lane] = r1;
+      fwd_pair_step<false, false>(bm0, bc0, bm1, bc1, ufh[2][2], ufl[2][2], ufh[3][2], ufl[3][2],
+                                  bh[2], bl[2], none, none, nob, nol);
+      fwd_pair_step<false, false>(bm0, bc0, bm1, bc1, ufh[2][3], ufl[2][3], ufh[3][3], ufl[3][3],
+                                  bh[3], bl[3], none, none, nob, nol);
+      asm volatile("s_nop 11" : "+v"(bm0), "+v"(bc0), "+v"(bm1), "+v"(bc1));
+      f32x4 r2, r3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        r2[e] = __builtin_fmaf(bc0[e], 1.f / kLoScale, bm0[e]);
+        r3[e] = __builtin_fmaf(bc1[e], 1.f / kLoScale, bm1[e]);
+      }
+      mine[2 * 64 + lane] = r2;
+      mine[3 * 64 + lane] = r3;
+    } else {
+#pragma unroll
+    for (int kk = 0; kk < NKW; ++kk) unpack(kk);
 #pragma unroll
     for (int j = 0; j < NJ; j += 2) {
       f32x4 am0, ac0, am1, ac1;
@@ -670,6 +799,7 @@ __device__ __forceinline__ void fwd_body_x(const LstmParams& p, int unit, int wg
       }
       mine[j * 64 + lane] = r0;
       mine[(j + 1) * 64 + lane] = r1;
+    }
     }
     }
     prof.stamp(2);
