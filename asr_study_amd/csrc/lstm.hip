@@ -383,7 +383,16 @@ int run(const asr_lstm_args* a, bool bwd, void* workspace, size_t ws_bytes,
   const bool prog_f = !bwd && pl.prec == 1 && (a->H == 256 || a->H == 512) && fwd_progressive(a->H);
   // (ASR_LSTM_PROG = n > 1: progressive with n naps before the first poll -- measurement switch)
   const int prog_naps = env_int("ASR_LSTM_PROG", 0) > 1 ? env_int("ASR_LSTM_PROG", 0) : 0;
-  p.prepoll = bwd ? (pl.form_c ? 2 : 4) : (prog_f ? prog_naps : (pl.P <= 16 ? 12 : 16));
+  // (forward, single-gather form at H = 512: 13 naps since the unpack rides in the MFMA stream --
+  // r6 sweep of 8 / 10 / 12 / 13 / 14 / 15 / 16 / 17 / 18 naps: 1.768 / 1.754 / 1.691 / 1.687 /
+  // 1.698 / 1.704 / 1.720 / 1.736 / 1.764 us per step; it was 16 with the longer chain)
+  // (two-dimensional BPTT, r6 with dz planes: no nap -- compact 2.394 / 2.442 / 2.457 / 2.473 us
+  // per step alone at 0 / 1 / 2 / 3 naps, 3.04 against 3.11 beside the GEMMs; default geometry flat)
+  p.prepoll = bwd ? (pl.form_c ? 0 : 4) : (prog_f ? prog_naps : (pl.P <= 16 ? 12 : 13));
+  // (ASR_LSTM_PREPOLL_FWD = n: measurement switch, forward single-gather form only)
+  if (!bwd && !prog_f && env_int("ASR_LSTM_PREPOLL_FWD", -1) >= 0)
+    p.prepoll = env_int("ASR_LSTM_PREPOLL_FWD", -1);
+  if (bwd && env_int("ASR_LSTM_PREPOLL_BWD", -1) >= 0) p.prepoll = env_int("ASR_LSTM_PREPOLL_BWD", -1);
   p.repoll = 1;
   p.xstride = fwd_xstride();
   // ASR_LSTM_SPIN_MS: bound of a persistent kernel's spins in milliseconds (default 600)
