@@ -995,6 +995,72 @@ pack_hl_kernel(const float* __restrict__ src, int rows, int cols, int ld,
   }
 }
 
+// Row planes only, streaming (r6): the form of the pack the training step runs on its critical
+// path (a layer input under one or both directions' masks; y (.) B_U).  pack_hl_kernel stages 64 x
+// 64 tiles through LDS because it may have to transpose; a row-only pack has nothing to
+// transpose: a thread takes FOUR consecutive columns of one row (one 16-byte load, coalesced over
+// the wave), the four lanes of a quad -- 16 columns, one (16 hi, 16 lo) group -- exchange their
+// 8-byte pieces with DPP quad permutes so that every lane stores 16 contiguous bytes (lane 0 / 1:
+// the hi halfs, lane 2 / 3: the lo halfs), and a wave writes 1 KB runs.  No LDS, no barrier.
+// Same arithmetic as pack_hl_kernel: bit-identical planes.  Needs cols % 16 == 0 == ldk_r - cols,
+// 16-byte aligned rows of source and masks.
+template <int CTRL>
+__device__ __forceinline__ unsigned quad_from(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+__global__ void __launch_bounds__(256)
+pack_rows_kernel(const float* __restrict__ src, long long total4, int c4, int ld,
+                 const float* __restrict__ mask, const float* __restrict__ mask2, int mask_period,
+                 int mask_ld, const float* __restrict__ absmax, float* __restrict__ scale_out,
+                 _Float16* __restrict__ r_hl, _Float16* __restrict__ r2_hl, int ldk) {
+  const float s = pow2_scale(absmax);
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
+  const int q = threadIdx.x & 3;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total4;
+       idx += (long long)gridDim.x * 256) {
+    const int r = (int)(idx / c4), c = 4 * (int)(idx - (long long)r * c4);
+    const float4 t = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+    const float v[4] = {t.x, t.y, t.z, t.w};
+    const size_t mo = (size_t)mod_period(r, mask_period) * mask_ld + c;
+    auto emit = [&](const float* m, _Float16* out) {
+      float w[4] = {v[0], v[1], v[2], v[3]};
+      if (m) {
+        const float4 mm = *reinterpret_cast<const float4*>(m + mo);
+        w[0] *= mm.x; w[1] *= mm.y; w[2] *= mm.z; w[3] *= mm.w;
+      }
+      hx4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = w[e] * s;
+        const _Float16 hh = (_Float16)x;
+        h[e] = hh;
+        l[e] = (_Float16)(x - (float)hh);
+      }
+      const unsigned long long hb = __builtin_bit_cast(unsigned long long, h);
+      const unsigned long long lb = __builtin_bit_cast(unsigned long long, l);
+      const unsigned h0 = (unsigned)hb, h1 = (unsigned)(hb >> 32);
+      const unsigned l0 = (unsigned)lb, l1 = (unsigned)(lb >> 32);
+      // lane q of the quad stores: 0 -> hi of lanes 0, 1; 1 -> hi of lanes 2, 3; 2 -> lo of
+      // lanes 0, 1; 3 -> lo of lanes 2, 3   (quad_perm [0,2,0,2] = 0x88, [1,3,1,3] = 0xDD)
+      const bool hi_lane = q < 2;
+      u32x4g o;
+      // (every permute is executed by ALL lanes and the pieces selected afterwards: a permute
+      // inside a divergent branch would read lanes that are switched off)
+      const unsigned ha0 = quad_from<0x88>(h0), ha1 = quad_from<0x88>(h1);
+      const unsigned hb0 = quad_from<0xDD>(h0), hb1 = quad_from<0xDD>(h1);
+      const unsigned la0 = quad_from<0x88>(l0), la1 = quad_from<0x88>(l1);
+      const unsigned lb0 = quad_from<0xDD>(l0), lb1 = quad_from<0xDD>(l1);
+      o[0] = hi_lane ? ha0 : la0;
+      o[1] = hi_lane ? ha1 : la1;
+      o[2] = hi_lane ? hb0 : lb0;
+      o[3] = hi_lane ? hb1 : lb1;
+      *reinterpret_cast<u32x4g*>(out + hl_index(r, c & ~15, ldk) + 8 * q) = o;
+    };
+    emit(mask, r_hl);
+    if (r2_hl) emit(mask2, r2_hl);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // The packed-plane kernel.  256 x 256 x 32 tile by default (outputs of at least 256 x 256).
 // With 128 x 128 tiles both split-fp16 GEMMs sit at ~250 TF/s algorithmic whatever the K loop
@@ -1988,6 +2054,26 @@ extern "C" int asr_pack_hl(const asr_pack_args* a, asr_stream_t stream_) {
   if (a->r2_hl)
     ASR_CHECK_ARG(a->r_hl && a->mask && a->mask2 && aligned16(a->r2_hl),
                   "pack_hl: the second row planes need r_hl, mask and mask2 (same period / ld)");
+  // row planes only, whole groups, aligned rows: the streaming kernel (ASR_PACK_ROWS=0: the tiled one)
+  {
+    const char* pr = getenv("ASR_PACK_ROWS");
+    const bool rows_ok = a->r_hl && !a->c_hl && a->cols % 16 == 0 && a->ldk_r == a->cols &&
+                         a->ld % 4 == 0 && aligned16(a->src) &&
+                         (!a->mask || (a->mask_ld % 4 == 0 && aligned16(a->mask))) &&
+                         (!a->r2_hl || aligned16(a->mask2)) && !(pr && *pr == '0');
+    if (rows_ok) {
+      const long long total4 = (long long)a->rows * (a->cols / 4);
+      long long blocks = (total4 + 255) / 256;
+      if (blocks > 256 * 32) blocks = 256 * 32;
+      hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a->src, total4,
+                         a->cols / 4, a->ld, a->mask, a->r2_hl ? a->mask2 : nullptr,
+                         a->mask ? a->mask_period : 1, a->mask_ld, a->absmax, a->scale_out,
+                         reinterpret_cast<_Float16*>(a->r_hl), reinterpret_cast<_Float16*>(a->r2_hl),
+                         a->ldk_r);
+      ASR_CHECK_LAUNCH();
+      return ASR_OK;
+    }
+  }
   dim3 grid((a->cols + 63) / 64, (a->rows + 63) / 64);
   const size_t pack_shm = (size_t)((a->r_hl ? 1 : 0) + (a->c_hl ? 1 : 0) + (a->r2_hl ? 1 : 0)) *
                           64 * 128 * sizeof(_Float16);

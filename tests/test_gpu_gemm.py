@@ -445,3 +445,48 @@ def test_gemm_hl_persistent_launches_on_two_streams_do_not_share_a_control_block
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o, want)
+
+
+@pytest.mark.parametrize('rows,cols,ld,off,period,two', [
+    (999 * 16, 80, 80, 0, 16, True),        # first-layer input, both directions' masks
+    (64 * 37, 1024, 1024, 0, 64, True),     # a BiLSTM(512) layer input
+    (64 * 37, 512, 1024, 512, 64, False),   # y (.) B_U: the second half of strided rows
+    (257, 16, 16, 0, 0, False),             # one group per row, no mask
+    (1000, 4096, 4096, 0, 0, False),        # dz-like, no mask
+    (333, 48, 64, 8, 48, True),             # period not a power of two, offset rows
+])
+def test_pack_hl_streaming_row_kernel_is_bit_identical(rows, cols, ld, off, period, two,
+                                                       monkeypatch):
+    """pack_rows_kernel (r6: row planes only -- four columns per thread, DPP quad exchange, 16-byte
+    stores, no LDS) against the tiled pack_hl_kernel (ASR_PACK_ROWS=0) and the NumPy split: same
+    planes, same scale, bit for bit; one and two masks, strided / offset sources."""
+    from asr_study_amd import ops
+    rs = np.random.RandomState(rows + cols + off)
+    src = (rs.randn(rows, ld) * 0.3).astype(np.float32)
+    m1 = ((rs.rand(max(period, 1), cols) > 0.2) / 0.8).astype(np.float32) if period else None
+    m2 = ((rs.rand(max(period, 1), cols) > 0.2) / 0.8).astype(np.float32) if two else None
+    sd = to_dev(src)
+    d1 = to_dev(m1) if period else None
+    d2 = to_dev(m2) if two else None
+    amax = ops.absmax(sd)
+
+    def run(mode):
+        monkeypatch.setenv('ASR_PACK_ROWS', mode)
+        ra, rb = ops.HlPlanes(rows, cols, 'cuda:0'), ops.HlPlanes(rows, cols, 'cuda:0')
+        ra.hl.fill_(7.0)
+        rb.hl.fill_(7.0)
+        ops.pack_hl(sd, rows, cols, ld=ld, src_off=off, mask=d1, mask_period=period, absmax=amax,
+                    r=ra, mask2=d2, r2=rb if two else None)
+        torch.cuda.synchronize()
+        return ra, rb
+    a0, b0 = run('0')
+    a1, b1 = run('1')
+    assert torch.equal(a0.hl, a1.hl) and float(a0.scale.item()) == float(a1.scale.item())
+    if two:
+        assert torch.equal(b0.hl, b1.hl)
+    x = src[:, off:off + cols].copy()
+    if period:
+        x = x * m1[np.arange(rows) % period]
+    hi, lo = _hl_ref(x, np.float32(a1.scale.item()))
+    assert np.array_equal(a1.hi.cpu().numpy()[:, :cols], hi)
+    assert np.array_equal(a1.lo.cpu().numpy()[:, :cols], lo)
