@@ -15,4 +15,4 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BU
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/step_$i -o g -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/step_$i.log 2>&1 </dev/null
 done
-python tools/pmc_parse.py $out $out/summary.md lstm_ gemm_hlx gemm_hlp pack_hl ctc_ adam norm_partial fe_ gemm_splitk conv_ | grep -v "^  " | head -40
+python tools/pmc_parse.py $out $out/summary.md lstm_ gemm_hlx gemm_hlp pack_hl pack_rows ctc_ adam norm_partial fe_ gemm_splitk conv_ | grep -v "^  " | head -40

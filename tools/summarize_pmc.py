@@ -85,7 +85,7 @@ def families(rd, wr, layers):
         return not (planes_on and k.startswith('lstm_bwd_kernel_c<') and k.rstrip().endswith('false>'))
     for key, pred in (('fwd', lambda k: k.startswith('lstm_fwd_kernel')),
                       ('bwd', is_bwd),
-                      ('pack', lambda k: k.startswith('pack_hl'))):
+                      ('pack', lambda k: k.startswith(('pack_hl', 'pack_rows')))):
         t, n = total(pred)
         if n:
             out[key] = round(t / (steps * (1 if key == 'pack' else layers)), 1)

@@ -34,7 +34,7 @@ def overlap_table(trace_csv):
     starts = [a for a, _ in bptt]
     agg = {}
     for n, a, b in ev:
-        if not (n.startswith('gemm_') or n.startswith('pack_hl') or n.startswith('colsum')):
+        if not (n.startswith('gemm_') or n.startswith(('pack_hl', 'pack_rows')) or n.startswith('colsum')):
             continue
         i = bisect.bisect_right(starts, b) - 1
         ov = 0
