@@ -515,16 +515,42 @@ class Model(object):
     def _pack_weights(self):
         """W of every packed stage -> planes for x@W (reduction over the input features:
         (8H, in)) and for dz@W^T (reduction over the gate columns: (in, 8H)); one pass per W,
-        ~0.3 GB per step at cfg3."""
-        for si, s in enumerate(self.stages):
-            if not self._stage_packed(s):
-                continue
+        ~0.3 GB per step at cfg3.  Only the FIRST packed stage's planes are needed at once: its
+        pack runs on the calling stream, the others' (two small kernels each, launch-bound: 0.15 ms
+        of a cfg3 step when they sat in front of the first GEMM) on the side stream beside the
+        first layer's work; self._w_ready[si] is the event the stage's first GEMM waits for."""
+        self._w_ready = {}
+        main = torch.cuda.current_stream(self.device) if self.device.type == 'cuda' else None
+        packed = [(si, s) for si, s in enumerate(self.stages) if self._stage_packed(s)]
+
+        def pack(si, s):
             n = s.f_in_pad * 8 * s.Hp
             w = self.params[s.oW:s.oW + n]
             amax = ops.absmax(w, self._buf('wamax%d' % si, (1,)))
             ops.pack_hl(self.params, s.f_in_pad, 8 * s.Hp, src_off=s.oW, absmax=amax,
                         r=self._planes('Wn%d' % si, s.f_in_pad, 8 * s.Hp),
                         c=self._planes('Wt%d' % si, 8 * s.Hp, s.f_in_pad))
+        aside = (self._side is not None and main is not None and len(packed) > 1
+                 and os.environ.get('ASR_PACK_W_ASIDE', '1') != '0')
+        for k, (si, s) in enumerate(packed):
+            if k == 0 or not aside:
+                pack(si, s)
+        if aside:
+            start = torch.cuda.Event()
+            start.record(main)              # (the weights are final on the calling stream here)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(start)
+                for si, s in packed[1:]:
+                    pack(si, s)
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    self._w_ready[si] = ev
+
+    def _await_weights(self, si):
+        """The calling stream waits for stage si's weight planes (packed on the side stream)."""
+        ev = getattr(self, '_w_ready', {}).pop(si, None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
 
     def _pack_input(self, si, s, a, BW, rows, n_pad, amax):
         """The stage's input slab (rows, f_in_pad) [x B_W of each direction] -> (rows, f_in_pad)
@@ -545,6 +571,7 @@ class Model(object):
         """zx = (a (.) B_W) @ W + b from packed planes (both directions in one GEMM without
         masks, one GEMM per direction with them)."""
         Hp = s.Hp
+        self._await_weights(si)
         Wt = self._planes('Wt%d' % si, 8 * Hp, s.f_in_pad)
         bias = self._view(s.ob, 8 * Hp)
         if len(pa) == 1:
