@@ -699,8 +699,23 @@ class Model(object):
                     # others the half of the reduction that was final by then (below): what is
                     # left on the critical path is the other half of those frames
                     main.wait_event(inner_done)
-                    self._gate_gemm_half(a, s, zx, BW, 0, (T - S) * n_pad, n_pad, 1, False)
-                    self._gate_gemm_half(a, s, zx, BW, S * n_pad, rows, n_pad, 0, False)
+                    # (r6) the two row ranges are independent and each is two launch-bound GEMMs
+                    # of ~25 us: one range on the pipe stream (idle by now), the other here
+                    fork = (self._pipe is not None
+                            and os.environ.get('ASR_PIPE_TAIL_FORK', '1') != '0')
+                    if fork:
+                        ev0 = torch.cuda.Event()
+                        ev0.record(main)
+                        with torch.cuda.stream(self._pipe):
+                            self._pipe.wait_event(ev0)
+                            self._gate_gemm_half(a, s, zx, BW, S * n_pad, rows, n_pad, 0, False)
+                            ev1 = torch.cuda.Event()
+                            ev1.record(self._pipe)
+                        self._gate_gemm_half(a, s, zx, BW, 0, (T - S) * n_pad, n_pad, 1, False)
+                        main.wait_event(ev1)
+                    else:
+                        self._gate_gemm_half(a, s, zx, BW, 0, (T - S) * n_pad, n_pad, 1, False)
+                        self._gate_gemm_half(a, s, zx, BW, S * n_pad, rows, n_pad, 0, False)
                 else:       # frames [T-S, S) were projected while the previous layer ran
                     self._gate_gemm(a, s, zx, BW, 0, (T - S) * n_pad, n_pad)
                     self._gate_gemm(a, s, zx, BW, S * n_pad, rows, n_pad)
