@@ -1283,8 +1283,20 @@ class Model(object):
 
                 if pipe_b and self._pipe_halves:
                     main.wait_event(dx_inner)
-                    self._dx_gemm_dir(dz, s, dx, BW, S * n_pad, rows, n_pad, zmx, 1, 1.0)
-                    self._dx_gemm_dir(dz, s, dx, BW, 0, (T - S) * n_pad, n_pad, zmx, 0, 1.0)
+                    # (r6: two independent row ranges, one launch-bound GEMM each: two streams)
+                    if os.environ.get('ASR_PIPE_TAIL_FORK', '1') != '0':
+                        ev0 = torch.cuda.Event()
+                        ev0.record(main)
+                        with torch.cuda.stream(self._pipe):
+                            self._pipe.wait_event(ev0)
+                            self._dx_gemm_dir(dz, s, dx, BW, 0, (T - S) * n_pad, n_pad, zmx, 0, 1.0)
+                            ev1 = torch.cuda.Event()
+                            ev1.record(self._pipe)
+                        self._dx_gemm_dir(dz, s, dx, BW, S * n_pad, rows, n_pad, zmx, 1, 1.0)
+                        main.wait_event(ev1)
+                    else:
+                        self._dx_gemm_dir(dz, s, dx, BW, S * n_pad, rows, n_pad, zmx, 1, 1.0)
+                        self._dx_gemm_dir(dz, s, dx, BW, 0, (T - S) * n_pad, n_pad, zmx, 0, 1.0)
                     da = dx
                 elif pipe_b:
                     self._dx_gemm(dz, s, dx, BW, 0, (T - S) * n_pad, n_pad, zmx)
