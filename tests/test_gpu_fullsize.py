@@ -169,3 +169,24 @@ def test_compact_bptt_under_uneven_load_at_full_size_is_bit_identical():
         ops.lstm_status(got[3])
         for a, b in zip(got[:3], want[:3]):
             assert torch.equal(a, b), rep
+
+
+@pytest.mark.timeout(300)
+def test_configs2_as_written_runs_its_first_steps_without_a_vetoed_step():
+    """Regression (round 6): with BPTT writing dz as packed planes the first bound policy (8 x the
+    measured maximum, followed at once) vetoed a step in EVERY run of configs[2] as written -- the
+    gate gradients of the layer above the conv front-end jump ~800 x between the first two steps
+    and fall ~5000 x in the third.  bench.py asserts `no timeout / fallback during the timed
+    steps`: eight steps from fresh weights must pass it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', 'cfg3_conv',
+                          '--steps', '6', '--warmup', '2', '--no-cpu-baseline', '--no-extras'],
+                         cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280,
+                         stdin=subprocess.DEVNULL)
+    assert out.returncode == 0, out.stderr.decode()[-1500:]
+    line = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')][-1])
+    assert line['fallbacks'] == 0 and line['config']['workload'].startswith('cfg3')
